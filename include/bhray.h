@@ -1,0 +1,301 @@
+/*
+ * bhray.h — C ABI of libbhray: the MI355X-native geodesic ray-trace pass.
+ *
+ * This is the drop-in boundary for ONE path of cleggacus/bhusie: the ray pass that the
+ * reference runs as `RayPipeline` (src/renderer/pipelines/ray_pipeline.rs:28-310) over the
+ * compute shader src/renderer/shaders/ray.wgsl:1-847, driven by `Renderer::new/render`
+ * (src/renderer/mod.rs:170-207, 378-420).  The Rust host keeps its window, UI and scene graph
+ * and calls these functions instead of wgpu for the ray pass (binding stub: INTEGRATION.md).
+ *
+ * Conventions
+ *   - every function returns 0 (BHRAY_OK) or a negative BHRAY_E_* code; nothing unwinds or
+ *     aborts across the boundary (the reference panics: mod.rs:66,75,89; model.rs:17).
+ *   - all pointer arguments are borrowed for the duration of the call only.
+ *   - a ctx is used from one thread at a time (the reference is single-threaded: app.rs:108-114).
+ *   - byte layouts of the uniform blocks are the reference's #[repr(C)] structs, so the host
+ *     passes `bytemuck::bytes_of(..)` unchanged.
+ *   - there is NO CPU fallback: bhray_create fails with BHRAY_E_NO_DEVICE when no gfx950
+ *     device is usable.
+ */
+#ifndef BHRAY_H
+#define BHRAY_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BHRAY_VERSION_MAJOR 0
+#define BHRAY_VERSION_MINOR 1
+
+/* ------------------------------------------------------------------------------------------
+ * Error codes
+ * ---------------------------------------------------------------------------------------- */
+enum {
+    BHRAY_OK            = 0,
+    BHRAY_E_INVALID     = -1,  /* bad argument / bad config                                  */
+    BHRAY_E_NO_DEVICE   = -2,  /* no usable HIP device (no CPU fallback exists)              */
+    BHRAY_E_HIP         = -3,  /* a HIP runtime call failed; see bhray_last_error            */
+    BHRAY_E_NOMEM       = -4,
+    BHRAY_E_STATE       = -5,  /* call order violated (e.g. render before set_uniforms)      */
+    BHRAY_E_BVH_DEPTH   = -6,  /* BVH deeper than BHRAY_BVH_STACK                            */
+    BHRAY_E_IO          = -7,  /* file could not be read / parsed (OBJ loader)               */
+    BHRAY_E_CAPACITY    = -8   /* model exceeds the reference's fixed capacities             */
+};
+
+/* ------------------------------------------------------------------------------------------
+ * Byte layouts shared with the reference (all little-endian, f32 = IEEE binary32)
+ * ---------------------------------------------------------------------------------------- */
+
+/* RayDetails — src/renderer/pipelines/ray_pipeline.rs:3-14  ⇄  ray.wgsl:25-34 (`Details`). */
+typedef struct bhray_details {
+    int32_t material_count;
+    int32_t model_count;
+    float   time;
+    int32_t integration_method;        /* 0 Euler, 1 "Runge Kutta" (Cash–Karp), ray.wgsl:29 */
+    float   step_size;
+    int32_t max_iterations;
+    float   angle_division_threshold;
+    int32_t highlight_interpolation;   /* no-op in the reference, ray.wgsl:230-234          */
+} bhray_details;                        /* 32 B */
+
+/* CameraUniform — src/scene/camera.rs:66-73  ⇄  ray.wgsl:41-45. */
+typedef struct bhray_camera_uniform {
+    float    position[3];
+    uint32_t _padding;
+    float    forward[3];
+    float    fov;
+} bhray_camera_uniform;                 /* 32 B */
+
+/* BlackHoleUniform — src/scene/blackhole.rs:37-51  ⇄  ray.wgsl:112-123. */
+typedef struct bhray_black_hole_uniform {
+    float   accretion_disk_inner;
+    float   accretion_disk_outer;
+    float   rotation_speed;
+    float   relativity_sphere_radius;
+    float   position[3];
+    int32_t show_disk_texture;
+    float   normal[3];
+    int32_t show_red_shift;
+    float   rotation_matrix[12];        /* 3 columns, each padded to vec4 (mat3x3 in WGSL)  */
+    float   feather_amount;
+    int32_t pad[8];
+} bhray_black_hole_uniform;             /* 132 B */
+
+/* NodeUniform — src/renderer/triangle.rs:45-52  ⇄  ray.wgsl:85-90. */
+typedef struct bhray_node {
+    float   min_corner[3];
+    int32_t left_child;                 /* inner: index of first child (second = +1); leaf: first bvh_lookup slot */
+    float   max_corner[3];
+    int32_t obj_count;                  /* 0 ⇒ inner node                                   */
+} bhray_node;                           /* 32 B */
+
+/* Triangle (index record) — src/renderer/triangle.rs:54-63  ⇄  ray.wgsl:67-74. */
+typedef struct bhray_triangle {
+    int32_t p1, p2, p3;
+    int32_t n1, n2, n3;
+} bhray_triangle;                       /* 24 B */
+
+/* ModelUniform — src/renderer/triangle.rs:268-285; the storage buffer bound at ray.wgsl:9.
+ * Fixed capacity arrays; byte offsets below are asserted in bhray_layout.cpp.              */
+#define BHRAY_MAX_MODEL_VERTICES 524288  /* triangle.rs:7, ray.wgsl:1 */
+#define BHRAY_MAX_MODELS         1       /* triangle.rs:6, ray.wgsl:2 */
+#define BHRAY_MAX_MATERIALS      8       /* material.rs:3, ray.wgsl:3 */
+#define BHRAY_MODEL_UNIFORM_BYTES 48234572u
+#define BHRAY_MODEL_OFF_POINTS    48u
+#define BHRAY_MODEL_OFF_NORMALS   (48u + 16u * BHRAY_MAX_MODEL_VERTICES)
+#define BHRAY_MODEL_OFF_TRIANGLES (48u + 32u * BHRAY_MAX_MODEL_VERTICES)
+#define BHRAY_MODEL_OFF_NODES     (48u + 56u * BHRAY_MAX_MODEL_VERTICES)
+#define BHRAY_MODEL_OFF_LOOKUP    (48u + 88u * BHRAY_MAX_MODEL_VERTICES)
+
+typedef struct bhray_model_header {     /* first 48 bytes of ModelUniform (Rust field order) */
+    float    position[3];
+    int32_t  visible;
+    float    rotation[3];               /* uploaded, never applied by the shader (ray.wgsl:56) */
+    uint32_t pad3;
+    int32_t  point_count;
+    int32_t  normal_count;
+    int32_t  triangle_count;
+    uint32_t pad0;
+} bhray_model_header;                   /* 48 B */
+
+/* Compact model: the same arrays, sized to the actual counts (what stays resident in HBM). */
+typedef struct bhray_model_desc {
+    float                 position[3];
+    int32_t               visible;
+    const float*          points;       /* point_count  × 4 f32 (xyz + pad)                 */
+    const float*          normals;      /* normal_count × 4 f32                             */
+    const bhray_triangle* triangles;    /* triangle_count                                    */
+    const bhray_node*     nodes;        /* node_count                                        */
+    const int32_t*        bvh_lookup;   /* triangle_count                                    */
+    int32_t point_count, normal_count, triangle_count, node_count;
+} bhray_model_desc;
+
+/* ------------------------------------------------------------------------------------------
+ * Context configuration
+ * ---------------------------------------------------------------------------------------- */
+#define BHRAY_MAX_LEVELS 8
+#define BHRAY_BVH_STACK  64            /* reference: 19 whole nodes, no overflow check (ray.wgsl:292) */
+
+enum {                                  /* bhray_config.flags */
+    BHRAY_F_COUNTERS   = 1u << 0,       /* kernels also accumulate bhray_counters (slower)   */
+    BHRAY_F_TIMING     = 1u << 1        /* record HIP events around every launch             */
+};
+
+/* The ladder is the reference's chain of RayPipelines (mod.rs:170-207): level 0 traces every
+ * pixel (its t_prev is the 1×1 base texture, ray.wgsl:178), level k>0 reads level k-1.
+ * The delivered frame is the window [crop_x, crop_x+frame_w) × [crop_y, crop_y+frame_h) of
+ * the last level; pixels outside it (and coarse pixels no window pixel depends on) are not
+ * computed.  With crop = 0 and frame = last level size this is exactly the reference.
+ *
+ * Row partition (multi-GPU row tiling): frame row r belongs to partition
+ * (r / stripe_rows) % row_world; this ctx renders only rows of partition row_rank and packs
+ * them densely, in increasing r, into its output buffer.  row_world = 1 ⇒ the whole frame. */
+typedef struct bhray_config {
+    uint32_t struct_size;               /* = sizeof(bhray_config)                            */
+    int32_t  device;                    /* HIP device ordinal                                */
+    uint32_t levels;                    /* 1..BHRAY_MAX_LEVELS                               */
+    uint32_t level_w[BHRAY_MAX_LEVELS];
+    uint32_t level_h[BHRAY_MAX_LEVELS];
+    uint32_t crop_x, crop_y;
+    uint32_t frame_w, frame_h;
+    uint32_t row_rank, row_world, stripe_rows;
+    uint32_t flags;
+} bhray_config;
+
+/* Reference ladder rule `r ← r·m − (m−1)` (mod.rs:177-205): fills level_w/h[0..levels).    */
+int bhray_ladder_from_base(uint32_t base_w, uint32_t base_h, uint32_t multiplier,
+                           uint32_t levels, bhray_config* cfg);
+/* Smallest reference-rule ladder whose last level covers frame_w × frame_h; the frame is the
+ * centred window of it.  1918×1081/levels 4 gives base 72×41, crop 0 — the shipped config.  */
+int bhray_ladder_for_frame(uint32_t frame_w, uint32_t frame_h, uint32_t multiplier,
+                           uint32_t levels, bhray_config* cfg);
+
+/* ------------------------------------------------------------------------------------------
+ * Lifecycle — replaces RayPipeline::new ×levels (ray_pipeline.rs:36-295, mod.rs:181-207)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct bhray_ctx bhray_ctx;
+
+int  bhray_create(const bhray_config* cfg, bhray_ctx** out);
+void bhray_destroy(bhray_ctx* ctx);
+const char* bhray_last_error(const bhray_ctx* ctx);   /* ctx may be NULL: last create error  */
+const char* bhray_strerror(int code);
+uint32_t    bhray_version(void);                      /* major<<16 | minor                   */
+int  bhray_device_count(void);                        /* usable gfx950 devices, ≥0           */
+
+/* Static inputs — replaces the include_bytes! textures (ray_pipeline.rs:63-70) and
+ * texture.rs:16-69 semantics: RGBA8 unorm, no sRGB decode, bilinear, clamp-to-edge, 1 mip.  */
+enum { BHRAY_TEX_TEMP_LUT = 0,   /* binding 7  color.png */
+       BHRAY_TEX_DISK     = 1,   /* binding 9  disk.png  */
+       BHRAY_TEX_SKY      = 2 }; /* binding 12 sky.png   */
+int bhray_set_texture(bhray_ctx* ctx, int slot, const uint8_t* rgba8, uint32_t w, uint32_t h);
+
+/* Model upload — replaces `scene.models.create_buffer/update_buffer` (mod.rs:114,391,
+ * array_buffer.rs:71-89).  Either the exact 48 234 572-byte ModelUniform or the compact form. */
+int bhray_upload_model_uniform(bhray_ctx* ctx, uint32_t model_index, const void* bytes, size_t size);
+int bhray_upload_model(bhray_ctx* ctx, uint32_t model_index, const bhray_model_desc* desc);
+/* Per-frame model state without re-uploading 48 MB (the reference re-uploads, mod.rs:391).  */
+int bhray_set_model_transform(bhray_ctx* ctx, uint32_t model_index, const float position[3], int32_t visible);
+
+/* Per-frame uniforms — replaces queue.write_buffer ×3 (mod.rs:386-388).                      */
+int bhray_set_uniforms(bhray_ctx* ctx, const void* camera_uniform_32,
+                       const void* black_hole_uniform_132, const void* ray_details_32);
+
+/* Dispatch — replaces `for rp in ray_pipelines { rp.pass() }` (mod.rs:415-417,
+ * ray_pipeline.rs:301-309).  Asynchronous on the ctx stream; levels ordered.                 */
+int bhray_render(bhray_ctx* ctx);
+int bhray_sync(bhray_ctx* ctx);
+
+/* Output — replaces RayPipeline::output_view (ray_pipeline.rs:297-299): RGBA32F,
+ * row 0 = top, x fastest (textureStore(screen_pos), ray.wgsl:182).  Rows of this ctx's
+ * partition only, packed; local_rows = bhray_local_rows().  Synchronises the stream.        */
+int bhray_read_hdr(bhray_ctx* ctx, float* dst_rgba32f, size_t row_pitch_bytes);
+/* Any ladder level, full size level_w×level_h (unrendered pixels are NaN-filled at create).  */
+int bhray_read_level(bhray_ctx* ctx, uint32_t level, float* dst_rgba32f, size_t row_pitch_bytes);
+uint32_t bhray_local_rows(const bhray_ctx* ctx);
+/* frame row index of packed row i (0 ≤ i < local_rows).                                      */
+int bhray_local_row_index(const bhray_ctx* ctx, uint32_t i, uint32_t* frame_row);
+
+/* Zero-copy consumers (sky pass, RCCL gather).  The output buffer holds
+ * local_rows × frame_w × 4 f32.  bhray_bind_output lets the caller supply device memory
+ * (e.g. a slice of the gather buffer) that subsequent renders write into; NULL restores the
+ * ctx-owned buffer.                                                                          */
+int bhray_hdr_device_ptr(bhray_ctx* ctx, void** dev_ptr, size_t* bytes);
+int bhray_bind_output(bhray_ctx* ctx, void* dev_ptr, size_t bytes);
+/* The hipStream_t all work is enqueued on; bhray_set_stream(NULL) restores the ctx's own.   */
+int bhray_get_stream(bhray_ctx* ctx, void** hip_stream);
+int bhray_set_stream(bhray_ctx* ctx, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement
+ * ---------------------------------------------------------------------------------------- */
+typedef struct bhray_counters {        /* summed over all levels of the last render          */
+    uint64_t pixels;                   /* pixels written (all levels)                        */
+    uint64_t copied;                   /* grid: copied from the coarser level (ray.wgsl:193) */
+    uint64_t interpolated;             /* grid: bilinear mix of directions (ray.wgsl:217)    */
+    uint64_t traced;                   /* pixels that ran trace_ray                          */
+    uint64_t steps;                    /* relativity iterations (integrator steps)           */
+    uint64_t flat_iters;               /* flat-space iterations                              */
+    uint64_t node_pairs;               /* BVH inner-node visits (2 AABB tests each)          */
+    uint64_t triangles;                /* hit_triangle calls                                 */
+    uint64_t disk_hits;                /* accretion-disk shading events                      */
+    uint64_t sky_samples;              /* in-kernel sky taps (ray.wgsl:587)                  */
+} bhray_counters;
+int bhray_get_counters(bhray_ctx* ctx, bhray_counters* out);   /* needs BHRAY_F_COUNTERS     */
+
+typedef struct bhray_timing {
+    float    total_ms;                 /* first launch → last launch of the last render      */
+    float    trace_ms;                 /* Σ trace kernels                                    */
+    float    classify_ms;              /* Σ grid classify kernels                            */
+    uint32_t trace_launches;
+    uint32_t classify_launches;
+    float    level_trace_ms[BHRAY_MAX_LEVELS];
+} bhray_timing;
+int bhray_get_timing(bhray_ctx* ctx, bhray_timing* out);       /* needs BHRAY_F_TIMING       */
+
+/* ------------------------------------------------------------------------------------------
+ * Host-side scene helpers (C++ behind this ABI; mirror the Rust host code on the path)
+ * ---------------------------------------------------------------------------------------- */
+
+/* CameraUniform::update — camera.rs:84-88.                                                   */
+void bhray_camera_uniform_update(bhray_camera_uniform* u, const float position[3],
+                                 const float forward[3], float fov);
+/* BlackHoleUniform::update — blackhole.rs:68-98 (cgmath Euler→quaternion, rotate (0,-1,0),
+ * right = z × up, forward = right × up).                                                     */
+typedef struct bhray_black_hole {      /* scene::BlackHole, blackhole.rs:3-13                 */
+    float   position[3];
+    float   accretion_disk_rotation[3];
+    float   accretion_disk_inner, accretion_disk_outer;
+    float   rotation_speed;
+    float   relativity_sphere_radius;
+    int32_t show_disk_texture, show_red_shift;
+    float   feather_amount;
+} bhray_black_hole;
+void bhray_black_hole_default(bhray_black_hole* bh);            /* blackhole.rs:16-28          */
+void bhray_black_hole_uniform_update(bhray_black_hole_uniform* u, const bhray_black_hole* bh);
+void bhray_details_default(bhray_details* d);                   /* mod.rs:116-121              */
+
+/* Model + BVH builder — triangle.rs:65-259 (`Model::{new,add_*,build_bvh}`), growable storage
+ * but the reference's capacity limit (524 288 per array) is enforced.                         */
+typedef struct bhray_model bhray_model;
+int  bhray_model_new(bhray_model** out);                        /* position (-10,0,30), visible 1 */
+void bhray_model_free(bhray_model* m);
+int  bhray_model_add_vertex(bhray_model* m, const float p[4]);
+int  bhray_model_add_normal(bhray_model* m, const float n[4]);
+int  bhray_model_add_triangle(bhray_model* m, const bhray_triangle* t);
+int  bhray_model_build_bvh(bhray_model* m);                     /* triangle.rs:143-259         */
+int  bhray_model_max_depth(const bhray_model* m);               /* deepest leaf, root = 1      */
+int  bhray_model_desc_get(const bhray_model* m, bhray_model_desc* out); /* borrowed pointers   */
+int  bhray_model_set_transform(bhray_model* m, const float position[3], int32_t visible);
+/* Writes the exact ModelUniform image (BHRAY_MODEL_UNIFORM_BYTES) — triangle.rs:308-325.     */
+int  bhray_model_pack_uniform(const bhray_model* m, void* dst, size_t size);
+/* load_model — model.rs:7-87: OBJ (v / vn / f, triangles only) → scaled (0.5,-0.5,0.5),
+ * flat-normal fallback, then build_bvh.                                                      */
+int  bhray_load_model(const char* obj_path, bhray_model** out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BHRAY_H */
