@@ -1,0 +1,15 @@
+"""bhusie_amd — MI355X-native geodesic ray-trace pass behind the reference's RayPipeline surface.
+
+The product is libbhray.so (hand-written gfx950 HIP kernels + a C ABI, include/bhray.h).  This
+package is the thin Python host side used by the tests and bench: ctypes bindings plus mirrors of
+the reference host types on the path (RayDetails, CameraUniform, BlackHoleUniform, Model,
+RayPipeline ladder).  Nothing here computes pixels on the CPU; importing the bindings fails loudly
+when the HIP library has not been built.
+"""
+from ._lib import lib, LibraryMissing, LIB_PATH  # noqa: F401
+from .layouts import (BhrayConfig, BhrayCounters, BhrayTiming, BhrayDetails, BhrayCameraUniform,  # noqa: F401
+                      BhrayBlackHoleUniform, BhrayBlackHole, BhrayModelDesc, BhrayNode, BhrayTriangle,
+                      BhrayError, check)
+from .scene import Camera, BlackHole, RayDetails  # noqa: F401
+from .model import Model, load_model  # noqa: F401
+from .renderer import RayPass, Renderer, ladder_from_base, ladder_for_frame  # noqa: F401

@@ -1,0 +1,627 @@
+// bhray_api.hip — the C ABI of include/bhray.h on top of the gfx950 kernels.
+//
+// Plays the role of RayPipeline::{new,pass,output_view}
+// (/root/reference/src/renderer/pipelines/ray_pipeline.rs:36-309) and of the ladder / per-frame
+// upload code in Renderer::{new,render} (src/renderer/mod.rs:113-207, 378-420).
+// All device memory is owned here; there is no CPU rendering path.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "bhray_internal.h"
+#include "bhray_math.h"
+
+using namespace bhray;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Level {
+    int w = 0, h = 0;
+    float4* out = nullptr;          // full w*h for non-final levels
+    std::vector<int32_t> rows;      // rows to compute
+    int32_t* d_rows = nullptr;
+    int32_t* d_rowmap = nullptr;    // final level only
+    uint32_t* queue = nullptr;
+    size_t queue_cap = 0;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // before classify, before trace, after trace
+};
+
+struct ModelStore {
+    float pos[3] = {0, 0, 0};
+    int visible = 0;
+    float4* points = nullptr; float4* normals = nullptr; int32_t* triangles = nullptr;
+    float4* nodes = nullptr; int32_t* lookup = nullptr;
+    int point_count = 0, normal_count = 0, triangle_count = 0, node_count = 0;
+    bool loaded = false;
+};
+
+}  // namespace
+
+struct bhray_ctx {
+    bhray_config cfg{};
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::vector<Level> levels;
+    // output
+    float4* own_out = nullptr;
+    float4* out = nullptr;
+    size_t out_bytes = 0;
+    std::vector<uint32_t> local_rows;      // frame rows of this partition, increasing
+    // scene
+    uint8_t* tex[3] = {nullptr, nullptr, nullptr};
+    int tex_w[3] = {0, 0, 0}, tex_h[3] = {0, 0, 0};
+    ModelStore models[BHRAY_MAX_MODELS];
+    bhray_camera_uniform cam{};
+    bhray_black_hole_uniform bh{};
+    bhray_details det{};
+    bool have_uniforms = false;
+    // work queues
+    uint32_t* d_qctl = nullptr;            // [2*levels]: qcount[l], qhead[l]
+    Counters64* d_counters = nullptr;
+    int* d_err = nullptr;
+    int num_cus = 256;
+    bool rendered = false;
+    std::string err;
+};
+
+namespace {
+
+int fail(bhray_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                             \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) return fail(ctx, BHRAY_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+// rows of level k-1 that the rows `fine` of level k read (ray.wgsl:185-201), same binary32 math
+std::vector<int32_t> coarse_rows_needed(const std::vector<int32_t>& fine, int h, int ph) {
+    std::vector<uint8_t> need((size_t)ph, 0);
+    if (ph == 1) return {};
+    const int sf = (h - 1) / (ph - 1);
+    const float ry = (float)ph / (float)(h + (sf - 1));
+    for (int32_t y : fine) {
+        const float ppy = (float)y * ry;
+        int tl = (int)floorf(ppy);
+        int a = tl < 0 ? 0 : (tl > ph - 1 ? ph - 1 : tl);
+        int b = tl + 1; b = b < 0 ? 0 : (b > ph - 1 ? ph - 1 : b);
+        need[(size_t)a] = 1; need[(size_t)b] = 1;
+    }
+    std::vector<int32_t> out;
+    for (int y = 0; y < ph; y++) if (need[(size_t)y]) out.push_back(y);
+    return out;
+}
+
+void derive_frame(const bhray_ctx* c, FrameParams& P) {
+    memset(&P, 0, sizeof P);
+    const bhray_camera_uniform& cam = c->cam;
+    const bhray_black_hole_uniform& bh = c->bh;
+    const bhray_details& d = c->det;
+    const F3 fwd = ld3(cam.forward);
+    const F3 plane_up = f3(0.0f, -1.0f, 0.0f);
+    const F3 right = normalize(cross(fwd, plane_up));               // ray.wgsl:276
+    const F3 up = normalize(cross(fwd, right));                     // ray.wgsl:277
+    const float fov_factor = 1.0f / tanf(cam.fov / 2.0f);           // ray.wgsl:279
+    const F3 fwd_ff = fwd * fov_factor;
+    const F3 cpos = ld3(cam.position), bpos = ld3(bh.position);
+    P.cam[0] = cpos.x; P.cam[1] = cpos.y; P.cam[2] = cpos.z;
+    P.right[0] = right.x; P.right[1] = right.y; P.right[2] = right.z;
+    P.up[0] = up.x; P.up[1] = up.y; P.up[2] = up.z;
+    P.fwd_ff[0] = fwd_ff.x; P.fwd_ff[1] = fwd_ff.y; P.fwd_ff[2] = fwd_ff.z;
+    P.ray_distance = distance(cpos, bpos);
+    P.relativity0 = P.ray_distance < bh.relativity_sphere_radius ? 1 : 0;
+    P.bh[0] = bpos.x; P.bh[1] = bpos.y; P.bh[2] = bpos.z;
+    memcpy(P.bn, bh.normal, 12);
+    P.inner = bh.accretion_disk_inner; P.outer = bh.accretion_disk_outer;
+    P.rot_speed = bh.rotation_speed; P.R = bh.relativity_sphere_radius;
+    P.show_tex = bh.show_disk_texture; P.show_shift = bh.show_red_shift;
+    for (int col = 0; col < 3; col++) for (int r = 0; r < 3; r++) P.M[3 * col + r] = bh.rotation_matrix[4 * col + r];
+    P.feather = bh.feather_amount;
+    P.time = d.time; P.method = d.integration_method != 0 ? 1 : 0; P.step_size = d.step_size;
+    P.max_iter = d.max_iterations; P.thr = d.angle_division_threshold;
+    int mc = d.model_count; if (mc < 0) mc = 0; if (mc > BHRAY_MAX_MODELS) mc = BHRAY_MAX_MODELS;
+    int usable = 0;
+    for (int i = 0; i < mc; i++) {
+        const ModelStore& m = c->models[i];
+        ModelDev& md = P.models[i];
+        memcpy(md.pos, m.pos, 12);
+        md.visible = (m.loaded && m.triangle_count > 0) ? m.visible : 0;
+        md.points = m.points; md.normals = m.normals; md.triangles = m.triangles; md.nodes = m.nodes; md.lookup = m.lookup;
+        md.node_count = m.node_count;
+        usable = i + 1;
+    }
+    P.model_count = usable;
+    bool any_visible = false;
+    for (int i = 0; i < usable; i++) any_visible |= P.models[i].visible != 0;
+    if (!any_visible) P.model_count = 0;     // nothing to traverse: the no-mesh kernel variant is exact
+    TexDev* t[3] = {&P.temp, &P.disk, &P.sky};
+    for (int i = 0; i < 3; i++) { t[i]->rgba = c->tex[i]; t[i]->w = c->tex_w[i]; t[i]->h = c->tex_h[i]; }
+}
+
+void free_model(ModelStore& m) {
+    if (m.points) (void)hipFree(m.points);
+    if (m.normals) (void)hipFree(m.normals);
+    if (m.triangles) (void)hipFree(m.triangles);
+    if (m.nodes) (void)hipFree(m.nodes);
+    if (m.lookup) (void)hipFree(m.lookup);
+    m = ModelStore();
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* bhray_strerror(int code) {
+    switch (code) {
+        case BHRAY_OK: return "ok";
+        case BHRAY_E_INVALID: return "invalid argument";
+        case BHRAY_E_NO_DEVICE: return "no usable HIP device";
+        case BHRAY_E_HIP: return "HIP runtime error";
+        case BHRAY_E_NOMEM: return "out of memory";
+        case BHRAY_E_STATE: return "call order violated";
+        case BHRAY_E_BVH_DEPTH: return "BVH deeper than the traversal stack";
+        case BHRAY_E_IO: return "I/O or parse error";
+        case BHRAY_E_CAPACITY: return "model exceeds reference capacity";
+        default: return "unknown error";
+    }
+}
+
+uint32_t bhray_version(void) { return (BHRAY_VERSION_MAJOR << 16) | BHRAY_VERSION_MINOR; }
+
+const char* bhray_last_error(const bhray_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int bhray_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int bhray_ladder_from_base(uint32_t base_w, uint32_t base_h, uint32_t m, uint32_t levels, bhray_config* cfg) {
+    if (!cfg || levels < 1 || levels > BHRAY_MAX_LEVELS || base_w < 2 || base_h < 2 || m < 2) return BHRAY_E_INVALID;
+    uint64_t w = base_w, h = base_h;
+    for (uint32_t i = 0; i < levels; i++) {
+        if (w > 65535 || h > 65535) return BHRAY_E_INVALID;          // queue entries pack (y<<16)|x
+        cfg->level_w[i] = (uint32_t)w; cfg->level_h[i] = (uint32_t)h;
+        w = w * m - (m - 1); h = h * m - (m - 1);                    // mod.rs:203-204
+    }
+    cfg->levels = levels;
+    cfg->crop_x = 0; cfg->crop_y = 0;
+    cfg->frame_w = cfg->level_w[levels - 1]; cfg->frame_h = cfg->level_h[levels - 1];
+    if (cfg->row_world == 0) { cfg->row_world = 1; cfg->row_rank = 0; }
+    if (cfg->stripe_rows == 0) cfg->stripe_rows = 27;
+    cfg->struct_size = sizeof(bhray_config);
+    return BHRAY_OK;
+}
+
+int bhray_ladder_for_frame(uint32_t frame_w, uint32_t frame_h, uint32_t m, uint32_t levels, bhray_config* cfg) {
+    if (!cfg || levels < 1 || levels > BHRAY_MAX_LEVELS || frame_w < 2 || frame_h < 2 || m < 2) return BHRAY_E_INVALID;
+    uint64_t s = 1;
+    for (uint32_t i = 1; i < levels; i++) s *= m;                    // last = (base-1)*m^(levels-1) + 1
+    const uint64_t bw = (frame_w - 1 + s - 1) / s + 1, bh_ = (frame_h - 1 + s - 1) / s + 1;
+    int rc = bhray_ladder_from_base((uint32_t)(bw < 2 ? 2 : bw), (uint32_t)(bh_ < 2 ? 2 : bh_), m, levels, cfg);
+    if (rc) return rc;
+    const uint32_t lw = cfg->level_w[levels - 1], lh = cfg->level_h[levels - 1];
+    cfg->crop_x = (lw - frame_w) / 2; cfg->crop_y = (lh - frame_h) / 2;
+    cfg->frame_w = frame_w; cfg->frame_h = frame_h;
+    return BHRAY_OK;
+}
+
+void bhray_destroy(bhray_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (Level& L : c->levels) {
+        if (L.out) (void)hipFree(L.out);
+        if (L.d_rows) (void)hipFree(L.d_rows);
+        if (L.d_rowmap) (void)hipFree(L.d_rowmap);
+        if (L.queue) (void)hipFree(L.queue);
+        for (auto& e : L.ev) if (e) (void)hipEventDestroy(e);
+    }
+    if (c->own_out) (void)hipFree(c->own_out);
+    for (auto& t : c->tex) if (t) (void)hipFree(t);
+    for (auto& m : c->models) free_model(m);
+    if (c->d_qctl) (void)hipFree(c->d_qctl);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_err) (void)hipFree(c->d_err);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
+    if (!cfg || !out) return fail(nullptr, BHRAY_E_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(bhray_config)) return fail(nullptr, BHRAY_E_INVALID, "bhray_config.struct_size mismatch");
+    if (cfg->levels < 1 || cfg->levels > BHRAY_MAX_LEVELS) return fail(nullptr, BHRAY_E_INVALID, "levels out of range");
+    for (uint32_t i = 0; i < cfg->levels; i++)
+        if (cfg->level_w[i] < 2 || cfg->level_h[i] < 2 || cfg->level_w[i] > 65535 || cfg->level_h[i] > 65535)
+            return fail(nullptr, BHRAY_E_INVALID, "level %u size %ux%u unsupported", i, cfg->level_w[i], cfg->level_h[i]);
+    const uint32_t lw = cfg->level_w[cfg->levels - 1], lh = cfg->level_h[cfg->levels - 1];
+    if (cfg->frame_w < 1 || cfg->frame_h < 1 || cfg->crop_x + cfg->frame_w > lw || cfg->crop_y + cfg->frame_h > lh)
+        return fail(nullptr, BHRAY_E_INVALID, "frame window outside the last level");
+    if (cfg->row_world < 1 || cfg->row_rank >= cfg->row_world || cfg->stripe_rows < 1)
+        return fail(nullptr, BHRAY_E_INVALID, "bad row partition");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, BHRAY_E_NO_DEVICE, "no HIP device visible (libbhray has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, BHRAY_E_NO_DEVICE, "device %d not present (%d visible)", cfg->device, ndev);
+
+    bhray_ctx* c = new (std::nothrow) bhray_ctx();
+    if (!c) return fail(nullptr, BHRAY_E_NOMEM, "host allocation failed");
+    c->cfg = *cfg;
+    c->device = cfg->device;
+#define CHK(call)                                                                                             \
+    do {                                                                                                      \
+        hipError_t e_ = (call);                                                                               \
+        if (e_ != hipSuccess) {                                                                               \
+            int rc_ = fail(nullptr, BHRAY_E_HIP, "%s: %s", #call, hipGetErrorString(e_));                     \
+            bhray_destroy(c);                                                                                 \
+            return rc_;                                                                                       \
+        }                                                                                                     \
+    } while (0)
+    CHK(hipSetDevice(c->device));
+    hipDeviceProp_t prop;
+    CHK(hipGetDeviceProperties(&prop, c->device));
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    CHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+
+    // rows of the frame owned by this partition
+    for (uint32_t r = 0; r < cfg->frame_h; r++)
+        if ((r / cfg->stripe_rows) % cfg->row_world == cfg->row_rank) c->local_rows.push_back(r);
+
+    const uint32_t nl = cfg->levels;
+    c->levels.resize(nl);
+    for (uint32_t l = 0; l < nl; l++) { c->levels[l].w = (int)cfg->level_w[l]; c->levels[l].h = (int)cfg->level_h[l]; }
+    // top-down row dependency
+    {
+        Level& F = c->levels[nl - 1];
+        for (uint32_t r : c->local_rows) F.rows.push_back((int32_t)(cfg->crop_y + r));
+        for (int l = (int)nl - 1; l > 0; l--)
+            c->levels[l - 1].rows = coarse_rows_needed(c->levels[l].rows, c->levels[l].h, c->levels[l - 1].h);
+    }
+    for (uint32_t l = 0; l < nl; l++) {
+        Level& L = c->levels[l];
+        const bool last = (l == nl - 1);
+        const size_t npix = (size_t)L.w * (size_t)L.h;
+        if (!last) {
+            CHK(hipMalloc(&L.out, npix * sizeof(float4)));
+            CHK(hipMemset(L.out, 0xFF, npix * sizeof(float4)));      // NaN: "never rendered"
+        }
+        const size_t nrows = L.rows.size();
+        if (nrows) {
+            CHK(hipMalloc(&L.d_rows, nrows * sizeof(int32_t)));
+            CHK(hipMemcpy(L.d_rows, L.rows.data(), nrows * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        const size_t span = last ? cfg->frame_w : (size_t)L.w;
+        L.queue_cap = nrows * span;
+        if (L.queue_cap) CHK(hipMalloc(&L.queue, L.queue_cap * sizeof(uint32_t)));
+        if (last) {
+            std::vector<int32_t> map((size_t)L.h, -1);
+            for (size_t i = 0; i < c->local_rows.size(); i++) map[(size_t)(cfg->crop_y + c->local_rows[i])] = (int32_t)i;
+            CHK(hipMalloc(&L.d_rowmap, (size_t)L.h * sizeof(int32_t)));
+            CHK(hipMemcpy(L.d_rowmap, map.data(), (size_t)L.h * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        if (cfg->flags & BHRAY_F_TIMING) for (auto& e : L.ev) CHK(hipEventCreate(&e));
+    }
+    c->out_bytes = c->local_rows.size() * (size_t)cfg->frame_w * sizeof(float4);
+    if (c->out_bytes) {
+        CHK(hipMalloc(&c->own_out, c->out_bytes));
+        CHK(hipMemset(c->own_out, 0xFF, c->out_bytes));
+    }
+    c->out = c->own_out;
+    CHK(hipMalloc(&c->d_qctl, 2 * BHRAY_MAX_LEVELS * sizeof(uint32_t)));
+    CHK(hipMemset(c->d_qctl, 0, 2 * BHRAY_MAX_LEVELS * sizeof(uint32_t)));
+    CHK(hipMalloc(&c->d_counters, sizeof(Counters64)));
+    CHK(hipMemset(c->d_counters, 0, sizeof(Counters64)));
+    CHK(hipMalloc(&c->d_err, sizeof(int)));
+    CHK(hipMemset(c->d_err, 0, sizeof(int)));
+    // 1x1 opaque-black defaults so a missing texture cannot fault
+    for (int s = 0; s < 3; s++) {
+        const uint8_t px[4] = {0, 0, 0, 255};
+        CHK(hipMalloc(&c->tex[s], 4));
+        CHK(hipMemcpy(c->tex[s], px, 4, hipMemcpyHostToDevice));
+        c->tex_w[s] = 1; c->tex_h[s] = 1;
+    }
+#undef CHK
+    *out = c;
+    return BHRAY_OK;
+}
+
+int bhray_set_texture(bhray_ctx* c, int slot, const uint8_t* rgba8, uint32_t w, uint32_t h) {
+    if (!c) return BHRAY_E_INVALID;
+    if (slot < 0 || slot > 2 || !rgba8 || w < 1 || h < 1 || w > 32768 || h > 32768) return fail(c, BHRAY_E_INVALID, "bad texture arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint8_t* d = nullptr;
+    const size_t bytes = (size_t)w * h * 4;
+    HIPCHK(c, hipMalloc(&d, bytes));
+    hipError_t e = hipMemcpy(d, rgba8, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); return fail(c, BHRAY_E_HIP, "texture upload: %s", hipGetErrorString(e)); }
+    if (c->tex[slot]) (void)hipFree(c->tex[slot]);
+    c->tex[slot] = d; c->tex_w[slot] = (int)w; c->tex_h[slot] = (int)h;
+    return BHRAY_OK;
+}
+
+int bhray_upload_model(bhray_ctx* c, uint32_t mi, const bhray_model_desc* d) {
+    if (!c) return BHRAY_E_INVALID;
+    if (mi >= BHRAY_MAX_MODELS || !d) return fail(c, BHRAY_E_INVALID, "bad model arguments");
+    if (d->point_count < 0 || d->normal_count < 0 || d->triangle_count < 0 || d->node_count < 0 ||
+        d->point_count > BHRAY_MAX_MODEL_VERTICES || d->normal_count > BHRAY_MAX_MODEL_VERTICES ||
+        d->triangle_count > BHRAY_MAX_MODEL_VERTICES || d->node_count > BHRAY_MAX_MODEL_VERTICES)
+        return fail(c, BHRAY_E_CAPACITY, "model exceeds MAX_MODEL_VERTICES (triangle.rs:7)");
+    if (d->triangle_count > 0 && (!d->points || !d->normals || !d->triangles || !d->nodes || !d->bvh_lookup || d->node_count < 1))
+        return fail(c, BHRAY_E_INVALID, "model arrays missing");
+    // validate indices so the kernel never reads out of bounds
+    for (int i = 0; i < d->triangle_count; i++) {
+        const bhray_triangle& t = d->triangles[i];
+        if (t.p1 < 0 || t.p2 < 0 || t.p3 < 0 || t.p1 >= d->point_count || t.p2 >= d->point_count || t.p3 >= d->point_count ||
+            t.n1 < 0 || t.n2 < 0 || t.n3 < 0 || t.n1 >= d->normal_count || t.n2 >= d->normal_count || t.n3 >= d->normal_count)
+            return fail(c, BHRAY_E_INVALID, "triangle %d has an index out of range", i);
+        if (d->bvh_lookup[i] < 0 || d->bvh_lookup[i] >= d->triangle_count) return fail(c, BHRAY_E_INVALID, "bvh_lookup[%d] out of range", i);
+    }
+    for (int i = 0; i < d->node_count; i++) {
+        const bhray_node& n = d->nodes[i];
+        if (n.obj_count < 0) return fail(c, BHRAY_E_INVALID, "node %d: negative obj_count", i);
+        if (n.obj_count == 0) {
+            if (n.left_child < 1 || n.left_child + 1 >= d->node_count)
+                return fail(c, BHRAY_E_INVALID, "node %d: children out of range", i);
+        } else if (n.left_child < 0 || (int64_t)n.left_child + n.obj_count > d->triangle_count) {
+            return fail(c, BHRAY_E_INVALID, "node %d: leaf range out of bounds", i);
+        }
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    ModelStore& m = c->models[mi];
+    free_model(m);
+    memcpy(m.pos, d->position, 12);
+    m.visible = d->visible;
+    m.point_count = d->point_count; m.normal_count = d->normal_count; m.triangle_count = d->triangle_count; m.node_count = d->node_count;
+    if (d->triangle_count > 0) {
+        HIPCHK(c, hipMalloc(&m.points, (size_t)d->point_count * 16));
+        HIPCHK(c, hipMalloc(&m.normals, (size_t)d->normal_count * 16));
+        HIPCHK(c, hipMalloc(&m.triangles, (size_t)d->triangle_count * 24));
+        HIPCHK(c, hipMalloc(&m.nodes, (size_t)d->node_count * 32));
+        HIPCHK(c, hipMalloc(&m.lookup, (size_t)d->triangle_count * 4));
+        HIPCHK(c, hipMemcpy(m.points, d->points, (size_t)d->point_count * 16, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(m.normals, d->normals, (size_t)d->normal_count * 16, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(m.triangles, d->triangles, (size_t)d->triangle_count * 24, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(m.nodes, d->nodes, (size_t)d->node_count * 32, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(m.lookup, d->bvh_lookup, (size_t)d->triangle_count * 4, hipMemcpyHostToDevice));
+    }
+    m.loaded = true;
+    return BHRAY_OK;
+}
+
+int bhray_upload_model_uniform(bhray_ctx* c, uint32_t mi, const void* bytes, size_t size) {
+    if (!c) return BHRAY_E_INVALID;
+    if (!bytes || size != BHRAY_MODEL_UNIFORM_BYTES) return fail(c, BHRAY_E_INVALID, "ModelUniform must be %u bytes", BHRAY_MODEL_UNIFORM_BYTES);
+    const uint8_t* b = (const uint8_t*)bytes;
+    bhray_model_header hd; memcpy(&hd, b, sizeof hd);
+    bhray_model_desc d; memset(&d, 0, sizeof d);
+    memcpy(d.position, hd.position, 12); d.visible = hd.visible;
+    d.points = (const float*)(b + BHRAY_MODEL_OFF_POINTS);
+    d.normals = (const float*)(b + BHRAY_MODEL_OFF_NORMALS);
+    d.triangles = (const bhray_triangle*)(b + BHRAY_MODEL_OFF_TRIANGLES);
+    d.nodes = (const bhray_node*)(b + BHRAY_MODEL_OFF_NODES);
+    d.bvh_lookup = (const int32_t*)(b + BHRAY_MODEL_OFF_LOOKUP);
+    d.point_count = hd.point_count; d.triangle_count = hd.triangle_count;
+    if (d.triangle_count < 0 || d.triangle_count > BHRAY_MAX_MODEL_VERTICES || d.point_count < 0 || d.point_count > BHRAY_MAX_MODEL_VERTICES)
+        return fail(c, BHRAY_E_CAPACITY, "counts in ModelUniform header out of range");
+    // ModelUniform::update never copies normal_count (triangle.rs:308-325) and carries no node
+    // count: recover both from the index data.
+    int nmax = -1;
+    for (int i = 0; i < d.triangle_count; i++) {
+        const bhray_triangle& t = d.triangles[i];
+        nmax = t.n1 > nmax ? t.n1 : nmax; nmax = t.n2 > nmax ? t.n2 : nmax; nmax = t.n3 > nmax ? t.n3 : nmax;
+    }
+    if (nmax >= BHRAY_MAX_MODEL_VERTICES) return fail(c, BHRAY_E_INVALID, "normal index out of range");
+    d.normal_count = nmax + 1;
+    int node_max = 0;
+    if (d.triangle_count > 0) {
+        std::vector<int> st; st.push_back(0);
+        size_t visited = 0;
+        while (!st.empty()) {
+            int n = st.back(); st.pop_back();
+            if (n < 0 || n >= BHRAY_MAX_MODEL_VERTICES || ++visited > (size_t)BHRAY_MAX_MODEL_VERTICES) return fail(c, BHRAY_E_INVALID, "malformed BVH");
+            node_max = n > node_max ? n : node_max;
+            if (d.nodes[n].obj_count == 0) { st.push_back(d.nodes[n].left_child); st.push_back(d.nodes[n].left_child + 1); }
+        }
+    }
+    d.node_count = d.triangle_count > 0 ? node_max + 1 : 0;
+    return bhray_upload_model(c, mi, &d);
+}
+
+int bhray_set_model_transform(bhray_ctx* c, uint32_t mi, const float position[3], int32_t visible) {
+    if (!c) return BHRAY_E_INVALID;
+    if (mi >= BHRAY_MAX_MODELS || !position) return fail(c, BHRAY_E_INVALID, "bad model arguments");
+    memcpy(c->models[mi].pos, position, 12);
+    c->models[mi].visible = visible;
+    return BHRAY_OK;
+}
+
+int bhray_set_uniforms(bhray_ctx* c, const void* cam32, const void* bh132, const void* det32) {
+    if (!c) return BHRAY_E_INVALID;
+    if (!cam32 || !bh132 || !det32) return fail(c, BHRAY_E_INVALID, "null uniform block");
+    static_assert(sizeof(bhray_camera_uniform) == 32 && sizeof(bhray_black_hole_uniform) == 132 && sizeof(bhray_details) == 32, "layout");
+    memcpy(&c->cam, cam32, 32); memcpy(&c->bh, bh132, 132); memcpy(&c->det, det32, 32);
+    c->have_uniforms = true;
+    return BHRAY_OK;
+}
+
+int bhray_render(bhray_ctx* c) {
+    if (!c) return BHRAY_E_INVALID;
+    if (!c->have_uniforms) return fail(c, BHRAY_E_STATE, "bhray_set_uniforms has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    FrameParams P;
+    derive_frame(c, P);
+    const uint32_t nl = c->cfg.levels;
+    const bool count = (c->cfg.flags & BHRAY_F_COUNTERS) != 0, timing = (c->cfg.flags & BHRAY_F_TIMING) != 0;
+    HIPCHK(c, hipMemsetAsync(c->d_qctl, 0, 2 * BHRAY_MAX_LEVELS * sizeof(uint32_t), c->stream));
+    if (count) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(Counters64), c->stream));
+    const int bpc = trace_blocks_per_cu(P.method, P.model_count > 0, count);
+    const int grid = c->num_cus * bpc;
+    for (uint32_t l = 0; l < nl; l++) {
+        Level& Lv = c->levels[l];
+        if (Lv.rows.empty()) continue;
+        const bool last = (l == nl - 1);
+        LevelParams L; memset(&L, 0, sizeof L);
+        L.w = Lv.w; L.h = Lv.h;
+        if (l == 0) { L.pw = 1; L.ph = 1; L.rx = 1.0f; L.ry = 1.0f; L.prev = nullptr; }
+        else {
+            const Level& Pv = c->levels[l - 1];
+            L.pw = Pv.w; L.ph = Pv.h; L.prev = Pv.out;
+            const int sfx = (L.w - 1) / (L.pw - 1), sfy = (L.h - 1) / (L.ph - 1);          // ray.wgsl:185
+            L.rx = (float)L.pw / (float)(L.w + (sfx - 1)); L.ry = (float)L.ph / (float)(L.h + (sfy - 1));   // ray.wgsl:187
+        }
+        if (last) {
+            L.out = c->out; L.out_pitch = (int)c->cfg.frame_w; L.out_x0 = (int)c->cfg.crop_x; L.rowmap = Lv.d_rowmap;
+            L.x0 = (int)c->cfg.crop_x; L.x1 = (int)(c->cfg.crop_x + c->cfg.frame_w);
+        } else {
+            L.out = Lv.out; L.out_pitch = Lv.w; L.out_x0 = 0; L.rowmap = nullptr; L.x0 = 0; L.x1 = Lv.w;
+        }
+        L.rows = Lv.d_rows; L.nrows = (int)Lv.rows.size();
+        uint32_t* qcount = c->d_qctl + 2 * l; uint32_t* qhead = qcount + 1;
+        if (timing) HIPCHK(c, hipEventRecord(Lv.ev[0], c->stream));
+        HIPCHK(c, launch_classify(P, L, Lv.queue, qcount, count ? c->d_counters : nullptr, c->stream));
+        if (timing) HIPCHK(c, hipEventRecord(Lv.ev[1], c->stream));
+        HIPCHK(c, launch_trace(P, L, Lv.queue, qcount, qhead, count ? c->d_counters : nullptr, c->d_err, grid, c->stream));
+        if (timing) HIPCHK(c, hipEventRecord(Lv.ev[2], c->stream));
+    }
+    c->rendered = true;
+    return BHRAY_OK;
+}
+
+int bhray_sync(bhray_ctx* c) {
+    if (!c) return BHRAY_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->rendered) {
+        int e = 0;
+        HIPCHK(c, hipMemcpy(&e, c->d_err, sizeof e, hipMemcpyDeviceToHost));
+        if (e != 0) {
+            HIPCHK(c, hipMemset(c->d_err, 0, sizeof(int)));
+            return fail(c, e, "kernel reported: %s", bhray_strerror(e));
+        }
+    }
+    return BHRAY_OK;
+}
+
+uint32_t bhray_local_rows(const bhray_ctx* c) { return c ? (uint32_t)c->local_rows.size() : 0; }
+
+int bhray_local_row_index(const bhray_ctx* c, uint32_t i, uint32_t* frame_row) {
+    if (!c || !frame_row || i >= c->local_rows.size()) return BHRAY_E_INVALID;
+    *frame_row = c->local_rows[i];
+    return BHRAY_OK;
+}
+
+int bhray_read_hdr(bhray_ctx* c, float* dst, size_t pitch) {
+    if (!c) return BHRAY_E_INVALID;
+    const size_t rowb = (size_t)c->cfg.frame_w * sizeof(float4);
+    if (!dst || pitch < rowb) return fail(c, BHRAY_E_INVALID, "bad destination / pitch");
+    int rc = bhray_sync(c);
+    if (rc) return rc;
+    if (c->local_rows.empty()) return BHRAY_OK;
+    HIPCHK(c, hipMemcpy2D(dst, pitch, c->out, rowb, rowb, c->local_rows.size(), hipMemcpyDeviceToHost));
+    return BHRAY_OK;
+}
+
+int bhray_read_level(bhray_ctx* c, uint32_t level, float* dst, size_t pitch) {
+    if (!c) return BHRAY_E_INVALID;
+    if (level >= c->cfg.levels) return fail(c, BHRAY_E_INVALID, "level out of range");
+    const Level& L = c->levels[level];
+    const size_t rowb = (size_t)L.w * sizeof(float4);
+    if (!dst || pitch < rowb) return fail(c, BHRAY_E_INVALID, "bad destination / pitch");
+    int rc = bhray_sync(c);
+    if (rc) return rc;
+    if (level + 1 < c->cfg.levels) {
+        HIPCHK(c, hipMemcpy2D(dst, pitch, L.out, rowb, rowb, (size_t)L.h, hipMemcpyDeviceToHost));
+        return BHRAY_OK;
+    }
+    // last level: scatter the packed window back into a NaN canvas of the full level size
+    for (int y = 0; y < L.h; y++) memset((uint8_t*)dst + (size_t)y * pitch, 0xFF, rowb);
+    const size_t frb = (size_t)c->cfg.frame_w * sizeof(float4);
+    std::vector<uint8_t> tmp(c->local_rows.size() * frb);
+    if (!tmp.empty()) HIPCHK(c, hipMemcpy(tmp.data(), c->out, tmp.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < c->local_rows.size(); i++) {
+        uint8_t* row = (uint8_t*)dst + (size_t)(c->cfg.crop_y + c->local_rows[i]) * pitch + (size_t)c->cfg.crop_x * sizeof(float4);
+        memcpy(row, tmp.data() + i * frb, frb);
+    }
+    return BHRAY_OK;
+}
+
+int bhray_hdr_device_ptr(bhray_ctx* c, void** p, size_t* bytes) {
+    if (!c || !p) return BHRAY_E_INVALID;
+    *p = c->out; if (bytes) *bytes = c->out_bytes;
+    return BHRAY_OK;
+}
+
+int bhray_bind_output(bhray_ctx* c, void* p, size_t bytes) {
+    if (!c) return BHRAY_E_INVALID;
+    if (!p) { c->out = c->own_out; return BHRAY_OK; }
+    if (bytes < c->out_bytes) return fail(c, BHRAY_E_INVALID, "output binding needs %zu bytes", c->out_bytes);
+    if (((uintptr_t)p & 15u) != 0) return fail(c, BHRAY_E_INVALID, "output binding must be 16-byte aligned");
+    c->out = (float4*)p;
+    return BHRAY_OK;
+}
+
+int bhray_get_stream(bhray_ctx* c, void** s) {
+    if (!c || !s) return BHRAY_E_INVALID;
+    *s = (void*)c->stream;
+    return BHRAY_OK;
+}
+
+int bhray_set_stream(bhray_ctx* c, void* s) {
+    if (!c) return BHRAY_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return BHRAY_OK;
+}
+
+int bhray_get_counters(bhray_ctx* c, bhray_counters* out) {
+    if (!c || !out) return BHRAY_E_INVALID;
+    if (!(c->cfg.flags & BHRAY_F_COUNTERS)) return fail(c, BHRAY_E_STATE, "ctx created without BHRAY_F_COUNTERS");
+    int rc = bhray_sync(c);
+    if (rc) return rc;
+    static_assert(sizeof(bhray_counters) == sizeof(Counters64), "counter layout");
+    HIPCHK(c, hipMemcpy(out, c->d_counters, sizeof(Counters64), hipMemcpyDeviceToHost));
+    return BHRAY_OK;
+}
+
+int bhray_get_timing(bhray_ctx* c, bhray_timing* out) {
+    if (!c || !out) return BHRAY_E_INVALID;
+    if (!(c->cfg.flags & BHRAY_F_TIMING)) return fail(c, BHRAY_E_STATE, "ctx created without BHRAY_F_TIMING");
+    if (!c->rendered) return fail(c, BHRAY_E_STATE, "nothing rendered yet");
+    int rc = bhray_sync(c);
+    if (rc) return rc;
+    memset(out, 0, sizeof *out);
+    hipEvent_t first = nullptr, last = nullptr;
+    for (uint32_t l = 0; l < c->cfg.levels; l++) {
+        Level& L = c->levels[l];
+        if (L.rows.empty()) continue;
+        float a = 0, b = 0;
+        HIPCHK(c, hipEventElapsedTime(&a, L.ev[0], L.ev[1]));
+        HIPCHK(c, hipEventElapsedTime(&b, L.ev[1], L.ev[2]));
+        out->classify_ms += a; out->trace_ms += b; out->level_trace_ms[l] = b;
+        out->classify_launches++; out->trace_launches++;
+        if (!first) first = L.ev[0];
+        last = L.ev[2];
+    }
+    if (first && last) HIPCHK(c, hipEventElapsedTime(&out->total_ms, first, last));
+    return BHRAY_OK;
+}
+
+}  // extern "C"

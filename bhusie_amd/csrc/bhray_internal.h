@@ -1,0 +1,80 @@
+// bhray_internal.h — structures passed from the C-ABI host layer to the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/bhray.h"
+
+namespace bhray {
+
+struct TexDev {
+    const uint8_t* rgba;   // RGBA8 unorm, row-major, tightly packed (texture.rs:16-69)
+    int w, h;
+};
+
+// Compact model resident in HBM.  Nodes are 32 B (two float4 halves); the two children of an
+// inner node are adjacent (triangle.rs:239-243), so a child pair is one 64 B aligned read.
+struct ModelDev {
+    float pos[3];
+    int visible;
+    const float4* points;
+    const float4* normals;
+    const int32_t* triangles;   // 6 ints each
+    const float4* nodes;        // 2 float4 per node
+    const int32_t* lookup;
+    int node_count;
+};
+
+// Everything that is uniform over a frame.  Passed by value (kernarg → SGPRs).
+// Derived members are computed on the host with the SAME binary32 operation sequence the shader
+// performs per pixel (ray.wgsl:270-281, 488, 511), so hoisting them cannot change a bit.
+struct FrameParams {
+    // camera (ray.wgsl:41-45, 269-285)
+    float cam[3];
+    float right[3];        // normalize(cross(forward, (0,-1,0)))
+    float up[3];           // normalize(cross(forward, right))
+    float fwd_ff[3];       // forward * (1 / tan(fov/2))
+    float ray_distance;    // distance(camera.position, black_hole.position)  (ray.wgsl:511,555)
+    int relativity0;       // ray_distance < relativity_radius                (ray.wgsl:488)
+    // black hole (ray.wgsl:112-123)
+    float bh[3];
+    float bn[3];
+    float inner, outer, rot_speed, R;
+    int show_tex, show_shift;
+    float M[9];            // rotation matrix columns c0,c1,c2
+    float feather;
+    // details (ray.wgsl:25-34)
+    float time;
+    int method;
+    float step_size;
+    int max_iter;
+    float thr;
+    int model_count;
+    TexDev temp, disk, sky;
+    ModelDev models[BHRAY_MAX_MODELS];
+};
+
+// One ladder level (one RayPipeline of the reference, ray_pipeline.rs:36-309).
+struct LevelParams {
+    int w, h;              // level size (textureDimensions(color_buffer))
+    int pw, ph;            // previous level size; 1x1 => base case (ray.wgsl:178)
+    float rx, ry;          // size_ratio (ray.wgsl:187), computed on the host in binary32
+    const float4* prev;    // previous level, full pw*ph
+    float4* out;           // this level's pixels
+    int out_pitch;         // pixels per output row
+    int out_x0;            // output column = x - out_x0
+    const int32_t* rowmap; // level row y -> output row (nullptr: identity)
+    const int32_t* rows;   // rows to compute (sorted), nrows entries
+    int nrows;
+    int x0, x1;            // columns to compute
+};
+
+struct Counters64 { unsigned long long v[10]; };   // order = bhray_counters
+
+// launchers (bhray_kernels.hip)
+hipError_t launch_classify(const FrameParams& P, const LevelParams& L, uint32_t* queue, uint32_t* qcount,
+                           Counters64* counters, hipStream_t s);
+hipError_t launch_trace(const FrameParams& P, const LevelParams& L, const uint32_t* queue, const uint32_t* qcount,
+                        uint32_t* qhead, Counters64* counters, int* err_flag, int grid_blocks, hipStream_t s);
+int trace_blocks_per_cu(int method, int has_models, int count);
+
+}  // namespace bhray

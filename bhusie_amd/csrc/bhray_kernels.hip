@@ -1,0 +1,673 @@
+// bhray_kernels.hip — gfx950 (CDNA4) kernels of the geodesic ray-trace pass.
+//
+// Replaces the WGSL compute shader /root/reference/src/renderer/shaders/ray.wgsl:1-847
+// (one invocation per pixel, @workgroup_size(8,8,1)) with two kernels per ladder level:
+//
+//   classify_kernel  ray.wgsl:167-243 (`main`): per pixel copy / interpolate from the coarser
+//                    level and store, or — when the pixel must be traced — append it to a work
+//                    queue.  One wave = one 8x8 pixel tile; the append is a wave ballot + one
+//                    atomic per wave, so queue order keeps tile locality.
+//   trace_kernel     ray.wgsl:269-285, 365-393, 401-666, 725-766 (`create_ray`, `trace_ray`
+//                    and everything it calls): persistent waves pull rays from the queue.  A
+//                    lane whose ray has finished is refilled from the queue (ballot + prefix
+//                    popcount), so step-count divergence between rays does not idle lanes; the
+//                    rare flat-space / BVH iterations and the epilogue are executed in their
+//                    own wave-uniform phases between batches of integrator steps, so that the
+//                    hot loop contains only the integrator and the per-step horizon/disk test.
+//
+// No MFMA: the path is an f32 ODE march (VALU) plus byte/int texture and BVH reads (HBM/L2).
+// Numerics: DESIGN.md §Numerics — compiled with -ffp-contract=off; operation order follows the
+// shader so results are bit-identical to the CPU oracle except for the shading-only
+// transcendentals (atan2f/sinf/cosf/powf from the device libm).
+#include "bhray_internal.h"
+#include "bhray_math.h"
+
+namespace bhray {
+
+// ------------------------------------------------------------------------------------------
+// portable transcendental forms (numerics contract N4) — same operation sequence as the oracle
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bh_pow_m001(float x) {          // x^(-0.001), ray.wgsl:459
+    if (!(x == x) || x < 0.0f) return __uint_as_float(0x7fc00000u);
+    if (x == 0.0f) return __uint_as_float(0x7f800000u);
+    if (x == __uint_as_float(0x7f800000u)) return 0.0f;
+    uint32_t u = __float_as_uint(x);
+    int e = (int)(u >> 23) - 127;
+    if ((u >> 23) == 0) { x = x * 8388608.0f; u = __float_as_uint(x); e = (int)(u >> 23) - 127 - 23; }
+    float m = __uint_as_float((u & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421354f) { m = m * 0.5f; e = e + 1; }
+    float s = (m - 1.0f) / (m + 1.0f);
+    float s2 = s * s;
+    float p = 0.111111112f;
+    p = p * s2 + 0.142857149f;
+    p = p * s2 + 0.2f;
+    p = p * s2 + 0.333333343f;
+    p = p * s2 + 1.0f;
+    float lnm = (2.0f * s) * p;
+    float lnx = (float)e * 0.693147182f + lnm;
+    float t = -0.001f * lnx;
+    float q = 0.00138888892f;
+    q = q * t + 0.00833333377f;
+    q = q * t + 0.0416666679f;
+    q = q * t + 0.166666672f;
+    q = q * t + 0.5f;
+    q = q * t + 1.0f;
+    q = q * t + 1.0f;
+    return q;
+}
+
+__device__ __forceinline__ float bh_asin_kernel(float z) {
+    float z2 = z * z;
+    float p = 4.2163199048e-2f;
+    p = p * z2 + 2.4181311049e-2f;
+    p = p * z2 + 4.5470025998e-2f;
+    p = p * z2 + 7.4953002686e-2f;
+    p = p * z2 + 1.6666752422e-1f;
+    return z + (z * z2) * p;
+}
+__device__ __forceinline__ float bh_acos(float x) {              // ray.wgsl:266
+    if (!(x == x) || x > 1.0f || x < -1.0f) return __uint_as_float(0x7fc00000u);
+    if (x > 0.5f) { float z = sqrtf((1.0f - x) * 0.5f); return 2.0f * bh_asin_kernel(z); }
+    if (x < -0.5f) { float z = sqrtf((1.0f + x) * 0.5f); return 3.14159274f - 2.0f * bh_asin_kernel(z); }
+    return 1.57079637f - bh_asin_kernel(x);
+}
+
+// ------------------------------------------------------------------------------------------
+// textures: RGBA8 unorm, bilinear, clamp-to-edge (texture.rs:32,61-69; textureSampleLevel 0)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 texel(const TexDev& t, int x, int y) {
+    const uchar4 p = *reinterpret_cast<const uchar4*>(t.rgba + 4 * ((size_t)y * (size_t)t.w + (size_t)x));
+    return make_float4((float)p.x / 255.0f, (float)p.y / 255.0f, (float)p.z / 255.0f, (float)p.w / 255.0f);
+}
+__device__ __forceinline__ float unit_coord(float u, int n, int& i0, int& i1) {
+    float x = u * (float)n - 0.5f;
+    if (!(x >= -1.0f)) x = -1.0f;
+    if (x > (float)n) x = (float)n;
+    float fl = floorf(x);
+    int a = (int)fl, b = a + 1;
+    a = a < 0 ? 0 : a; a = a > n - 1 ? n - 1 : a;
+    b = b < 0 ? 0 : b; b = b > n - 1 ? n - 1 : b;
+    i0 = a; i1 = b;
+    return x - fl;
+}
+__device__ __forceinline__ float4 sample_bilinear(const TexDev& t, float u, float v) {
+    int x0, x1, y0, y1;
+    float fx = unit_coord(u, t.w, x0, x1);
+    float fy = unit_coord(v, t.h, y0, y1);
+    float4 a = texel(t, x0, y0), b = texel(t, x1, y0), c = texel(t, x0, y1), d = texel(t, x1, y1);
+    float4 r;
+    r.x = mix_(mix_(a.x, b.x, fx), mix_(c.x, d.x, fx), fy);
+    r.y = mix_(mix_(a.y, b.y, fx), mix_(c.y, d.y, fx), fy);
+    r.z = mix_(mix_(a.z, b.z, fx), mix_(c.z, d.z, fx), fy);
+    r.w = mix_(mix_(a.w, b.w, fx), mix_(c.w, d.w, fx), fy);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// intersections
+// ------------------------------------------------------------------------------------------
+struct Hit {            // RenderState (ray.wgsl:92-98) without the members nothing reads
+    F3 color;
+    float opacity;
+    float t;
+    bool hit;
+};
+
+// hit_sphere, ray.wgsl:725-766.  Returns hit and t (the normal is never consumed on this path).
+__device__ __forceinline__ bool hit_sphere(F3 pos, F3 dir, float radius, F3 center, float t_min, float t_max, float& t_out) {
+    F3 oc = pos - center;
+    float a = dot(dir, dir);
+    float b = 2.0f * dot(oc, dir);
+    float c = dot(oc, oc) - radius * radius;
+    float disc = b * b - 4.0f * a * c;
+    if (disc > 0.0f) {
+        float sq = sqrtf(disc);
+        float t1 = (-b - sq) / (2.0f * a);
+        float t2 = (-b + sq) / (2.0f * a);
+        float tc = t_max;
+        if (t1 > t_min && t1 < t_max) tc = t1;
+        if (t2 > t_min && t2 < t_max && t2 < tc) tc = t2;
+        if (tc < t_max && tc > t_min) { t_out = tc; return true; }
+    }
+    return false;
+}
+
+// hit_torus2d, ray.wgsl:668-701.
+__device__ __forceinline__ bool hit_torus2d(F3 pos, F3 dir, float inner, float outer, F3 tpos, F3 normal,
+                                            float t_min, float t_max, float& t_out) {
+    float denom = dot(normal, dir);
+    F3 dist = tpos - pos;
+    float t = dot(dist, normal) / denom;
+    if (t < t_max && t > t_min) {
+        F3 ip = pos + dir * t;
+        float dc = distance(tpos, ip);
+        if (dc >= inner && dc <= outer) { t_out = t; return true; }
+    }
+    return false;
+}
+
+// Disk shading, ray.wgsl:612-663 (the part of hit_black_hole after the disk won).
+template <bool COUNT>
+__device__ __noinline__ void shade_disk(const FrameParams& P, F3 pos, F3 dir, float t, float total_distance, Hit& rs,
+                                        unsigned long long* cnt) {
+    F3 bpos = ld3(P.bh);
+    F3 ip = pos + dir * t;
+    float dist = distance(bpos, ip);
+    float density = 1.0f - length(div_s(ip, P.outer));
+    {
+        float e0 = P.inner, e1 = P.inner + 1.0f;
+        float s = clamp_((dist - e0) / (e1 - e0), 0.0f, 1.0f);
+        density *= s * s * (3.0f - 2.0f * s);
+    }
+    density *= 1.0f / sqrtf(dist);
+    float od = powf(30.0f * density, 1.3f);
+    rs.opacity = clamp_(od * 0.2f, 0.0f, 1.0f);
+    rs.color = f3(od, od, od);
+    if (COUNT) cnt[8]++;
+    if (P.show_tex != 0) {
+        float r = (dist - P.inner) / (P.outer - P.inner);
+        F3 rel = div_s(ip - bpos, P.outer);
+        F3 c0 = f3(P.M[0], P.M[1], P.M[2]), c1 = f3(P.M[3], P.M[4], P.M[5]), c2 = f3(P.M[6], P.M[7], P.M[8]);
+        F3 rot = (c0 * rel.x + c1 * rel.y) + c2 * rel.z;
+        float angle = -atan2f(rot.z, rot.x);
+        float ph = angle + P.time * P.rot_speed;
+        float u = sinf(ph) * r, v = cosf(ph) * r;
+        u = (u + 1.0f) * 0.5f; v = (v + 1.0f) * 0.5f;
+        float4 dc = sample_bilinear(P.disk, u, v);
+        rs.opacity *= clamp_(0.7f + dc.w * 0.5f, 0.0f, 1.0f);
+        rs.color = rs.color * (f3(dc.x, dc.y, dc.z) * dc.w);
+    }
+    if (P.show_shift != 0) {
+        float temp_max = 100000.0f, temp_min = 10000.0f, temp = 15000.0f;
+        float y = 1.0f - (temp - temp_min) / (temp_max - temp_min);
+        F3 sv = cross(normalize(ip), normalize(f3(0.0f, -1.0f, 0.0f))) * 0.6f;
+        float velocity = dot(dir, sv);
+        float doppler = sqrtf((1.0f - velocity) / (1.0f + velocity));
+        float grav = sqrtf((1.0f - 2.0f / dist) / (1.0f - 2.0f / total_distance));
+        float sh = clamp_(grav * doppler, 0.0f, 1.0f);
+        float4 sc = sample_bilinear(P.temp, sh * sh, y);
+        rs.color = rs.color * f3(sc.x, sc.y, sc.z);
+    }
+}
+
+// hit_black_hole, ray.wgsl:598-666: horizon sphere (radius 1, colour 0) vs. disk.
+template <bool COUNT>
+__device__ __forceinline__ void hit_black_hole(const FrameParams& P, F3 pos, F3 dir, float t_min, float t_max,
+                                               float total_distance, Hit& rs, unsigned long long* cnt) {
+    F3 bpos = ld3(P.bh);
+    float ts = t_max, td = t_max;
+    bool hs = hit_sphere(pos, dir, 1.0f, bpos, t_min, t_max, ts);
+    bool hd = hit_torus2d(pos, dir, P.inner, P.outer, bpos, ld3(P.bn), t_min, t_max, td);
+    rs.hit = hs; rs.t = hs ? ts : t_max; rs.color = f3(0.0f, 0.0f, 0.0f); rs.opacity = hs ? 1.0f : 0.0f;
+    if (hd && td < rs.t) {
+        rs.hit = true; rs.t = td;
+        shade_disk<COUNT>(P, pos, dir, td, total_distance, rs, cnt);
+    }
+}
+
+// hit_aabb, ray.wgsl:703-723 (node = two float4 halves).
+__device__ __forceinline__ float hit_aabb(F3 pos, F3 inv, float4 lo, float4 hi, F3 offset) {
+    F3 mn = f3(lo.x, lo.y, lo.z) + offset, mx = f3(hi.x, hi.y, hi.z) + offset;
+    F3 t1 = (mn - pos) * inv, t2 = (mx - pos) * inv;
+    F3 tmn = f3(min_(t1.x, t2.x), min_(t1.y, t2.y), min_(t1.z, t2.z));
+    F3 tmx = f3(max_(t1.x, t2.x), max_(t1.y, t2.y), max_(t1.z, t2.z));
+    float tmin_axis = max_(max_(tmn.x, tmn.y), tmn.z);
+    float tmax_axis = min_(min_(tmx.x, tmx.y), tmx.z);
+    if (tmin_axis > tmax_axis || tmax_axis < 0.0f) return 1e8f;
+    return tmin_axis;
+}
+
+__device__ __forceinline__ float det3(F3 c0, F3 c1, F3 c2) {
+    return (c0.x * (c1.y * c2.z - c2.y * c1.z) - c1.x * (c0.y * c2.z - c2.y * c0.z))
+           + c2.x * (c0.y * c1.z - c1.y * c0.z);
+}
+
+// hit_triangle, ray.wgsl:768-847.  normal_out = face normal (consumed by the diffuse term).
+__device__ __forceinline__ bool hit_triangle(F3 pos, F3 dir, float t_min, float t_max, F3 A, F3 B, F3 C,
+                                             F3 n1, F3 n2, F3 n3, float& t_out, F3& color_out, F3& normal_out) {
+    F3 ab = B - A, ac = C - A;
+    F3 n = normalize(cross(ab, ac));
+    float rdt = dot(dir, n);
+    if (rdt > 0.0f) { rdt = rdt * -1.0f; n = n * -1.0f; }
+    if (fabsf(rdt) < 0.00001f) return false;
+    float den = det3(dir, A - B, A - C);
+    if (fabsf(den) < 0.00001f) return false;
+    float u = det3(dir, A - pos, A - C) / den;
+    if (u < 0.0f || u > 1.0f) return false;
+    float v = det3(dir, A - B, A - pos) / den;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t = det3(A - pos, A - B, A - C) / den;
+    if (t > t_min && t < t_max) {
+        F3 nm = (n1 * ((1.0f - u) - v) + n2 * u) + n3 * v;
+        color_out = f3(-nm.x * 0.5f + 0.5f, -nm.y * 0.5f + 0.5f, -nm.z * 0.5f + 0.5f);
+        normal_out = n; t_out = t;
+        return true;
+    }
+    return false;
+}
+
+// trace_ray_model, ray.wgsl:287-363.  The traversal stack holds node indices (the reference
+// stacks 19 whole nodes and has no overflow check); an overflow raises *err instead of
+// corrupting memory.
+template <bool COUNT>
+__device__ __noinline__ void trace_ray_model(const ModelDev& M, F3 pos, F3 dir, float t_min, float t_max, Hit& closest,
+                                             F3& normal_out, unsigned long long* cnt, int* err) {
+    F3 mpos = ld3(M.pos);
+    F3 inv = f3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+    closest.hit = false; closest.t = t_max; closest.color = f3(0, 0, 0); closest.opacity = 0.0f;
+    normal_out = f3(0, 0, 0);
+    int node = 0;
+    int stack[BHRAY_BVH_STACK];
+    int sp = 0;
+    for (;;) {
+        const float4 n_hi = M.nodes[2 * node + 1];
+        const float4 n_lo = M.nodes[2 * node];
+        const int obj_count = __float_as_int(n_hi.w), contents = __float_as_int(n_lo.w);
+        if (obj_count == 0) {
+            int c1 = contents, c2 = contents + 1;
+            // adjacent children: 4 x float4 = one 64 B segment
+            const float4 a_lo = M.nodes[2 * c1], a_hi = M.nodes[2 * c1 + 1];
+            const float4 b_lo = M.nodes[2 * c2], b_hi = M.nodes[2 * c2 + 1];
+            if (COUNT) cnt[6]++;
+            float d1 = hit_aabb(pos, inv, a_lo, a_hi, mpos);
+            float d2 = hit_aabb(pos, inv, b_lo, b_hi, mpos);
+            if (d1 > d2) { float td = d1; d1 = d2; d2 = td; int tc = c1; c1 = c2; c2 = tc; }
+            if (d1 > closest.t) {
+                if (sp == 0) break;
+                node = stack[--sp];
+            } else {
+                node = c1;
+                if (d2 < closest.t) {
+                    if (sp < BHRAY_BVH_STACK) stack[sp++] = c2; else *err = BHRAY_E_BVH_DEPTH;
+                }
+            }
+        } else {
+            for (int i = 0; i < obj_count; i++) {
+                const int idx = M.lookup[contents + i];
+                const int32_t* ti = M.triangles + 6 * (size_t)idx;
+                const int p1 = ti[0], p2 = ti[1], p3 = ti[2], q1 = ti[3], q2 = ti[4], q3 = ti[5];
+                const float4 A = M.points[p1], B = M.points[p2], Cc = M.points[p3];
+                const float4 N1 = M.normals[q1], N2 = M.normals[q2], N3 = M.normals[q3];
+                if (COUNT) cnt[7]++;
+                float t; F3 col, nrm;
+                if (hit_triangle(pos, dir, t_min, t_max, f3(A.x, A.y, A.z) + mpos, f3(B.x, B.y, B.z) + mpos,
+                                 f3(Cc.x, Cc.y, Cc.z) + mpos, f3(N1.x, N1.y, N1.z), f3(N2.x, N2.y, N2.z),
+                                 f3(N3.x, N3.y, N3.z), t, col, nrm)) {
+                    if (t < closest.t) { closest.hit = true; closest.t = t; closest.color = col; closest.opacity = 1.0f; normal_out = nrm; }
+                }
+            }
+            if (sp == 0) break;
+            node = stack[--sp];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// integrators
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pow5(float d) { return ((d * d) * (d * d)) * d; }
+
+// f, ray.wgsl:401-403, with the per-step invariants factored: c = -1.5*h2, r = 1/dist^5.
+__device__ __forceinline__ F3 f_acc(F3 p, F3 bpos, float c, float r) { return ((p - bpos) * c) * r; }
+
+// Cash–Karp tableau, ray.wgsl:133-165: untyped consts are evaluated in binary64 and rounded once.
+#define KF(x) ((float)(x))
+__device__ constexpr float A21 = KF(1.0 / 5.0);
+__device__ constexpr float A31 = KF(3.0 / 40.0), A32 = KF(9.0 / 40.0);
+__device__ constexpr float A41 = KF(3.0 / 10.0), A42 = KF(-9.0 / 10.0), A43 = KF(6.0 / 5.0);
+__device__ constexpr float A51 = KF(-11.0 / 54.0), A52 = KF(5.0 / 2.0), A53 = KF(-70.0 / 27.0), A54 = KF(35.0 / 27.0);
+__device__ constexpr float A61 = KF(1631.0 / 55296.0), A62 = KF(175.0 / 512.0), A63 = KF(575.0 / 13824.0),
+                           A64 = KF(44275.0 / 110592.0), A65 = KF(253.0 / 4096.0);
+__device__ constexpr float BA1 = KF(2825.0 / 27648.0), BA2 = KF(0.0), BA3 = KF(18575.0 / 48384.0),
+                           BA4 = KF(13525.0 / 55296.0), BA5 = KF(277.0 / 14336.0), BA6 = KF(1.0 / 4.0);
+__device__ constexpr float DB1 = KF(37.0 / 378.0 - 2825.0 / 27648.0), DB2 = KF(0.0 - 0.0),
+                           DB3 = KF(250.0 / 621.0 - 18575.0 / 48384.0), DB4 = KF(125.0 / 594.0 - 13525.0 / 55296.0),
+                           DB5 = KF(0.0 - 277.0 / 14336.0), DB6 = KF(512.0 / 1771.0 - 1.0 / 4.0);
+
+// next_ray_rk, ray.wgsl:405-465.  The retry loop (425-451) cannot change h and is run once.
+__device__ __forceinline__ void next_ray_rk(F3 bpos, F3& pos, F3& dir, float& h_io) {
+    const F3 p0 = pos, d0 = dir;
+    const float dist = length(p0 - bpos);
+    const float lc = length(cross(p0, d0));
+    const float h2 = lc * lc;
+    const float c = -1.5f * h2;
+    const float r = 1.0f / pow5(dist);
+    const float h = h_io;
+    const F3 k1 = f_acc(p0, bpos, c, r);
+    const F3 k2 = f_acc(p0 + (k1 * A21) * h, bpos, c, r);
+    const F3 k3 = f_acc(p0 + (k1 * A31 + k2 * A32) * h, bpos, c, r);
+    const F3 k4 = f_acc(p0 + ((k1 * A41 + k2 * A42) + k2 * A43) * h, bpos, c, r);
+    const F3 k5 = f_acc(p0 + (((k1 * A51 + k2 * A52) + k3 * A53) + k4 * A54) * h, bpos, c, r);
+    const F3 k6 = f_acc(p0 + ((((k1 * A61 + k2 * A62) + k3 * A63) + k4 * A64) + k5 * A65) * h, bpos, c, r);
+    const F3 es = ((((k1 * DB1 + k2 * DB2) + k3 * DB3) + k4 * DB4) + k5 * DB5) + k6 * DB6;
+    const F3 e = es * h;
+    const float e_max = max_(max_(fabsf(e.x), fabsf(e.y)), fabsf(e.z));
+    const F3 ds = ((((k1 * BA1 + k2 * BA2) + k3 * BA3) + k4 * BA4) + k5 * BA5) + k6 * BA6;
+    dir = normalize(d0 + ds * h);
+    pos = p0 + d0 * h;
+    if (e_max > 0.00002f) h_io = h * (0.9f * bh_pow_m001(e_max));
+    else h_io = h * 1.0001f;
+}
+
+// next_ray_euler, ray.wgsl:467-480.
+__device__ __forceinline__ void next_ray_euler(F3 bpos, F3& pos, F3& dir, float step) {
+    const float lc = length(cross(pos, dir));
+    const float h2 = lc * lc;
+    const float dist = length(pos - bpos);
+    const float c = -1.5f * h2;
+    const float r = 1.0f / pow5(dist);
+    dir = normalize(dir + f_acc(pos, bpos, c, r) * step);
+    pos = pos + dir * step;
+}
+
+// ------------------------------------------------------------------------------------------
+// classify: ray.wgsl:167-243
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 load_prev(const LevelParams& L, int x, int y) {
+    x = x < 0 ? 0 : (x > L.pw - 1 ? L.pw - 1 : x);
+    y = y < 0 ? 0 : (y > L.ph - 1 ? L.ph - 1 : y);
+    return L.prev[(size_t)y * (size_t)L.pw + (size_t)x];
+}
+__device__ __forceinline__ float angle_between(float4 a, float4 b) {     // ray.wgsl:263-267
+    F3 v1 = f3(a.x, a.y, a.z), v2 = f3(b.x, b.y, b.z);
+    float d = dot(v1, v2);
+    float c = d / (length(v1) * length(v2));
+    return bh_acos(c);
+}
+__device__ __forceinline__ size_t out_index(const LevelParams& L, int x, int y) {
+    const int oy = L.rowmap ? L.rowmap[y] : y;
+    return (size_t)oy * (size_t)L.out_pitch + (size_t)(x - L.out_x0);
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void classify_kernel(const FrameParams P, const LevelParams L, uint32_t* __restrict__ queue,
+                                                       uint32_t* __restrict__ qcount, Counters64* __restrict__ counters) {
+    // one wave = one 8x8 tile; 4 tiles per block side by side in x
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int tiles_x = (L.x1 - L.x0 + 7) >> 3;
+    const int tile = blockIdx.x * 4 + wave;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int x = L.x0 + tx * 8 + (lane & 7);
+    const int j = ty * 8 + (lane >> 3);
+    const bool valid = (x < L.x1) && (j < L.nrows);
+    const int y = valid ? L.rows[j] : 0;
+    bool need_trace = false;
+    int kind = -1;                                   // 0 copy, 1 interpolate, 2 trace
+    if (valid) {
+        if (L.pw == 1 && L.ph == 1) {
+            need_trace = true; kind = 2;
+        } else {
+            const float ppx = (float)x * L.rx, ppy = (float)y * L.ry;
+            const float tlx = floorf(ppx), tly = floorf(ppy);
+            const float4 c_tl = load_prev(L, (int)tlx, (int)tly);
+            if (fabsf(tlx - ppx) < 0.001f && fabsf(tly - ppy) < 0.001f) {
+                L.out[out_index(L, x, y)] = c_tl; kind = 0;
+            } else {
+                const float4 c_bl = load_prev(L, (int)tlx, (int)(tly + 1.0f));
+                const float4 c_tr = load_prev(L, (int)(tlx + 1.0f), (int)tly);
+                const float4 c_br = load_prev(L, (int)(tlx + 1.0f), (int)(tly + 1.0f));
+                const bool alphas0 = c_tl.w == 0.0f && c_tr.w == 0.0f && c_bl.w == 0.0f && c_br.w == 0.0f;
+                bool interp = false;
+                if (alphas0) {
+                    const float a0 = angle_between(c_bl, c_tl), a1 = angle_between(c_br, c_tr);
+                    const float a2 = angle_between(c_tl, c_tr), a3 = angle_between(c_bl, c_br);
+                    interp = a0 < P.thr && a1 < P.thr && a2 < P.thr && a3 < P.thr;
+                }
+                if (interp) {
+                    const float tx_ = ppx - tlx, ty_ = ppy - tly;
+                    F3 top = mix3(f3(c_tl.x, c_tl.y, c_tl.z), f3(c_tr.x, c_tr.y, c_tr.z), tx_);
+                    F3 bot = mix3(f3(c_bl.x, c_bl.y, c_bl.z), f3(c_br.x, c_br.y, c_br.z), tx_);
+                    F3 p = mix3(top, bot, ty_);
+                    L.out[out_index(L, x, y)] = make_float4(p.x, p.y, p.z, 0.0f); kind = 1;
+                } else {
+                    need_trace = true; kind = 2;
+                }
+            }
+        }
+    }
+    // wave-ballot compaction: one atomic per wave, lanes keep tile order
+    const unsigned long long m = __ballot(need_trace);
+    if (m) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(qcount, (uint32_t)__popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (need_trace) queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)y << 16) | (uint32_t)x;
+    }
+    if (COUNT) {
+        const unsigned long long mv = __ballot(valid), m0 = __ballot(kind == 0), m1 = __ballot(kind == 1);
+        if (lane == 0) {
+            atomicAdd(&counters->v[0], (unsigned long long)__popcll(mv));
+            atomicAdd(&counters->v[1], (unsigned long long)__popcll(m0));
+            atomicAdd(&counters->v[2], (unsigned long long)__popcll(m1));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// trace: ray.wgsl:269-285 + 482-596
+// ------------------------------------------------------------------------------------------
+enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3 };
+#define BHRAY_REL_BATCH 16
+
+template <int METHOD, bool MODELS, bool COUNT>
+__global__ __launch_bounds__(256) void trace_kernel(const FrameParams P, const LevelParams L, const uint32_t* __restrict__ queue,
+                                                    const uint32_t* __restrict__ qcount_p, uint32_t* __restrict__ qhead,
+                                                    Counters64* __restrict__ counters, int* __restrict__ err_flag) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t qcount = *qcount_p;
+    const F3 bpos = ld3(P.bh);
+    const F3 cam = ld3(P.cam);
+    const float t_max = 1e5f, t_min = 1e-8f;
+
+    // per-lane ray state (trace_ray locals, ray.wgsl:486-516)
+    int mode = M_EMPTY;
+    uint32_t pix = 0;
+    F3 cpos = cam, cdir = f3(0, 0, 1), ppos = cam, pdir = f3(0, 0, 1), rdir = f3(0, 0, 1);
+    F3 rkpos = cam, rkdir = f3(0, 0, 1);
+    float rkh = 0.0f;
+    F3 color = f3(0, 0, 0);
+    float amount = 1.0f, step = P.step_size, closest = P.ray_distance;
+    int it = 0;
+    bool hit = false;
+    bool exhausted = false;
+    unsigned long long cnt[10];
+    if (COUNT) { for (int k = 0; k < 10; k++) cnt[k] = 0; }
+    int err = 0;
+
+    for (;;) {
+        // ---- refill finished lanes from the queue (wave ballot + prefix popcount)
+        {
+            const unsigned long long need = __ballot(mode == M_EMPTY);
+            if (need != 0ull && !exhausted) {
+                const uint32_t n = (uint32_t)__popcll(need);
+                uint32_t base = 0;
+                if (lane == (int)__builtin_ctzll(need)) base = atomicAdd(qhead, n);
+                base = (uint32_t)__shfl((int)base, (int)__builtin_ctzll(need));
+                if (base + n >= qcount) exhausted = true;
+                const uint32_t idx = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                if (mode == M_EMPTY && idx < qcount) {
+                    pix = queue[idx];
+                    const int px = (int)(pix & 0xffffu), py = (int)(pix >> 16);
+                    // create_ray, ray.wgsl:269-285 (right/up/fwd_ff hoisted to the host, bit-identical)
+                    const int sm = (L.w - 1) < (L.h - 1) ? (L.w - 1) : (L.h - 1);
+                    const float increment = 1.0f / (float)sm;
+                    const float posx = (2.0f * ((float)px - (float)(L.w - 1) * 0.5f)) * increment;
+                    const float posy = (2.0f * ((float)py - (float)(L.h - 1) * 0.5f)) * increment;
+                    rdir = normalize((ld3(P.right) * posx + ld3(P.up) * posy) + ld3(P.fwd_ff));
+                    cpos = cam; cdir = rdir; ppos = cam; pdir = rdir;
+                    rkpos = cam; rkdir = rdir; rkh = P.step_size;
+                    color = f3(0, 0, 0); amount = 1.0f; step = P.step_size; closest = P.ray_distance;
+                    it = 0; hit = false;
+                    mode = P.relativity0 ? M_REL : M_FLAT;
+                    if (COUNT) cnt[3]++;
+                }
+            }
+            if (!__any(mode != M_EMPTY)) break;
+        }
+
+        // ---- flat-space iterations (ray.wgsl:554-569), one per lane that is in flat space
+        if (__any(mode == M_FLAT)) {
+            if (mode == M_FLAT) {
+                if (it >= P.max_iter) {
+                    mode = M_FINISH;
+                } else {
+                    if (COUNT) cnt[5]++;
+                    Hit rs; rs.hit = false; rs.t = t_max; rs.color = f3(0, 0, 0); rs.opacity = 0.0f;
+                    if (MODELS) {
+                        for (int mi = 0; mi < P.model_count; mi++) {
+                            if (P.models[mi].visible != 0) {
+                                Hit r; F3 nrm;
+                                trace_ray_model<COUNT>(P.models[mi], cpos, cdir, t_min, t_max, r, nrm, cnt, &err);
+                                if (r.hit && r.t < rs.t) {
+                                    rs = r;
+                                    const F3 light = normalize(f3(0.2f, 0.2f, -1.0f));
+                                    rs.color = rs.color * dot(nrm, light);
+                                }
+                            }
+                        }
+                    }
+                    float ths = t_max;
+                    const bool hs = hit_sphere(ppos, pdir, P.R, bpos, t_min, t_max, ths);
+                    if (!hs && !rs.hit) {
+                        mode = M_FINISH;                                   // break (no increment)
+                    } else {
+                        bool chit = false; Hit crs = rs;
+                        if (hs && ths < rs.t) { cpos = cpos + cdir * ths; mode = M_REL; }
+                        else { chit = rs.hit; }
+                        if (chit) {
+                            cpos = cpos + pdir * crs.t;
+                            const F3 cc = f3(clamp_(crs.color.x, 0.0f, 1.0f), clamp_(crs.color.y, 0.0f, 1.0f), clamp_(crs.color.z, 0.0f, 1.0f));
+                            color = color + cc * (amount * crs.opacity);
+                            amount *= 1.0f - crs.opacity;
+                            hit = true;
+                        }
+                        if (amount < 0.005f) mode = M_FINISH; else it++;
+                    }
+                }
+            }
+        }
+
+        // ---- epilogue (ray.wgsl:583-595) for lanes whose loop ended
+        if (__any(mode == M_FINISH)) {
+            if (mode == M_FINISH) {
+                float4 o;
+                if (hit || it <= 5) {
+                    if (amount > 0.001f) {
+                        if (COUNT) cnt[9]++;
+                        // cartesian_to_spherical(dir.xzy), ray.wgsl:255-261, 585-586
+                        const float theta = atan2f(sqrtf(cdir.x * cdir.x + cdir.z * cdir.z), cdir.y);
+                        const float phi = atan2f(cdir.z, cdir.x);
+                        const float PI_F = 3.1415926f;
+                        float u = (phi + 2.6f * PI_F) / (2.0f * PI_F);
+                        float v = (PI_F - theta) / PI_F;
+                        u = u - truncf(u); v = v - truncf(v);
+                        const float4 sc = sample_bilinear(P.sky, u, v);
+                        const F3 miss = f3((sc.x * sc.x) * (sc.x * sc.x), (sc.y * sc.y) * (sc.y * sc.y), (sc.z * sc.z) * (sc.z * sc.z));
+                        color = color + miss * amount;
+                    }
+                    o = make_float4(color.x, color.y, color.z, 1.0f);
+                } else {
+                    o = make_float4(cdir.x, cdir.y, cdir.z, 0.0f);
+                }
+                L.out[out_index(L, (int)(pix & 0xffffu), (int)(pix >> 16))] = o;
+                mode = M_EMPTY;
+            }
+        }
+
+        // ---- a batch of integrator steps (ray.wgsl:522-553) for lanes inside the sphere
+        for (int k = 0; k < BHRAY_REL_BATCH; k++) {
+            if (!__any(mode == M_REL)) break;
+            if (mode == M_REL) {
+                if (it >= P.max_iter) {
+                    mode = M_FINISH;
+                } else {
+                    if (COUNT) cnt[4]++;
+                    ppos = cpos; pdir = cdir;
+                    if (METHOD == 0) {
+                        next_ray_euler(bpos, cpos, cdir, step);
+                    } else {
+                        next_ray_rk(bpos, rkpos, rkdir, rkh);
+                        cpos = rkpos; cdir = rkdir; step = rkh;
+                    }
+                    const float cd = distance(cpos, bpos);
+                    if (cd < closest) closest = cd;
+                    pdir = cdir;
+                    Hit crs;
+                    hit_black_hole<COUNT>(P, ppos, pdir, t_min, step, P.ray_distance, crs, cnt);
+                    if (cd > P.R) {
+                        mode = M_FLAT;
+                        const float fw = P.R * P.feather;
+                        const float fs = P.R - fw;
+                        const float lin = clamp_((closest - fs) / fw, 0.0f, 1.0f);
+                        const float m = lin * lin;
+                        cdir = mix3(cdir, rdir, m);
+                    }
+                    if (crs.hit) {
+                        cpos = cpos + pdir * crs.t;
+                        const F3 cc = f3(clamp_(crs.color.x, 0.0f, 1.0f), clamp_(crs.color.y, 0.0f, 1.0f), clamp_(crs.color.z, 0.0f, 1.0f));
+                        color = color + cc * (amount * crs.opacity);
+                        amount *= 1.0f - crs.opacity;
+                        hit = true;
+                    }
+                    if (amount < 0.005f) mode = M_FINISH; else it++;
+                }
+            }
+        }
+    }
+
+    if (COUNT) {
+        for (int k = 3; k < 10; k++) {
+            unsigned long long v = cnt[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if (lane == 0 && v) atomicAdd(&counters->v[k], v);
+        }
+    }
+    if (err) *err_flag = err;
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+hipError_t launch_classify(const FrameParams& P, const LevelParams& L, uint32_t* queue, uint32_t* qcount,
+                           Counters64* counters, hipStream_t s) {
+    const int tiles_x = (L.x1 - L.x0 + 7) / 8, tiles_y = (L.nrows + 7) / 8;
+    const int tiles = tiles_x * tiles_y;
+    if (tiles <= 0) return hipSuccess;
+    const int blocks = (tiles + 3) / 4;
+    if (counters) hipLaunchKernelGGL(classify_kernel<true>, dim3(blocks), dim3(256), 0, s, P, L, queue, qcount, counters);
+    else hipLaunchKernelGGL(classify_kernel<false>, dim3(blocks), dim3(256), 0, s, P, L, queue, qcount, counters);
+    return hipGetLastError();
+}
+
+template <int METHOD, bool MODELS>
+static hipError_t launch_trace_t(const FrameParams& P, const LevelParams& L, const uint32_t* queue, const uint32_t* qcount,
+                                 uint32_t* qhead, Counters64* counters, int* err_flag, int grid_blocks, hipStream_t s) {
+    if (counters) hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, true>), dim3(grid_blocks), dim3(256), 0, s, P, L, queue, qcount, qhead, counters, err_flag);
+    else hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, false>), dim3(grid_blocks), dim3(256), 0, s, P, L, queue, qcount, qhead, counters, err_flag);
+    return hipGetLastError();
+}
+
+hipError_t launch_trace(const FrameParams& P, const LevelParams& L, const uint32_t* queue, const uint32_t* qcount,
+                        uint32_t* qhead, Counters64* counters, int* err_flag, int grid_blocks, hipStream_t s) {
+    const bool models = P.model_count > 0;
+    if (P.method == 0) {
+        return models ? launch_trace_t<0, true>(P, L, queue, qcount, qhead, counters, err_flag, grid_blocks, s)
+                      : launch_trace_t<0, false>(P, L, queue, qcount, qhead, counters, err_flag, grid_blocks, s);
+    }
+    return models ? launch_trace_t<1, true>(P, L, queue, qcount, qhead, counters, err_flag, grid_blocks, s)
+                  : launch_trace_t<1, false>(P, L, queue, qcount, qhead, counters, err_flag, grid_blocks, s);
+}
+
+int trace_blocks_per_cu(int method, int has_models, int count) {
+    int n = 0;
+    const void* f;
+#define PICK(M, MD, C) (const void*)trace_kernel<M, MD, C>
+    if (method == 0) f = has_models ? (count ? PICK(0, true, true) : PICK(0, true, false)) : (count ? PICK(0, false, true) : PICK(0, false, false));
+    else f = has_models ? (count ? PICK(1, true, true) : PICK(1, true, false)) : (count ? PICK(1, false, true) : PICK(1, false, false));
+#undef PICK
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 256, 0) != hipSuccess || n < 1) n = 2;
+    return n;
+}
+
+}  // namespace bhray

@@ -1,0 +1,161 @@
+"""RayPass / Renderer — the Python mirror of the reference's ray-pass surface.
+
+RayPass   = the chain of RayPipelines (src/renderer/pipelines/ray_pipeline.rs:28-310) as one
+            object over a bhray_ctx: textures, model, per-frame uniforms, dispatch, output.
+Renderer  = the part of Renderer::{new,render} on the path (src/renderer/mod.rs:113-207,
+            378-420): default RayDetails, the 72x41 x3 x4 ladder, per-frame call order.
+All pixels come from libbhray (gfx950); nothing is computed here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import lib
+from .layouts import (F_COUNTERS, F_TIMING, TEX_DISK, TEX_SKY, TEX_TEMP_LUT, BhrayConfig, BhrayCounters, BhrayTiming,
+                      check)
+from .model import Model
+from .scene import BlackHole, Camera, RayDetails
+
+
+def ladder_from_base(base=(72, 41), multiplier=3, levels=4) -> BhrayConfig:
+    cfg = BhrayConfig()
+    check(lib().bhray_ladder_from_base(base[0], base[1], multiplier, levels, C.byref(cfg)))
+    return cfg
+
+
+def ladder_for_frame(frame=(1920, 1080), multiplier=3, levels=4) -> BhrayConfig:
+    cfg = BhrayConfig()
+    check(lib().bhray_ladder_for_frame(frame[0], frame[1], multiplier, levels, C.byref(cfg)))
+    return cfg
+
+
+class RayPass:
+    def __init__(self, cfg: BhrayConfig, device=0, counters=False, timing=False, row_rank=0, row_world=1, stripe_rows=27):
+        cfg = BhrayConfig.from_buffer_copy(bytes(cfg))
+        cfg.struct_size = C.sizeof(BhrayConfig)
+        cfg.device = device
+        cfg.flags = (F_COUNTERS if counters else 0) | (F_TIMING if timing else 0)
+        cfg.row_rank, cfg.row_world, cfg.stripe_rows = row_rank, row_world, stripe_rows
+        self.cfg = cfg
+        h = C.c_void_p()
+        check(lib().bhray_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib().bhray_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- static inputs
+    def set_texture(self, slot: int, rgba: np.ndarray):
+        a = np.ascontiguousarray(rgba, dtype=np.uint8)
+        assert a.ndim == 3 and a.shape[2] == 4
+        check(lib().bhray_set_texture(self._h, slot, a.ctypes.data, a.shape[1], a.shape[0]), self._h)
+
+    def set_textures(self, temp_lut, disk, sky):
+        self.set_texture(TEX_TEMP_LUT, temp_lut); self.set_texture(TEX_DISK, disk); self.set_texture(TEX_SKY, sky)
+
+    def upload_model(self, model: Model, index=0):
+        d = model.desc()
+        check(lib().bhray_upload_model(self._h, index, C.byref(d)), self._h)
+
+    def upload_model_uniform(self, blob: bytes, index=0):
+        check(lib().bhray_upload_model_uniform(self._h, index, blob, len(blob)), self._h)
+
+    def set_model_transform(self, position, visible=1, index=0):
+        check(lib().bhray_set_model_transform(self._h, index, (C.c_float * 3)(*[float(x) for x in position]), int(visible)), self._h)
+
+    # -- per frame
+    def set_uniforms(self, camera: bytes, black_hole: bytes, details: bytes):
+        assert len(camera) == 32 and len(black_hole) == 132 and len(details) == 32
+        check(lib().bhray_set_uniforms(self._h, camera, black_hole, details), self._h)
+
+    def render(self):
+        check(lib().bhray_render(self._h), self._h)
+
+    def sync(self):
+        check(lib().bhray_sync(self._h), self._h)
+
+    # -- output
+    @property
+    def frame_size(self):
+        return int(self.cfg.frame_w), int(self.cfg.frame_h)
+
+    def local_rows(self) -> np.ndarray:
+        n = int(lib().bhray_local_rows(self._h))
+        out = np.zeros(n, dtype=np.uint32)
+        r = C.c_uint32()
+        for i in range(n):
+            check(lib().bhray_local_row_index(self._h, i, C.byref(r)), self._h)
+            out[i] = r.value
+        return out
+
+    def read_hdr(self) -> np.ndarray:
+        n = int(lib().bhray_local_rows(self._h))
+        out = np.empty((n, int(self.cfg.frame_w), 4), dtype=np.float32)
+        check(lib().bhray_read_hdr(self._h, out.ctypes.data, out.strides[0]), self._h)
+        return out
+
+    def read_level(self, level: int) -> np.ndarray:
+        w, h = int(self.cfg.level_w[level]), int(self.cfg.level_h[level])
+        out = np.empty((h, w, 4), dtype=np.float32)
+        check(lib().bhray_read_level(self._h, level, out.ctypes.data, out.strides[0]), self._h)
+        return out
+
+    def device_ptr(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        check(lib().bhray_hdr_device_ptr(self._h, C.byref(p), C.byref(n)), self._h)
+        return p.value, n.value
+
+    def bind_output(self, ptr, nbytes):
+        check(lib().bhray_bind_output(self._h, C.c_void_p(ptr), nbytes), self._h)
+
+    def stream(self):
+        s = C.c_void_p()
+        check(lib().bhray_get_stream(self._h, C.byref(s)), self._h)
+        return s.value
+
+    def set_stream(self, s):
+        check(lib().bhray_set_stream(self._h, C.c_void_p(s)), self._h)
+
+    def counters(self) -> dict:
+        c = BhrayCounters()
+        check(lib().bhray_get_counters(self._h, C.byref(c)), self._h)
+        return c.as_dict()
+
+    def timing(self) -> BhrayTiming:
+        t = BhrayTiming()
+        check(lib().bhray_get_timing(self._h, C.byref(t)), self._h)
+        return t
+
+
+class Renderer:
+    """Renderer::{new,render} restricted to the ray pass (mod.rs:113-207, 378-420)."""
+
+    def __init__(self, cfg: BhrayConfig | None = None, device=0, **kw):
+        self.camera = Camera()
+        self.black_hole = BlackHole()
+        self.ray_details = RayDetails()                      # mod.rs:116-121
+        self.ray_pass = RayPass(cfg if cfg is not None else ladder_from_base((72, 41), 3, 4), device=device, **kw)
+        self.model: Model | None = None
+
+    def set_model(self, model: Model):
+        self.model = model
+        self.ray_pass.upload_model(model, 0)
+        self.ray_details.model_count = 1                     # mod.rs:384 (scene.models.size())
+
+    def render(self, dt: float = 0.0):
+        self.ray_details.time += dt                          # mod.rs:382
+        self.ray_pass.set_uniforms(self.camera.uniform(), self.black_hole.uniform(), self.ray_details.uniform())
+        self.ray_pass.render()
+
+    def read_hdr(self):
+        return self.ray_pass.read_hdr()
