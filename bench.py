@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the geodesic ray-trace pass on N MI355X (BASELINE.json metric).
+
+One step = one frame of the workload through the whole pass (all ladder levels; at N>1 also the
+gather of the row tiles to rank 0 and the de-interleave into the frame).  Inputs (uniforms,
+textures, mesh) are resident in HBM before the timed region.  value = frame pixels * steps / time.
+
+    python bench.py                       # N=1, configs[1]: 1920x1080 adaptive RK, disk + adaptive grid
+    python bench.py --workload mesh       # configs[2]: + BVH mesh (.obj)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N   # row-tiled
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (trace_kernel; averaged over
+all its launches, i.e. the 4 ladder levels, so that it matches the per-kernel average of
+`rocprofv3 --kernel-trace --stats`), measured with HIP events recorded on the stream the kernels run
+on.  `cpu_baseline` is the CPU oracle (a port of the reference WGSL; the reference itself is
+Rust+wgpu and cannot run on this box) on a bounded sample, N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_PEAK_TFLOPS = 157.3       # vector FP32 peak
+FLOPS_PER_STEP = {0: 125.0, 1: 390.0}     # Euler / Cash–Karp, incl. per-step hit tests
+FLOPS_NODE_PAIR, FLOPS_TRIANGLE = 60.0, 120.0
+
+
+def algorithmic_bytes_trace(c: dict) -> float:
+    """HBM bytes the trace kernel must move: per traced ray a 4 B queue entry and a
+    16 B RGBA32F store; 32 B per disk shading event (2 bilinear taps x 4 texels x 4 B), 16 B per sky
+    sample, 64 B per BVH node pair, 124 B per leaf triangle."""
+    return (c["traced"] * 20.0 + c["disk_hits"] * 32.0 + c["sky_samples"] * 16.0
+            + c["node_pairs"] * 64.0 + c["triangles"] * 124.0)
+
+
+def algorithmic_bytes_frame(c: dict) -> float:
+    """Whole pass: 16 B store per pixel per level, +16 B per copied pixel, +64 B (4 coarse texels)
+    per interpolated/refined pixel, + the trace-side taps."""
+    refined = c["traced"]
+    return (c["pixels"] * 16.0 + c["copied"] * 16.0 + (c["interpolated"] + refined) * 64.0
+            + c["disk_hits"] * 32.0 + c["sky_samples"] * 16.0 + c["node_pairs"] * 64.0 + c["triangles"] * 124.0)
+
+
+def algorithmic_flops(c: dict, method: int) -> float:
+    return c["steps"] * FLOPS_PER_STEP[method] + c["node_pairs"] * FLOPS_NODE_PAIR + c["triangles"] * FLOPS_TRIANGLE
+
+
+def build_scene(args):
+    import bhusie_amd as B
+    from bhusie_amd import assets
+    tex = (assets.temp_lut(256), assets.disk_texture(1000, seed=1), assets.sky_texture(4096, 2048, seed=2))
+    cam, bh = B.Camera(), B.BlackHole()
+    det = B.RayDetails(integration_method=1, step_size=0.15, max_iterations=args.max_iterations,
+                       angle_division_threshold=0.02, time=0.0)
+    model = None
+    if args.workload == "mesh":
+        import tempfile
+        obj = assets.sphere_mesh_obj(320, 320, radius=8.0, bump=0.15, seed=3)      # 204 160 triangles
+        with tempfile.NamedTemporaryFile("w", suffix=".obj", delete=False) as f:
+            f.write(obj)
+            path = f.name
+        model = B.load_model(path)
+        os.unlink(path)
+        det.model_count = 1
+    return tex, cam, bh, det, model
+
+
+def cpu_baseline(args, tex, cam, bh, det, model):
+    """Oracle (port of ray.wgsl) on a bounded sample: the same camera/scene at a quarter-size frame."""
+    import bhusie_amd as B
+    from oracle import oracle as O
+    fw, fh = max(64, args.width // 2), max(36, args.height // 2)
+    cfg = B.ladder_for_frame((fw, fh), 3, args.levels)
+    models = []
+    if model is not None:
+        models = [model.arrays()]
+    sc = O.OracleScene(cam.uniform(), bh.uniform(), det.uniform(), tex[0], tex[1], tex[2], models)
+    t0 = time.perf_counter()
+    O.render_ladder(sc, cfg.sizes())
+    dt = time.perf_counter() - t0
+    last = cfg.sizes()[-1]
+    return {"value": round(last[0] * last[1] / dt / 1e6, 4), "unit": "Mrays/s", "cores": O.num_threads(), "kind": "port",
+            "sample": f"CPU oracle (C restatement of ray.wgsl, OpenMP x{O.num_threads()}), one {last[0]}x{last[1]} frame "
+                      f"(ladder {cfg.sizes()[0][0]}x{cfg.sizes()[0][1]} x3 x{args.levels}, same camera/scene, adaptive RK), "
+                      f"{dt:.2f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", choices=["disk", "mesh"], default="disk")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--levels", type=int, default=4)
+    ap.add_argument("--max-iterations", type=int, default=2000)
+    ap.add_argument("--stripe-rows", type=int, default=27)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    distributed = world > 1
+
+    torch = dist = None
+    if distributed:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import bhusie_amd as B
+    from bhusie_amd.rowtile import FrameGather
+
+    tex, cam, bh, det, model = build_scene(args)
+    cfg = B.ladder_for_frame((args.width, args.height), 3, args.levels)
+    dev = local_rank if distributed else 0
+
+    def make_pass(**kw):
+        rp = B.RayPass(cfg, device=dev, row_rank=rank, row_world=world, stripe_rows=args.stripe_rows, **kw)
+        rp.set_textures(*tex)
+        if model is not None:
+            rp.upload_model(model)
+        rp.set_uniforms(cam.uniform(), bh.uniform(), det.uniform())
+        return rp
+
+    # counters (algorithmic work) from an untimed render of the same frame
+    rpc = make_pass(counters=True)
+    rpc.render()
+    counters = rpc.counters()
+    rpc.close()
+
+    rp = make_pass(timing=True)
+    gathers = None
+    if distributed:
+        # two frame slots so the gather of frame k overlaps the render of frame k+1
+        gathers = [FrameGather(args.width, args.height, rank, world, args.stripe_rows, 0, device=torch.device("cuda", local_rank))
+                   for _ in range(2)]
+        rp.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    pending = [None, None]
+
+    def step(k):
+        if not distributed:
+            rp.render()
+            return
+        g = gathers[k & 1]
+        if pending[k & 1] is not None:          # slot reuse: its gather (frame k-2) must be complete
+            pending[k & 1].wait()
+            pending[k & 1] = None
+            g.assemble()
+        rp.bind_output(g.local.data_ptr(), g.local.numel() * 4)
+        rp.render()
+        pending[k & 1] = g.gather(async_op=True)
+
+    def drain():
+        if not distributed:
+            rp.sync()
+            return
+        for s in (0, 1):
+            if pending[s] is not None:
+                pending[s].wait()
+                pending[s] = None
+                gathers[s].assemble()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    drain()
+    rp.timing()                                  # reset the event aggregation
+    if distributed:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    drain()
+    if distributed:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    tm = rp.timing()
+    if rank == 0:
+        pixels = args.width * args.height
+        ms_per_step = elapsed / args.steps * 1e3
+        value = pixels * args.steps / elapsed / 1e6
+        # dominant kernel: trace_kernel (rank 0's launches; at N>1 rank 0 traced only its row tiles, and
+        # `counters` are then rank 0's as well, so bytes and time stay consistent)
+        launches = max(1, tm.trace_launches)
+        avg_ms = tm.trace_ms / launches
+        frames = max(1, tm.frames)
+        bytes_per_launch = algorithmic_bytes_trace(counters) * frames / launches
+        achieved_gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        flops_per_frame = algorithmic_flops(counters, 1)
+        valu_tflops = flops_per_frame * frames / (tm.trace_ms * 1e-3) / 1e12 if tm.trace_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/sec at 1920x1080 adaptive-RK4; 1/2/4/8 MI355X + % HBM roofline",
+            "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": ("configs[2]: " if args.workload == "mesh" else "configs[1]: ")
+                + f"{args.width}x{args.height} adaptive RK (Cash-Karp), accretion disk + adaptive background grid"
+                + (" + BVH mesh (204160-triangle OBJ) at (-10,0,30)" if args.workload == "mesh" else ""),
+                "ladder": [list(s) for s in cfg.sizes()], "crop": [int(cfg.crop_x), int(cfg.crop_y)],
+                "step_size": 0.15, "max_iterations": args.max_iterations, "angle_division_threshold": 0.02,
+                "parallelism": f"row-tiled x{world}, stripes of {args.stripe_rows} rows, gather to rank 0" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "trace_kernel", "achieved": round(achieved_gbs, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": None,
+                "avg_launch_ms": round(avg_ms, 5), "launches": int(tm.trace_launches),
+                "algorithmic_bytes_per_launch": round(bytes_per_launch, 1),
+                "note": "VALU-bound f32 ODE march (SURVEY.md F8): algorithmic HBM traffic is tiny; see `valu` for the binding roofline",
+            },
+            "valu": {"achieved": round(valu_tflops, 4), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(valu_tflops / VALU_PEAK_TFLOPS, 6),
+                     "algorithmic_flops_per_frame": flops_per_frame},
+            "pass_ms": {"event_total": round(tm.total_ms / frames, 5), "trace": round(tm.trace_ms / frames, 5),
+                        "classify": round(tm.classify_ms / frames, 5),
+                        "level_trace": [round(tm.level_trace_ms[i] / frames, 5) for i in range(args.levels)]},
+            "counters": counters,
+            "algorithmic_bytes_per_frame": algorithmic_bytes_frame(counters),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, tex, cam, bh, det, model)
+        print(json.dumps(out), flush=True)
+    rp.close()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -30,7 +30,6 @@ struct Level {
     int32_t* d_rowmap = nullptr;    // final level only
     uint32_t* queue = nullptr;
     size_t queue_cap = 0;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // before classify, before trace, after trace
 };
 
 struct ModelStore {
@@ -65,7 +64,9 @@ struct bhray_ctx {
     bool have_uniforms = false;
     // work queues
     uint32_t* d_qctl = nullptr;            // [2*levels]: qcount[l], qhead[l]
-    Counters64* d_counters = nullptr;
+    Counters64* d_counters = nullptr;      // [BHRAY_MAX_LEVELS]
+    std::vector<hipEvent_t> events;        // ring: [BHRAY_TIMING_RING][levels][3] (before classify, before trace, after trace)
+    uint64_t frame_counter = 0, timing_begin = 0;
     int* d_err = nullptr;
     int num_cus = 256;
     bool rendered = false;
@@ -228,13 +229,13 @@ void bhray_destroy(bhray_ctx* c) {
         if (L.d_rows) (void)hipFree(L.d_rows);
         if (L.d_rowmap) (void)hipFree(L.d_rowmap);
         if (L.queue) (void)hipFree(L.queue);
-        for (auto& e : L.ev) if (e) (void)hipEventDestroy(e);
     }
     if (c->own_out) (void)hipFree(c->own_out);
     for (auto& t : c->tex) if (t) (void)hipFree(t);
     for (auto& m : c->models) free_model(m);
     if (c->d_qctl) (void)hipFree(c->d_qctl);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    for (auto& e : c->events) if (e) (void)hipEventDestroy(e);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -314,7 +315,6 @@ int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
             CHK(hipMalloc(&L.d_rowmap, (size_t)L.h * sizeof(int32_t)));
             CHK(hipMemcpy(L.d_rowmap, map.data(), (size_t)L.h * sizeof(int32_t), hipMemcpyHostToDevice));
         }
-        if (cfg->flags & BHRAY_F_TIMING) for (auto& e : L.ev) CHK(hipEventCreate(&e));
     }
     c->out_bytes = c->local_rows.size() * (size_t)cfg->frame_w * sizeof(float4);
     if (c->out_bytes) {
@@ -324,8 +324,12 @@ int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
     c->out = c->own_out;
     CHK(hipMalloc(&c->d_qctl, 2 * BHRAY_MAX_LEVELS * sizeof(uint32_t)));
     CHK(hipMemset(c->d_qctl, 0, 2 * BHRAY_MAX_LEVELS * sizeof(uint32_t)));
-    CHK(hipMalloc(&c->d_counters, sizeof(Counters64)));
-    CHK(hipMemset(c->d_counters, 0, sizeof(Counters64)));
+    CHK(hipMalloc(&c->d_counters, BHRAY_MAX_LEVELS * sizeof(Counters64)));
+    CHK(hipMemset(c->d_counters, 0, BHRAY_MAX_LEVELS * sizeof(Counters64)));
+    if (cfg->flags & BHRAY_F_TIMING) {
+        c->events.assign((size_t)BHRAY_TIMING_RING * nl * 3, nullptr);
+        for (auto& e : c->events) CHK(hipEventCreate(&e));
+    }
     CHK(hipMalloc(&c->d_err, sizeof(int)));
     CHK(hipMemset(c->d_err, 0, sizeof(int)));
     // 1x1 opaque-black defaults so a missing texture cannot fault
@@ -470,7 +474,8 @@ int bhray_render(bhray_ctx* c) {
     const uint32_t nl = c->cfg.levels;
     const bool count = (c->cfg.flags & BHRAY_F_COUNTERS) != 0, timing = (c->cfg.flags & BHRAY_F_TIMING) != 0;
     HIPCHK(c, hipMemsetAsync(c->d_qctl, 0, 2 * BHRAY_MAX_LEVELS * sizeof(uint32_t), c->stream));
-    if (count) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, sizeof(Counters64), c->stream));
+    if (count) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, BHRAY_MAX_LEVELS * sizeof(Counters64), c->stream));
+    hipEvent_t* fev = timing ? &c->events[(size_t)(c->frame_counter % BHRAY_TIMING_RING) * nl * 3] : nullptr;
     const int bpc = trace_blocks_per_cu(P.method, P.model_count > 0, count);
     const int grid = c->num_cus * bpc;
     for (uint32_t l = 0; l < nl; l++) {
@@ -494,13 +499,14 @@ int bhray_render(bhray_ctx* c) {
         }
         L.rows = Lv.d_rows; L.nrows = (int)Lv.rows.size();
         uint32_t* qcount = c->d_qctl + 2 * l; uint32_t* qhead = qcount + 1;
-        if (timing) HIPCHK(c, hipEventRecord(Lv.ev[0], c->stream));
-        HIPCHK(c, launch_classify(P, L, Lv.queue, qcount, count ? c->d_counters : nullptr, c->stream));
-        if (timing) HIPCHK(c, hipEventRecord(Lv.ev[1], c->stream));
-        HIPCHK(c, launch_trace(P, L, Lv.queue, qcount, qhead, count ? c->d_counters : nullptr, c->d_err, grid, c->stream));
-        if (timing) HIPCHK(c, hipEventRecord(Lv.ev[2], c->stream));
+        if (timing) HIPCHK(c, hipEventRecord(fev[3 * l + 0], c->stream));
+        HIPCHK(c, launch_classify(P, L, Lv.queue, qcount, count ? c->d_counters + l : nullptr, c->stream));
+        if (timing) HIPCHK(c, hipEventRecord(fev[3 * l + 1], c->stream));
+        HIPCHK(c, launch_trace(P, L, Lv.queue, qcount, qhead, count ? c->d_counters + l : nullptr, c->d_err, grid, c->stream));
+        if (timing) HIPCHK(c, hipEventRecord(fev[3 * l + 2], c->stream));
     }
     c->rendered = true;
+    c->frame_counter++;
     return BHRAY_OK;
 }
 
@@ -591,36 +597,57 @@ int bhray_set_stream(bhray_ctx* c, void* s) {
     return BHRAY_OK;
 }
 
-int bhray_get_counters(bhray_ctx* c, bhray_counters* out) {
+int bhray_get_level_counters(bhray_ctx* c, uint32_t level, bhray_counters* out) {
     if (!c || !out) return BHRAY_E_INVALID;
     if (!(c->cfg.flags & BHRAY_F_COUNTERS)) return fail(c, BHRAY_E_STATE, "ctx created without BHRAY_F_COUNTERS");
+    if (level >= c->cfg.levels) return fail(c, BHRAY_E_INVALID, "level out of range");
     int rc = bhray_sync(c);
     if (rc) return rc;
     static_assert(sizeof(bhray_counters) == sizeof(Counters64), "counter layout");
-    HIPCHK(c, hipMemcpy(out, c->d_counters, sizeof(Counters64), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out, c->d_counters + level, sizeof(Counters64), hipMemcpyDeviceToHost));
+    return BHRAY_OK;
+}
+
+int bhray_get_counters(bhray_ctx* c, bhray_counters* out) {
+    if (!c || !out) return BHRAY_E_INVALID;
+    memset(out, 0, sizeof *out);
+    for (uint32_t l = 0; l < c->cfg.levels; l++) {
+        bhray_counters t;
+        int rc = bhray_get_level_counters(c, l, &t);
+        if (rc) return rc;
+        const uint64_t* a = (const uint64_t*)&t; uint64_t* b = (uint64_t*)out;
+        for (size_t k = 0; k < sizeof(bhray_counters) / 8; k++) b[k] += a[k];
+    }
     return BHRAY_OK;
 }
 
 int bhray_get_timing(bhray_ctx* c, bhray_timing* out) {
     if (!c || !out) return BHRAY_E_INVALID;
     if (!(c->cfg.flags & BHRAY_F_TIMING)) return fail(c, BHRAY_E_STATE, "ctx created without BHRAY_F_TIMING");
-    if (!c->rendered) return fail(c, BHRAY_E_STATE, "nothing rendered yet");
     int rc = bhray_sync(c);
     if (rc) return rc;
     memset(out, 0, sizeof *out);
-    hipEvent_t first = nullptr, last = nullptr;
-    for (uint32_t l = 0; l < c->cfg.levels; l++) {
-        Level& L = c->levels[l];
-        if (L.rows.empty()) continue;
-        float a = 0, b = 0;
-        HIPCHK(c, hipEventElapsedTime(&a, L.ev[0], L.ev[1]));
-        HIPCHK(c, hipEventElapsedTime(&b, L.ev[1], L.ev[2]));
-        out->classify_ms += a; out->trace_ms += b; out->level_trace_ms[l] = b;
-        out->classify_launches++; out->trace_launches++;
-        if (!first) first = L.ev[0];
-        last = L.ev[2];
+    const uint32_t nl = c->cfg.levels;
+    uint64_t begin = c->timing_begin;
+    if (c->frame_counter - begin > BHRAY_TIMING_RING) begin = c->frame_counter - BHRAY_TIMING_RING;
+    for (uint64_t f = begin; f < c->frame_counter; f++) {
+        hipEvent_t* ev = &c->events[(size_t)(f % BHRAY_TIMING_RING) * nl * 3];
+        hipEvent_t first = nullptr, last = nullptr;
+        for (uint32_t l = 0; l < nl; l++) {
+            if (c->levels[l].rows.empty()) continue;
+            float a = 0, b = 0;
+            HIPCHK(c, hipEventElapsedTime(&a, ev[3 * l], ev[3 * l + 1]));
+            HIPCHK(c, hipEventElapsedTime(&b, ev[3 * l + 1], ev[3 * l + 2]));
+            out->classify_ms += a; out->trace_ms += b;
+            out->level_classify_ms[l] += a; out->level_trace_ms[l] += b;
+            out->classify_launches++; out->trace_launches++;
+            if (!first) first = ev[3 * l];
+            last = ev[3 * l + 2];
+        }
+        if (first && last) { float t = 0; HIPCHK(c, hipEventElapsedTime(&t, first, last)); out->total_ms += t; }
+        out->frames++;
     }
-    if (first && last) HIPCHK(c, hipEventElapsedTime(&out->total_ms, first, last));
+    c->timing_begin = c->frame_counter;
     return BHRAY_OK;
 }
 

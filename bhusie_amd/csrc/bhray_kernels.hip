@@ -18,7 +18,7 @@
 // No MFMA: the path is an f32 ODE march (VALU) plus byte/int texture and BVH reads (HBM/L2).
 // Numerics: DESIGN.md §Numerics — compiled with -ffp-contract=off; operation order follows the
 // shader so results are bit-identical to the CPU oracle except for the shading-only
-// transcendentals (atan2f/sinf/cosf/powf from the device libm).
+// optical-depth powf(.,1.3) (device libm, 1-2 ulp, not amplified).
 #include "bhray_internal.h"
 #include "bhray_math.h"
 
@@ -70,6 +70,54 @@ __device__ __forceinline__ float bh_acos(float x) {              // ray.wgsl:266
     if (x > 0.5f) { float z = sqrtf((1.0f - x) * 0.5f); return 2.0f * bh_asin_kernel(z); }
     if (x < -0.5f) { float z = sqrtf((1.0f + x) * 0.5f); return 3.14159274f - 2.0f * bh_asin_kernel(z); }
     return 1.57079637f - bh_asin_kernel(x);
+}
+
+
+__device__ __forceinline__ float bh_atan2(float y, float x) {      // ray.wgsl:257-258, 632
+    float ax = fabsf(x), ay = fabsf(y);
+    float mx = ax < ay ? ay : ax, mn = ax < ay ? ax : ay;
+    float a = mx == 0.0f ? 0.0f : mn / mx;
+    float t = a, base = 0.0f;
+    if (a > 0.414213568f) { t = (a - 1.0f) / (a + 1.0f); base = 0.785398185f; }
+    float z = t * t;
+    float p = 8.05374449538e-2f;
+    p = p * z - 1.38776856032e-1f;
+    p = p * z + 1.99777106478e-1f;
+    p = p * z - 3.33329491539e-1f;
+    float r = base + ((p * z) * t + t);
+    if (ay > ax) r = 1.57079637f - r;
+    if (x < 0.0f) r = 3.14159274f - r;
+    return (__float_as_uint(y) >> 31) ? -r : r;
+}
+
+template <int KIND>   // 0 sin, 1 cos (ray.wgsl:634)
+__device__ __forceinline__ float bh_sincos(float xin) {
+    float x = fabsf(xin);
+    bool sign = (KIND == 0) ? ((__float_as_uint(xin) >> 31) != 0u) : false;
+    if (!(x <= 3.0e9f)) return __uint_as_float(0x7fc00000u);
+    uint32_t j = (uint32_t)(x * 1.27323954f);
+    j = j + (j & 1u);
+    float y = (float)j;
+    x = ((x - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    j = j & 7u;
+    if (j > 3u) { sign = !sign; j = j - 4u; }
+    if (KIND == 1 && j > 1u) sign = !sign;
+    float z = x * x;
+    const bool mid = (j == 1u || j == 2u);
+    const bool use_cos = (KIND == 0) ? mid : !mid;
+    float r;
+    if (use_cos) {
+        float p = 2.443315711809948e-5f;
+        p = p * z - 1.388731625493765e-3f;
+        p = p * z + 4.166664568298827e-2f;
+        r = ((p * z) * z - 0.5f * z) + 1.0f;
+    } else {
+        float p = -1.9515295891e-4f;
+        p = p * z + 8.3321608736e-3f;
+        p = p * z - 1.6666654611e-1f;
+        r = (p * z) * x + x;
+    }
+    return sign ? -r : r;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -169,9 +217,9 @@ __device__ __noinline__ void shade_disk(const FrameParams& P, F3 pos, F3 dir, fl
         F3 rel = div_s(ip - bpos, P.outer);
         F3 c0 = f3(P.M[0], P.M[1], P.M[2]), c1 = f3(P.M[3], P.M[4], P.M[5]), c2 = f3(P.M[6], P.M[7], P.M[8]);
         F3 rot = (c0 * rel.x + c1 * rel.y) + c2 * rel.z;
-        float angle = -atan2f(rot.z, rot.x);
+        float angle = -bh_atan2(rot.z, rot.x);
         float ph = angle + P.time * P.rot_speed;
-        float u = sinf(ph) * r, v = cosf(ph) * r;
+        float u = bh_sincos<0>(ph) * r, v = bh_sincos<1>(ph) * r;
         u = (u + 1.0f) * 0.5f; v = (v + 1.0f) * 0.5f;
         float4 dc = sample_bilinear(P.disk, u, v);
         rs.opacity *= clamp_(0.7f + dc.w * 0.5f, 0.0f, 1.0f);
@@ -556,8 +604,8 @@ __global__ __launch_bounds__(256) void trace_kernel(const FrameParams P, const L
                     if (amount > 0.001f) {
                         if (COUNT) cnt[9]++;
                         // cartesian_to_spherical(dir.xzy), ray.wgsl:255-261, 585-586
-                        const float theta = atan2f(sqrtf(cdir.x * cdir.x + cdir.z * cdir.z), cdir.y);
-                        const float phi = atan2f(cdir.z, cdir.x);
+                        const float theta = bh_atan2(sqrtf(cdir.x * cdir.x + cdir.z * cdir.z), cdir.y);
+                        const float phi = bh_atan2(cdir.z, cdir.x);
                         const float PI_F = 3.1415926f;
                         float u = (phi + 2.6f * PI_F) / (2.0f * PI_F);
                         float v = (PI_F - theta) / PI_F;

@@ -76,9 +76,9 @@ class BhrayCounters(C.Structure):
 
 
 class BhrayTiming(C.Structure):
-    _fields_ = [("total_ms", C.c_float), ("trace_ms", C.c_float), ("classify_ms", C.c_float),
+    _fields_ = [("frames", C.c_uint32), ("total_ms", C.c_float), ("trace_ms", C.c_float), ("classify_ms", C.c_float),
                 ("trace_launches", C.c_uint32), ("classify_launches", C.c_uint32),
-                ("level_trace_ms", C.c_float * MAX_LEVELS)]
+                ("level_trace_ms", C.c_float * MAX_LEVELS), ("level_classify_ms", C.c_float * MAX_LEVELS)]
 
 
 assert C.sizeof(BhrayDetails) == 32 and C.sizeof(BhrayCameraUniform) == 32 and C.sizeof(BhrayBlackHoleUniform) == 132
@@ -112,6 +112,7 @@ SYMBOLS = {
     "bhray_get_stream": (C.c_int, [vp, P(vp)]),
     "bhray_set_stream": (C.c_int, [vp, vp]),
     "bhray_get_counters": (C.c_int, [vp, P(BhrayCounters)]),
+    "bhray_get_level_counters": (C.c_int, [vp, u32, P(BhrayCounters)]),
     "bhray_get_timing": (C.c_int, [vp, P(BhrayTiming)]),
     "bhray_camera_uniform_update": (None, [P(BhrayCameraUniform), P(C.c_float), P(C.c_float), C.c_float]),
     "bhray_black_hole_default": (None, [P(BhrayBlackHole)]),

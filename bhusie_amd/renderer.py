@@ -131,6 +131,11 @@ class RayPass:
         check(lib().bhray_get_counters(self._h, C.byref(c)), self._h)
         return c.as_dict()
 
+    def level_counters(self, level: int) -> dict:
+        c = BhrayCounters()
+        check(lib().bhray_get_level_counters(self._h, level, C.byref(c)), self._h)
+        return c.as_dict()
+
     def timing(self) -> BhrayTiming:
         t = BhrayTiming()
         check(lib().bhray_get_timing(self._h, C.byref(t)), self._h)

@@ -244,14 +244,20 @@ typedef struct bhray_counters {        /* summed over all levels of the last ren
     uint64_t sky_samples;              /* in-kernel sky taps (ray.wgsl:587)                  */
 } bhray_counters;
 int bhray_get_counters(bhray_ctx* ctx, bhray_counters* out);   /* needs BHRAY_F_COUNTERS     */
+int bhray_get_level_counters(bhray_ctx* ctx, uint32_t level, bhray_counters* out);
 
+/* HIP-event timing of every launch (events recorded on the ctx stream).  bhray_get_timing sums
+ * over the frames rendered since the previous call (at most BHRAY_TIMING_RING of them).       */
+#define BHRAY_TIMING_RING 128
 typedef struct bhray_timing {
-    float    total_ms;                 /* first launch → last launch of the last render      */
+    uint32_t frames;                   /* frames aggregated                                  */
+    float    total_ms;                 /* Σ (first launch → last launch) per frame           */
     float    trace_ms;                 /* Σ trace kernels                                    */
     float    classify_ms;              /* Σ grid classify kernels                            */
     uint32_t trace_launches;
     uint32_t classify_launches;
     float    level_trace_ms[BHRAY_MAX_LEVELS];
+    float    level_classify_ms[BHRAY_MAX_LEVELS];
 } bhray_timing;
 int bhray_get_timing(bhray_ctx* ctx, bhray_timing* out);       /* needs BHRAY_F_TIMING       */
 

@@ -22,9 +22,11 @@
  *   N2  vector / scalar  = vector * (1.0f / scalar)   (one correctly rounded reciprocal)
  *       normalize(v)     = v / length(v) under N2
  *   N3  pow(x, 2.0) = x*x ; pow(x, 4.0) = (x*x)*(x*x) ; pow(x, 5.0) = ((x*x)*(x*x))*x
- *   N4  pow(e_max, -0.001) and acos() use the portable polynomial forms bh_pow_m001 /
- *       bh_acos below (trajectory- and classification-relevant, so they are specified to
- *       the bit); the shading-only transcendentals (atan2, sin, cos, pow(.,1.3)) use libm.
+ *   N4  pow(e_max, -0.001), acos, atan2, sin and cos use the portable polynomial forms bh_*
+ *       below, specified to the bit: they steer the trajectory (pow), the copy/interpolate/
+ *       trace classification (acos) or texture coordinates, where an ulp is amplified by the
+ *       texture gradient (atan2, sin, cos).  Only pow(.,1.3) (optical depth, ray.wgsl:623)
+ *       uses libm; its 1-2 ulp spread is not amplified.
  *   N5  mix(a,b,t) = a*(1-t) + b*t ; clamp(x,lo,hi) = min(max(x,lo),hi) with
  *       max(a,b) = a<b ? b : a and min(a,b) = b<a ? b : a ; smoothstep per WGSL spec.
  *   N6  untyped WGSL `const` expressions (the Cash–Karp tableau, b_i - b*_i) are evaluated
@@ -163,6 +165,58 @@ float bh_acos(float x) {
     return 1.57079637f - bh_asin_kernel(x);
 }
 
+
+/* atan2(y,x) (ray.wgsl:257-258, 632): a = min/max of |x|,|y|; atan(a) on [0,1] with one reduction at
+ * tan(pi/8) and the classic degree-4 odd single-precision kernel; then octant / sign fix-ups. */
+float bh_atan2(float y, float x) {
+    float ax = fabsf(x), ay = fabsf(y);
+    float mx = ax < ay ? ay : ax, mn = ax < ay ? ax : ay;
+    float a = mx == 0.0f ? 0.0f : mn / mx;
+    float t = a, base = 0.0f;
+    if (a > 0.414213568f) { t = (a - 1.0f) / (a + 1.0f); base = 0.785398185f; }
+    float z = t * t;
+    float p = 8.05374449538e-2f;
+    p = p * z - 1.38776856032e-1f;
+    p = p * z + 1.99777106478e-1f;
+    p = p * z - 3.33329491539e-1f;
+    float r = base + ((p * z) * t + t);
+    if (ay > ax) r = 1.57079637f - r;
+    if (x < 0.0f) r = 3.14159274f - r;
+    return (f2u(y) >> 31) ? -r : r;
+}
+
+/* sin / cos (ray.wgsl:634): Cody–Waite reduction by pi/4 octants (three-part pi/4, exact products for
+ * |x| < 8192) and the classic single-precision kernels on [-pi/4, pi/4].  kind 0 = sin, 1 = cos. */
+static inline float bh_sincos(float xin, int kind) {
+    float x = fabsf(xin);
+    int sign = (kind == 0) ? (int)(f2u(xin) >> 31) : 0;
+    if (!(x <= 3.0e9f)) return u2f(0x7fc00000u);         /* inf / NaN (and beyond int range) */
+    uint32_t j = (uint32_t)(x * 1.27323954f);            /* x * 4/pi, truncated */
+    j = j + (j & 1u);
+    float y = (float)j;
+    x = ((x - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    j = j & 7u;
+    if (j > 3u) { sign = !sign; j = j - 4u; }
+    if (kind == 1 && j > 1u) sign = !sign;
+    float z = x * x;
+    int use_cos = (kind == 0) ? (j == 1u || j == 2u) : !(j == 1u || j == 2u);
+    float r;
+    if (use_cos) {
+        float p = 2.443315711809948e-5f;
+        p = p * z - 1.388731625493765e-3f;
+        p = p * z + 4.166664568298827e-2f;
+        r = ((p * z) * z - 0.5f * z) + 1.0f;
+    } else {
+        float p = -1.9515295891e-4f;
+        p = p * z + 8.3321608736e-3f;
+        p = p * z - 1.6666654611e-1f;
+        r = (p * z) * x + x;
+    }
+    return sign ? -r : r;
+}
+float bh_sin(float x) { return bh_sincos(x, 0); }
+float bh_cos(float x) { return bh_sincos(x, 1); }
+
 /* ---- textures: texture.rs:16-69 + textureSampleLevel(.., 0.0) --------------------------- */
 static inline v4 texel(const o_tex* t, int x, int y) {
     const uint8_t* p = t->rgba + 4 * ((size_t)y * (size_t)t->w + (size_t)x);
@@ -219,8 +273,8 @@ static const float db_1 = K(37.0 / 378.0 - 2825.0 / 27648.0), db_2 = K(0.0 - 0.0
 /* ---- ray.wgsl:245-267 helpers ------------------------------------------------------------ */
 static v3 cartesian_to_spherical(v3 c) {                       /* ray.wgsl:255-261 */
     float rho = length(c);
-    float theta = atan2f(sqrtf(c.x * c.x + c.y * c.y), c.z);
-    float phi = atan2f(c.y, c.x);
+    float theta = bh_atan2(sqrtf(c.x * c.x + c.y * c.y), c.z);
+    float phi = bh_atan2(c.y, c.x);
     return V(rho, theta, phi);
 }
 static float angle_between(v3 v1, v3 v2) {                     /* ray.wgsl:263-267 */
@@ -318,9 +372,9 @@ static RenderState hit_black_hole(const scene* S, Ray ray, float t_min, float t_
             const float* M = bh->rotation_matrix;
             v3 c0 = V(M[0], M[1], M[2]), c1 = V(M[4], M[5], M[6]), c2 = V(M[8], M[9], M[10]);
             v3 rot = add(add(muls(c0, rel.x), muls(c1, rel.y)), muls(c2, rel.z));
-            float angle = -atan2f(rot.z, rot.x);
+            float angle = -bh_atan2(rot.z, rot.x);
             float ph = angle + S->details->time * bh->rotation_speed;
-            float u = sinf(ph) * r, v = cosf(ph) * r;
+            float u = bh_sin(ph) * r, v = bh_cos(ph) * r;
             u = (u + 1.0f) * 0.5f; v = (v + 1.0f) * 0.5f;              /* (uv+1)/2 under N2 */
             v4 dc = sample_bilinear(&S->t_disk, u, v);
             rs.opacity *= clampf(0.7f + dc.w * 0.5f, 0.0f, 1.0f);

@@ -84,3 +84,80 @@ def test_crop_window_and_row_partition():
         assert len(rows) > 0 and np.all((rows // 9) % 3 == rank)
         canvas[rows] = rp.read_hdr()
     assert np.array_equal(canvas, full), "row-partitioned render must reassemble bit-identically"
+
+
+def _mesh_model(tmp_path, n_lat=20, n_lon=28, with_normals=True):
+    from bhusie_amd import assets
+    p = tmp_path / "mesh.obj"
+    p.write_text(assets.sphere_mesh_obj(n_lat, n_lon, radius=8.0, bump=0.2, seed=5, with_normals=with_normals))
+    return B.load_model(str(p))
+
+
+@pytest.mark.parametrize("with_normals", [True, False])
+def test_mesh_parity(tmp_path, with_normals):
+    """configs[2]: BVH mesh in the flat-space phases (ray.wgsl:556), default model position (-10,0,30)."""
+    tex = T.textures()
+    model = _mesh_model(tmp_path, with_normals=with_normals)
+    # camera outside the sphere looking at both the hole and the mesh
+    d = np.array([-0.12, 0.0, 1.0]); d /= np.linalg.norm(d)
+    cam = B.Camera(position=(0.0, 0.0, -40.0), forward=tuple(d), fov=1.2)
+    for method in (0, 1):
+        u = T.uniforms(camera=cam, integration_method=method, model_count=1)
+        cfg = B.ladder_from_base((40, 24), 3, 2)
+        rp = run_gpu(cfg, *u, tex, model=model, counters=True)
+        cnt = O.Counters()
+        want = O.render_ladder(T.oracle_scene(*u, tex, [model.arrays()]), cfg.sizes(), cnt)
+        T.assert_parity(rp.read_hdr(), want[-1], f"mesh method {method}")
+        c = rp.counters()
+        assert c == cnt.as_dict()
+        assert c["triangles"] > 0 and c["node_pairs"] > 0
+
+
+def test_mesh_behind_hole_is_lensed(tmp_path):
+    """Camera inside the sphere, mesh beyond it: rays leave the sphere bent and then hit the mesh."""
+    tex = T.textures()
+    model = _mesh_model(tmp_path)
+    model.set_transform((-6.0, 0.0, 32.0), 1)
+    u = T.uniforms(integration_method=1, model_count=1)
+    cfg = B.ladder_from_base((48, 27), 3, 2)
+    rp = run_gpu(cfg, *u, tex, model=model, counters=True)
+    want = O.render_ladder(T.oracle_scene(*u, tex, [model.arrays()]), cfg.sizes())
+    T.assert_parity(rp.read_hdr(), want[-1], "mesh behind hole")
+    assert rp.counters()["triangles"] > 0
+
+
+def test_model_uniform_blob_equals_compact_upload(tmp_path):
+    """The exact 48 234 572-byte ModelUniform (triangle.rs:268-325) and the compact upload give the same frame;
+    set_model_transform replaces the per-frame 48 MB re-upload (mod.rs:391)."""
+    tex = T.textures()
+    model = _mesh_model(tmp_path, 10, 14)
+    cam = B.Camera(position=(0.0, 0.0, -40.0), forward=(-0.12, 0.0, 0.99), fov=1.2)
+    u = T.uniforms(camera=cam, integration_method=0, model_count=1)
+    cfg = B.ladder_from_base((40, 24), 3, 1)
+    a = run_gpu(cfg, *u, tex, model=model).read_hdr()
+    rp = B.RayPass(cfg, device=0)
+    rp.set_textures(*tex)
+    rp.upload_model_uniform(model.pack_uniform())
+    rp.set_uniforms(*u)
+    rp.render()
+    b = rp.read_hdr()
+    assert np.array_equal(a, b)
+    rp.set_model_transform((0.0, 0.0, 60.0), 0)       # invisible: no triangle may be hit
+    rp.render()
+    c = rp.read_hdr()
+    want = O.render_level(T.oracle_scene(*T.uniforms(camera=cam, integration_method=0, model_count=0), tex), (40, 24))
+    T.assert_parity(c, want, "invisible model")
+
+
+def test_reference_native_ladder_1918x1081():
+    """The reference's shipped configuration (mod.rs:177-179): 72x41 x3 x4 -> 1918x1081, adaptive RK."""
+    tex = T.textures()
+    u = T.uniforms(integration_method=1)
+    cfg = B.ladder_from_base((72, 41), 3, 4)
+    assert cfg.sizes()[-1] == (1918, 1081)
+    rp = run_gpu(cfg, *u, tex, counters=True)
+    cnt = O.Counters()
+    want = O.render_ladder(T.oracle_scene(*u, tex), cfg.sizes(), cnt)
+    mx, exact = T.assert_parity(rp.read_hdr(), want[-1], "1918x1081")
+    assert rp.counters() == cnt.as_dict()
+    print(f"1918x1081: max rel {mx:.3g}, bit-exact {exact:.5f}, counters {cnt.as_dict()}")
