@@ -115,7 +115,7 @@ void derive_frame(const bhray_ctx* c, FrameParams& P) {
     const F3 plane_up = f3(0.0f, -1.0f, 0.0f);
     const F3 right = normalize(cross(fwd, plane_up));               // ray.wgsl:276
     const F3 up = normalize(cross(fwd, right));                     // ray.wgsl:277
-    const float fov_factor = 1.0f / tanf(cam.fov / 2.0f);           // ray.wgsl:279
+    const float fov_factor = 1.0f / bh_tan(cam.fov / 2.0f);         // ray.wgsl:279
     const F3 fwd_ff = fwd * fov_factor;
     const F3 cpos = ld3(cam.position), bpos = ld3(bh.position);
     P.cam[0] = cpos.x; P.cam[1] = cpos.y; P.cam[2] = cpos.z;

@@ -67,6 +67,9 @@ struct bhray_model {
                 }
             }
         }
+        // f32::min/max leave the sign of a zero result unspecified (minNum(-0,+0) may be either);
+        // canonicalise zero bounds to +0 so that every builder produces the same bytes.
+        for (int a = 0; a < 3; a++) { n.min_corner[a] += 0.0f; n.max_corner[a] += 0.0f; }
     }
 
     // subdivide, triangle.rs:196-259.  The reference recurses (and grows its stack to 1 GiB,

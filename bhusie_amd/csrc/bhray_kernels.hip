@@ -25,102 +25,6 @@
 namespace bhray {
 
 // ------------------------------------------------------------------------------------------
-// portable transcendental forms (numerics contract N4) — same operation sequence as the oracle
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float bh_pow_m001(float x) {          // x^(-0.001), ray.wgsl:459
-    if (!(x == x) || x < 0.0f) return __uint_as_float(0x7fc00000u);
-    if (x == 0.0f) return __uint_as_float(0x7f800000u);
-    if (x == __uint_as_float(0x7f800000u)) return 0.0f;
-    uint32_t u = __float_as_uint(x);
-    int e = (int)(u >> 23) - 127;
-    if ((u >> 23) == 0) { x = x * 8388608.0f; u = __float_as_uint(x); e = (int)(u >> 23) - 127 - 23; }
-    float m = __uint_as_float((u & 0x007fffffu) | 0x3f800000u);
-    if (m > 1.41421354f) { m = m * 0.5f; e = e + 1; }
-    float s = (m - 1.0f) / (m + 1.0f);
-    float s2 = s * s;
-    float p = 0.111111112f;
-    p = p * s2 + 0.142857149f;
-    p = p * s2 + 0.2f;
-    p = p * s2 + 0.333333343f;
-    p = p * s2 + 1.0f;
-    float lnm = (2.0f * s) * p;
-    float lnx = (float)e * 0.693147182f + lnm;
-    float t = -0.001f * lnx;
-    float q = 0.00138888892f;
-    q = q * t + 0.00833333377f;
-    q = q * t + 0.0416666679f;
-    q = q * t + 0.166666672f;
-    q = q * t + 0.5f;
-    q = q * t + 1.0f;
-    q = q * t + 1.0f;
-    return q;
-}
-
-__device__ __forceinline__ float bh_asin_kernel(float z) {
-    float z2 = z * z;
-    float p = 4.2163199048e-2f;
-    p = p * z2 + 2.4181311049e-2f;
-    p = p * z2 + 4.5470025998e-2f;
-    p = p * z2 + 7.4953002686e-2f;
-    p = p * z2 + 1.6666752422e-1f;
-    return z + (z * z2) * p;
-}
-__device__ __forceinline__ float bh_acos(float x) {              // ray.wgsl:266
-    if (!(x == x) || x > 1.0f || x < -1.0f) return __uint_as_float(0x7fc00000u);
-    if (x > 0.5f) { float z = sqrtf((1.0f - x) * 0.5f); return 2.0f * bh_asin_kernel(z); }
-    if (x < -0.5f) { float z = sqrtf((1.0f + x) * 0.5f); return 3.14159274f - 2.0f * bh_asin_kernel(z); }
-    return 1.57079637f - bh_asin_kernel(x);
-}
-
-
-__device__ __forceinline__ float bh_atan2(float y, float x) {      // ray.wgsl:257-258, 632
-    float ax = fabsf(x), ay = fabsf(y);
-    float mx = ax < ay ? ay : ax, mn = ax < ay ? ax : ay;
-    float a = mx == 0.0f ? 0.0f : mn / mx;
-    float t = a, base = 0.0f;
-    if (a > 0.414213568f) { t = (a - 1.0f) / (a + 1.0f); base = 0.785398185f; }
-    float z = t * t;
-    float p = 8.05374449538e-2f;
-    p = p * z - 1.38776856032e-1f;
-    p = p * z + 1.99777106478e-1f;
-    p = p * z - 3.33329491539e-1f;
-    float r = base + ((p * z) * t + t);
-    if (ay > ax) r = 1.57079637f - r;
-    if (x < 0.0f) r = 3.14159274f - r;
-    return (__float_as_uint(y) >> 31) ? -r : r;
-}
-
-template <int KIND>   // 0 sin, 1 cos (ray.wgsl:634)
-__device__ __forceinline__ float bh_sincos(float xin) {
-    float x = fabsf(xin);
-    bool sign = (KIND == 0) ? ((__float_as_uint(xin) >> 31) != 0u) : false;
-    if (!(x <= 3.0e9f)) return __uint_as_float(0x7fc00000u);
-    uint32_t j = (uint32_t)(x * 1.27323954f);
-    j = j + (j & 1u);
-    float y = (float)j;
-    x = ((x - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
-    j = j & 7u;
-    if (j > 3u) { sign = !sign; j = j - 4u; }
-    if (KIND == 1 && j > 1u) sign = !sign;
-    float z = x * x;
-    const bool mid = (j == 1u || j == 2u);
-    const bool use_cos = (KIND == 0) ? mid : !mid;
-    float r;
-    if (use_cos) {
-        float p = 2.443315711809948e-5f;
-        p = p * z - 1.388731625493765e-3f;
-        p = p * z + 4.166664568298827e-2f;
-        r = ((p * z) * z - 0.5f * z) + 1.0f;
-    } else {
-        float p = -1.9515295891e-4f;
-        p = p * z + 8.3321608736e-3f;
-        p = p * z - 1.6666654611e-1f;
-        r = (p * z) * x + x;
-    }
-    return sign ? -r : r;
-}
-
-// ------------------------------------------------------------------------------------------
 // textures: RGBA8 unorm, bilinear, clamp-to-edge (texture.rs:32,61-69; textureSampleLevel 0)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float4 texel(const TexDev& t, int x, int y) {

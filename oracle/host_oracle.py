@@ -161,8 +161,9 @@ class Model:
             idx = self.bvh_lookup[first:first + cnt]
             pts = self._P[self._tri[idx, :3].reshape(-1), :3]
             lo = np.minimum(lo, pts.min(axis=0)); hi = np.maximum(hi, pts.max(axis=0))
-        self.nodes[ni]["min_corner"] = lo
-        self.nodes[ni]["max_corner"] = hi
+        # zero bounds canonicalised to +0 (f32::min/max leave the sign of a zero result unspecified)
+        self.nodes[ni]["min_corner"] = lo + f32(0.0)
+        self.nodes[ni]["max_corner"] = hi + f32(0.0)
 
     def _subdivide(self, ni):                        # triangle.rs:196-259
         n = self.nodes[ni]

@@ -229,7 +229,8 @@ def create_rays(S: Scene, px, py, sw, sh):
     plane_up = np.array([0.0, -1.0, 0.0], dtype=np.float32)
     right = vnorm(vcross(S.cam_fwd, plane_up))
     up = vnorm(vcross(S.cam_fwd, right))
-    ff = f32(1.0) / f32(np.tan(S.fov / f32(2.0)))
+    half = np.asarray([S.fov / f32(2.0)], dtype=np.float32)
+    ff = f32(1.0) / (bh_sin(half) / bh_cos(half))[0]
     d = (posx[:, None] * right[None, :] + posy[:, None] * up[None, :]) + (S.cam_fwd * ff)[None, :]
     d = vnorm(d)
     o = np.broadcast_to(S.cam_pos, d.shape).astype(np.float32).copy()
@@ -288,6 +289,7 @@ def hit_black_hole(S: Scene, pos, dirn, t_min, t_max, total_distance):
     if k.size:
         with np.errstate(invalid="ignore", divide="ignore"):
             p, d, tt = pos[k], dirn[k], td[k]
+            total_distance = np.broadcast_to(np.asarray(total_distance, dtype=np.float32), (n,))[k]
             ip = p + d * tt[:, None]
             dist = vlen(S.bh_pos - ip)
             density = f32(1.0) - vlen(vdivs(ip, S.outer))

@@ -22,7 +22,7 @@
  *   N2  vector / scalar  = vector * (1.0f / scalar)   (one correctly rounded reciprocal)
  *       normalize(v)     = v / length(v) under N2
  *   N3  pow(x, 2.0) = x*x ; pow(x, 4.0) = (x*x)*(x*x) ; pow(x, 5.0) = ((x*x)*(x*x))*x
- *   N4  pow(e_max, -0.001), acos, atan2, sin and cos use the portable polynomial forms bh_*
+ *   N4  pow(e_max, -0.001), acos, atan2, sin, cos and tan (= sin/cos) use the portable forms bh_*
  *       below, specified to the bit: they steer the trajectory (pow), the copy/interpolate/
  *       trace classification (acos) or texture coordinates, where an ulp is amplified by the
  *       texture gradient (atan2, sin, cos).  Only pow(.,1.3) (optical depth, ray.wgsl:623)
@@ -216,6 +216,7 @@ static inline float bh_sincos(float xin, int kind) {
 }
 float bh_sin(float x) { return bh_sincos(x, 0); }
 float bh_cos(float x) { return bh_sincos(x, 1); }
+float bh_tan(float x) { return bh_sincos(x, 0) / bh_sincos(x, 1); }   /* ray.wgsl:279 */
 
 /* ---- textures: texture.rs:16-69 + textureSampleLevel(.., 0.0) --------------------------- */
 static inline v4 texel(const o_tex* t, int x, int y) {
@@ -293,7 +294,7 @@ static Ray create_ray(const scene* S, int px, int py, int sw, int sh) {
     v3 plane_up = V(0.0f, -1.0f, 0.0f);
     v3 right = normalize(cross(fwd, plane_up));
     v3 up = normalize(cross(fwd, right));
-    float fov_factor = 1.0f / tanf(S->camera->fov / 2.0f);
+    float fov_factor = 1.0f / bh_tan(S->camera->fov / 2.0f);
     v3 d = normalize(add(add(muls(right, posx), muls(up, posy)), muls(fwd, fov_factor)));
     Ray r = { fromp(S->camera->position), d };
     return r;
