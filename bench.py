@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--max-iterations", type=int, default=2000)
     ap.add_argument("--stripe-rows", type=int, default=27)
+    ap.add_argument("--frames-in-flight", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -141,38 +142,46 @@ def main():
     counters = rpc.counters()
     rpc.close()
 
-    rp = make_pass(timing=True)
-    gathers = None
+    rp = make_pass(timing=True, frames_in_flight=args.frames_in_flight)
+    gathers = side = None
+    nbuf = max(1, args.frames_in_flight)
     if distributed:
-        # two frame slots so the gather of frame k overlaps the render of frame k+1
-        gathers = [FrameGather(args.width, args.height, rank, world, args.stripe_rows, 0, device=torch.device("cuda", local_rank))
-                   for _ in range(2)]
-        rp.set_stream(torch.cuda.current_stream().cuda_stream)
+        # one gather buffer + one torch side stream per frame in flight: the gather of frame k overlaps
+        # the render of frame k+1; buffer reuse is ordered by the side stream, never by the host
+        dev_t = torch.device("cuda", local_rank)
+        gathers = [FrameGather(args.width, args.height, rank, world, args.stripe_rows, 0, device=dev_t) for _ in range(nbuf)]
+        side = [torch.cuda.Stream(device=dev_t) for _ in range(nbuf)]
 
-    pending = [None, None]
+    pending = [None] * nbuf
 
     def step(k):
         if not distributed:
             rp.render()
             return
-        g = gathers[k & 1]
-        if pending[k & 1] is not None:          # slot reuse: its gather (frame k-2) must be complete
-            pending[k & 1].wait()
-            pending[k & 1] = None
-            g.assemble()
-        rp.bind_output(g.local.data_ptr(), g.local.numel() * 4)
-        rp.render()
-        pending[k & 1] = g.gather(async_op=True)
+        b = k % nbuf
+        g = gathers[b]
+        with torch.cuda.stream(side[b]):
+            if pending[b] is not None:          # frame k-nbuf: gathered -> de-interleave on rank 0
+                pending[b].wait()
+                pending[b] = None
+                g.assemble()
+            rp.wait_stream(side[b].cuda_stream)             # render k may overwrite the buffer only after that
+            rp.bind_output(g.local.data_ptr(), g.local.numel() * 4)
+            rp.render()
+            rp.signal_stream(side[b].cuda_stream)           # the gather reads the buffer only after render k
+            pending[b] = g.gather(async_op=True)
 
     def drain():
         if not distributed:
             rp.sync()
             return
-        for s in (0, 1):
-            if pending[s] is not None:
-                pending[s].wait()
-                pending[s] = None
-                gathers[s].assemble()
+        for b in range(nbuf):
+            with torch.cuda.stream(side[b]):
+                if pending[b] is not None:
+                    pending[b].wait()
+                    pending[b] = None
+                    gathers[b].assemble()
+        rp.sync()
         torch.cuda.synchronize()
 
     for k in range(args.warmup):
@@ -221,6 +230,7 @@ def main():
                 "ladder": [list(s) for s in cfg.sizes()], "crop": [int(cfg.crop_x), int(cfg.crop_y)],
                 "step_size": 0.15, "max_iterations": args.max_iterations, "angle_division_threshold": 0.02,
                 "parallelism": f"row-tiled x{world}, stripes of {args.stripe_rows} rows, gather to rank 0" if world > 1 else "single GPU",
+                "frames_in_flight": args.frames_in_flight,
             },
             "roofline": {
                 "bound": "hbm", "kernel": "trace_kernel", "achieved": round(achieved_gbs, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",

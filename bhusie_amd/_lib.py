@@ -4,7 +4,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbhray.so")
+# BHRAY_LIB selects another in-tree build of the SAME sources (kernel tuning variants); never a fallback.
+LIB_PATH = os.environ.get("BHRAY_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbhray.so")
 
 
 class LibraryMissing(RuntimeError):

@@ -22,14 +22,24 @@ namespace {
 
 thread_local std::string g_create_error;
 
-struct Level {
+struct Level {                      // geometry of one ladder level (shared by all frame slots)
     int w = 0, h = 0;
-    float4* out = nullptr;          // full w*h for non-final levels
     std::vector<int32_t> rows;      // rows to compute
     int32_t* d_rows = nullptr;
     int32_t* d_rowmap = nullptr;    // final level only
-    uint32_t* queue = nullptr;
     size_t queue_cap = 0;
+};
+
+// One frame in flight: its own stream, level images, work queues and output buffer.
+struct Slot {
+    hipStream_t stream = nullptr;
+    std::vector<float4*> level_out;     // [levels-1] full-size images of the non-final levels
+    std::vector<uint32_t*> queue;       // [levels]
+    uint32_t* d_qctl = nullptr;         // [2*levels]: qcount[l], qhead[l]
+    Counters64* d_counters = nullptr;   // [BHRAY_MAX_LEVELS]
+    float4* own_out = nullptr;
+    float4* out = nullptr;              // where this slot's frame is written (own_out or a bound buffer)
+    hipEvent_t done = nullptr;          // recorded after the slot's last launch
 };
 
 struct ModelStore {
@@ -46,12 +56,12 @@ struct ModelStore {
 struct bhray_ctx {
     bhray_config cfg{};
     int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
     std::vector<Level> levels;
-    // output
-    float4* own_out = nullptr;
-    float4* out = nullptr;
+    std::vector<Slot> slots;               // frames in flight
+    int last_slot = 0;                     // slot of the most recently enqueued frame
+    float4* bound_out = nullptr;           // bhray_bind_output: destination of the next frame(s)
+    hipEvent_t wait_ev = nullptr;          // bhray_wait_stream: pending dependency of the next render
+    bool wait_pending = false;
     size_t out_bytes = 0;
     std::vector<uint32_t> local_rows;      // frame rows of this partition, increasing
     // scene
@@ -62,9 +72,6 @@ struct bhray_ctx {
     bhray_black_hole_uniform bh{};
     bhray_details det{};
     bool have_uniforms = false;
-    // work queues
-    uint32_t* d_qctl = nullptr;            // [2*levels]: qcount[l], qhead[l]
-    Counters64* d_counters = nullptr;      // [BHRAY_MAX_LEVELS]
     std::vector<hipEvent_t> events;        // ring: [BHRAY_TIMING_RING][levels][3] (before classify, before trace, after trace)
     uint64_t frame_counter = 0, timing_begin = 0;
     int* d_err = nullptr;
@@ -126,6 +133,7 @@ void derive_frame(const bhray_ctx* c, FrameParams& P) {
     P.relativity0 = P.ray_distance < bh.relativity_sphere_radius ? 1 : 0;
     P.bh[0] = bpos.x; P.bh[1] = bpos.y; P.bh[2] = bpos.z;
     memcpy(P.bn, bh.normal, 12);
+    P.bn_len = length(ld3(bh.normal));
     P.inner = bh.accretion_disk_inner; P.outer = bh.accretion_disk_outer;
     P.rot_speed = bh.rotation_speed; P.R = bh.relativity_sphere_radius;
     P.show_tex = bh.show_disk_texture; P.show_shift = bh.show_red_shift;
@@ -150,6 +158,14 @@ void derive_frame(const bhray_ctx* c, FrameParams& P) {
     if (!any_visible) P.model_count = 0;     // nothing to traverse: the no-mesh kernel variant is exact
     TexDev* t[3] = {&P.temp, &P.disk, &P.sky};
     for (int i = 0; i < 3; i++) { t[i]->rgba = c->tex[i]; t[i]->w = c->tex_w[i]; t[i]->h = c->tex_h[i]; }
+}
+
+hipError_t sync_all(bhray_ctx* c) {
+    for (Slot& S : c->slots) {
+        hipError_t e = hipStreamSynchronize(S.stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 void free_model(ModelStore& m) {
@@ -223,21 +239,25 @@ int bhray_ladder_for_frame(uint32_t frame_w, uint32_t frame_h, uint32_t m, uint3
 void bhray_destroy(bhray_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (Slot& S : c->slots) if (S.stream) (void)hipStreamSynchronize(S.stream);
+    for (Slot& S : c->slots) {
+        for (auto p : S.level_out) if (p) (void)hipFree(p);
+        for (auto p : S.queue) if (p) (void)hipFree(p);
+        if (S.d_qctl) (void)hipFree(S.d_qctl);
+        if (S.d_counters) (void)hipFree(S.d_counters);
+        if (S.own_out) (void)hipFree(S.own_out);
+        if (S.done) (void)hipEventDestroy(S.done);
+        if (S.stream) (void)hipStreamDestroy(S.stream);
+    }
     for (Level& L : c->levels) {
-        if (L.out) (void)hipFree(L.out);
         if (L.d_rows) (void)hipFree(L.d_rows);
         if (L.d_rowmap) (void)hipFree(L.d_rowmap);
-        if (L.queue) (void)hipFree(L.queue);
     }
-    if (c->own_out) (void)hipFree(c->own_out);
     for (auto& t : c->tex) if (t) (void)hipFree(t);
     for (auto& m : c->models) free_model(m);
-    if (c->d_qctl) (void)hipFree(c->d_qctl);
-    if (c->d_counters) (void)hipFree(c->d_counters);
     for (auto& e : c->events) if (e) (void)hipEventDestroy(e);
+    if (c->wait_ev) (void)hipEventDestroy(c->wait_ev);
     if (c->d_err) (void)hipFree(c->d_err);
-    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
 
@@ -254,6 +274,7 @@ int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
         return fail(nullptr, BHRAY_E_INVALID, "frame window outside the last level");
     if (cfg->row_world < 1 || cfg->row_rank >= cfg->row_world || cfg->stripe_rows < 1)
         return fail(nullptr, BHRAY_E_INVALID, "bad row partition");
+    if (cfg->frames_in_flight > BHRAY_MAX_FRAMES_IN_FLIGHT) return fail(nullptr, BHRAY_E_INVALID, "frames_in_flight > %d", BHRAY_MAX_FRAMES_IN_FLIGHT);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(nullptr, BHRAY_E_NO_DEVICE, "no HIP device visible (libbhray has no CPU path)");
@@ -276,8 +297,10 @@ int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
     hipDeviceProp_t prop;
     CHK(hipGetDeviceProperties(&prop, c->device));
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    CHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    c->stream = c->own_stream;
+    const uint32_t nslots = cfg->frames_in_flight ? cfg->frames_in_flight : 2;
+    c->cfg.frames_in_flight = nslots;
+    c->slots.resize(nslots);
+    CHK(hipEventCreateWithFlags(&c->wait_ev, hipEventDisableTiming));
 
     // rows of the frame owned by this partition
     for (uint32_t r = 0; r < cfg->frame_h; r++)
@@ -296,11 +319,6 @@ int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
     for (uint32_t l = 0; l < nl; l++) {
         Level& L = c->levels[l];
         const bool last = (l == nl - 1);
-        const size_t npix = (size_t)L.w * (size_t)L.h;
-        if (!last) {
-            CHK(hipMalloc(&L.out, npix * sizeof(float4)));
-            CHK(hipMemset(L.out, 0xFF, npix * sizeof(float4)));      // NaN: "never rendered"
-        }
         const size_t nrows = L.rows.size();
         if (nrows) {
             CHK(hipMalloc(&L.d_rows, nrows * sizeof(int32_t)));
@@ -308,7 +326,6 @@ int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
         }
         const size_t span = last ? cfg->frame_w : (size_t)L.w;
         L.queue_cap = nrows * span;
-        if (L.queue_cap) CHK(hipMalloc(&L.queue, L.queue_cap * sizeof(uint32_t)));
         if (last) {
             std::vector<int32_t> map((size_t)L.h, -1);
             for (size_t i = 0; i < c->local_rows.size(); i++) map[(size_t)(cfg->crop_y + c->local_rows[i])] = (int32_t)i;
@@ -317,15 +334,30 @@ int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
         }
     }
     c->out_bytes = c->local_rows.size() * (size_t)cfg->frame_w * sizeof(float4);
-    if (c->out_bytes) {
-        CHK(hipMalloc(&c->own_out, c->out_bytes));
-        CHK(hipMemset(c->own_out, 0xFF, c->out_bytes));
+    for (Slot& S : c->slots) {
+        CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+        CHK(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
+        S.level_out.assign(nl > 0 ? nl - 1 : 0, nullptr);
+        S.queue.assign(nl, nullptr);
+        for (uint32_t l = 0; l < nl; l++) {
+            const Level& L = c->levels[l];
+            if (l + 1 < nl) {
+                const size_t npix = (size_t)L.w * (size_t)L.h;
+                CHK(hipMalloc(&S.level_out[l], npix * sizeof(float4)));
+                CHK(hipMemset(S.level_out[l], 0xFF, npix * sizeof(float4)));      // NaN: "never rendered"
+            }
+            if (L.queue_cap) CHK(hipMalloc(&S.queue[l], L.queue_cap * sizeof(uint32_t)));
+        }
+        if (c->out_bytes) {
+            CHK(hipMalloc(&S.own_out, c->out_bytes));
+            CHK(hipMemset(S.own_out, 0xFF, c->out_bytes));
+        }
+        S.out = S.own_out;
+        CHK(hipMalloc(&S.d_qctl, 2 * BHRAY_MAX_LEVELS * sizeof(uint32_t)));
+        CHK(hipMemset(S.d_qctl, 0, 2 * BHRAY_MAX_LEVELS * sizeof(uint32_t)));
+        CHK(hipMalloc(&S.d_counters, BHRAY_MAX_LEVELS * sizeof(Counters64)));
+        CHK(hipMemset(S.d_counters, 0, BHRAY_MAX_LEVELS * sizeof(Counters64)));
     }
-    c->out = c->own_out;
-    CHK(hipMalloc(&c->d_qctl, 2 * BHRAY_MAX_LEVELS * sizeof(uint32_t)));
-    CHK(hipMemset(c->d_qctl, 0, 2 * BHRAY_MAX_LEVELS * sizeof(uint32_t)));
-    CHK(hipMalloc(&c->d_counters, BHRAY_MAX_LEVELS * sizeof(Counters64)));
-    CHK(hipMemset(c->d_counters, 0, BHRAY_MAX_LEVELS * sizeof(Counters64)));
     if (cfg->flags & BHRAY_F_TIMING) {
         c->events.assign((size_t)BHRAY_TIMING_RING * nl * 3, nullptr);
         for (auto& e : c->events) CHK(hipEventCreate(&e));
@@ -348,7 +380,7 @@ int bhray_set_texture(bhray_ctx* c, int slot, const uint8_t* rgba8, uint32_t w, 
     if (!c) return BHRAY_E_INVALID;
     if (slot < 0 || slot > 2 || !rgba8 || w < 1 || h < 1 || w > 32768 || h > 32768) return fail(c, BHRAY_E_INVALID, "bad texture arguments");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all(c));
     uint8_t* d = nullptr;
     const size_t bytes = (size_t)w * h * 4;
     HIPCHK(c, hipMalloc(&d, bytes));
@@ -387,7 +419,7 @@ int bhray_upload_model(bhray_ctx* c, uint32_t mi, const bhray_model_desc* d) {
         }
     }
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all(c));
     ModelStore& m = c->models[mi];
     free_model(m);
     memcpy(m.pos, d->position, 12);
@@ -473,8 +505,13 @@ int bhray_render(bhray_ctx* c) {
     derive_frame(c, P);
     const uint32_t nl = c->cfg.levels;
     const bool count = (c->cfg.flags & BHRAY_F_COUNTERS) != 0, timing = (c->cfg.flags & BHRAY_F_TIMING) != 0;
-    HIPCHK(c, hipMemsetAsync(c->d_qctl, 0, 2 * BHRAY_MAX_LEVELS * sizeof(uint32_t), c->stream));
-    if (count) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, BHRAY_MAX_LEVELS * sizeof(Counters64), c->stream));
+    const int si = (int)(c->frame_counter % c->slots.size());
+    Slot& S = c->slots[(size_t)si];
+    hipStream_t st = S.stream;
+    if (c->wait_pending) { HIPCHK(c, hipStreamWaitEvent(st, c->wait_ev, 0)); c->wait_pending = false; }
+    S.out = c->bound_out ? c->bound_out : S.own_out;
+    HIPCHK(c, hipMemsetAsync(S.d_qctl, 0, 2 * BHRAY_MAX_LEVELS * sizeof(uint32_t), st));
+    if (count) HIPCHK(c, hipMemsetAsync(S.d_counters, 0, BHRAY_MAX_LEVELS * sizeof(Counters64), st));
     hipEvent_t* fev = timing ? &c->events[(size_t)(c->frame_counter % BHRAY_TIMING_RING) * nl * 3] : nullptr;
     const int bpc = trace_blocks_per_cu(P.method, P.model_count > 0, count);
     const int grid = c->num_cus * bpc;
@@ -487,24 +524,26 @@ int bhray_render(bhray_ctx* c) {
         if (l == 0) { L.pw = 1; L.ph = 1; L.rx = 1.0f; L.ry = 1.0f; L.prev = nullptr; }
         else {
             const Level& Pv = c->levels[l - 1];
-            L.pw = Pv.w; L.ph = Pv.h; L.prev = Pv.out;
+            L.pw = Pv.w; L.ph = Pv.h; L.prev = S.level_out[l - 1];
             const int sfx = (L.w - 1) / (L.pw - 1), sfy = (L.h - 1) / (L.ph - 1);          // ray.wgsl:185
             L.rx = (float)L.pw / (float)(L.w + (sfx - 1)); L.ry = (float)L.ph / (float)(L.h + (sfy - 1));   // ray.wgsl:187
         }
         if (last) {
-            L.out = c->out; L.out_pitch = (int)c->cfg.frame_w; L.out_x0 = (int)c->cfg.crop_x; L.rowmap = Lv.d_rowmap;
+            L.out = S.out; L.out_pitch = (int)c->cfg.frame_w; L.out_x0 = (int)c->cfg.crop_x; L.rowmap = Lv.d_rowmap;
             L.x0 = (int)c->cfg.crop_x; L.x1 = (int)(c->cfg.crop_x + c->cfg.frame_w);
         } else {
-            L.out = Lv.out; L.out_pitch = Lv.w; L.out_x0 = 0; L.rowmap = nullptr; L.x0 = 0; L.x1 = Lv.w;
+            L.out = S.level_out[l]; L.out_pitch = Lv.w; L.out_x0 = 0; L.rowmap = nullptr; L.x0 = 0; L.x1 = Lv.w;
         }
         L.rows = Lv.d_rows; L.nrows = (int)Lv.rows.size();
-        uint32_t* qcount = c->d_qctl + 2 * l; uint32_t* qhead = qcount + 1;
-        if (timing) HIPCHK(c, hipEventRecord(fev[3 * l + 0], c->stream));
-        HIPCHK(c, launch_classify(P, L, Lv.queue, qcount, count ? c->d_counters + l : nullptr, c->stream));
-        if (timing) HIPCHK(c, hipEventRecord(fev[3 * l + 1], c->stream));
-        HIPCHK(c, launch_trace(P, L, Lv.queue, qcount, qhead, count ? c->d_counters + l : nullptr, c->d_err, grid, c->stream));
-        if (timing) HIPCHK(c, hipEventRecord(fev[3 * l + 2], c->stream));
+        uint32_t* qcount = S.d_qctl + 2 * l; uint32_t* qhead = qcount + 1;
+        if (timing) HIPCHK(c, hipEventRecord(fev[3 * l + 0], st));
+        HIPCHK(c, launch_classify(P, L, S.queue[l], qcount, count ? S.d_counters + l : nullptr, st));
+        if (timing) HIPCHK(c, hipEventRecord(fev[3 * l + 1], st));
+        HIPCHK(c, launch_trace(P, L, S.queue[l], qcount, qhead, count ? S.d_counters + l : nullptr, c->d_err, grid, st));
+        if (timing) HIPCHK(c, hipEventRecord(fev[3 * l + 2], st));
     }
+    HIPCHK(c, hipEventRecord(S.done, st));
+    c->last_slot = si;
     c->rendered = true;
     c->frame_counter++;
     return BHRAY_OK;
@@ -513,7 +552,7 @@ int bhray_render(bhray_ctx* c) {
 int bhray_sync(bhray_ctx* c) {
     if (!c) return BHRAY_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all(c));
     if (c->rendered) {
         int e = 0;
         HIPCHK(c, hipMemcpy(&e, c->d_err, sizeof e, hipMemcpyDeviceToHost));
@@ -540,7 +579,7 @@ int bhray_read_hdr(bhray_ctx* c, float* dst, size_t pitch) {
     int rc = bhray_sync(c);
     if (rc) return rc;
     if (c->local_rows.empty()) return BHRAY_OK;
-    HIPCHK(c, hipMemcpy2D(dst, pitch, c->out, rowb, rowb, c->local_rows.size(), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy2D(dst, pitch, c->slots[(size_t)c->last_slot].out, rowb, rowb, c->local_rows.size(), hipMemcpyDeviceToHost));
     return BHRAY_OK;
 }
 
@@ -553,14 +592,14 @@ int bhray_read_level(bhray_ctx* c, uint32_t level, float* dst, size_t pitch) {
     int rc = bhray_sync(c);
     if (rc) return rc;
     if (level + 1 < c->cfg.levels) {
-        HIPCHK(c, hipMemcpy2D(dst, pitch, L.out, rowb, rowb, (size_t)L.h, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy2D(dst, pitch, c->slots[(size_t)c->last_slot].level_out[level], rowb, rowb, (size_t)L.h, hipMemcpyDeviceToHost));
         return BHRAY_OK;
     }
     // last level: scatter the packed window back into a NaN canvas of the full level size
     for (int y = 0; y < L.h; y++) memset((uint8_t*)dst + (size_t)y * pitch, 0xFF, rowb);
     const size_t frb = (size_t)c->cfg.frame_w * sizeof(float4);
     std::vector<uint8_t> tmp(c->local_rows.size() * frb);
-    if (!tmp.empty()) HIPCHK(c, hipMemcpy(tmp.data(), c->out, tmp.size(), hipMemcpyDeviceToHost));
+    if (!tmp.empty()) HIPCHK(c, hipMemcpy(tmp.data(), c->slots[(size_t)c->last_slot].out, tmp.size(), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < c->local_rows.size(); i++) {
         uint8_t* row = (uint8_t*)dst + (size_t)(c->cfg.crop_y + c->local_rows[i]) * pitch + (size_t)c->cfg.crop_x * sizeof(float4);
         memcpy(row, tmp.data() + i * frb, frb);
@@ -570,30 +609,32 @@ int bhray_read_level(bhray_ctx* c, uint32_t level, float* dst, size_t pitch) {
 
 int bhray_hdr_device_ptr(bhray_ctx* c, void** p, size_t* bytes) {
     if (!c || !p) return BHRAY_E_INVALID;
-    *p = c->out; if (bytes) *bytes = c->out_bytes;
+    *p = c->slots[(size_t)c->last_slot].out; if (bytes) *bytes = c->out_bytes;
     return BHRAY_OK;
 }
 
 int bhray_bind_output(bhray_ctx* c, void* p, size_t bytes) {
     if (!c) return BHRAY_E_INVALID;
-    if (!p) { c->out = c->own_out; return BHRAY_OK; }
+    if (!p) { c->bound_out = nullptr; return BHRAY_OK; }
     if (bytes < c->out_bytes) return fail(c, BHRAY_E_INVALID, "output binding needs %zu bytes", c->out_bytes);
     if (((uintptr_t)p & 15u) != 0) return fail(c, BHRAY_E_INVALID, "output binding must be 16-byte aligned");
-    c->out = (float4*)p;
+    c->bound_out = (float4*)p;
     return BHRAY_OK;
 }
 
-int bhray_get_stream(bhray_ctx* c, void** s) {
-    if (!c || !s) return BHRAY_E_INVALID;
-    *s = (void*)c->stream;
-    return BHRAY_OK;
-}
-
-int bhray_set_stream(bhray_ctx* c, void* s) {
+int bhray_wait_stream(bhray_ctx* c, void* s) {
     if (!c) return BHRAY_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    HIPCHK(c, hipEventRecord(c->wait_ev, (hipStream_t)s));
+    c->wait_pending = true;
+    return BHRAY_OK;
+}
+
+int bhray_signal_stream(bhray_ctx* c, void* s) {
+    if (!c) return BHRAY_E_INVALID;
+    if (!c->rendered) return BHRAY_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamWaitEvent((hipStream_t)s, c->slots[(size_t)c->last_slot].done, 0));
     return BHRAY_OK;
 }
 
@@ -604,7 +645,7 @@ int bhray_get_level_counters(bhray_ctx* c, uint32_t level, bhray_counters* out) 
     int rc = bhray_sync(c);
     if (rc) return rc;
     static_assert(sizeof(bhray_counters) == sizeof(Counters64), "counter layout");
-    HIPCHK(c, hipMemcpy(out, c->d_counters + level, sizeof(Counters64), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out, c->slots[(size_t)c->last_slot].d_counters + level, sizeof(Counters64), hipMemcpyDeviceToHost));
     return BHRAY_OK;
 }
 

@@ -38,6 +38,7 @@ struct FrameParams {
     // black hole (ray.wgsl:112-123)
     float bh[3];
     float bn[3];
+    float bn_len;          // length(normal) (host), for the conservative disk cull
     float inner, outer, rot_speed, R;
     int show_tex, show_shift;
     float M[9];            // rotation matrix columns c0,c1,c2

@@ -100,7 +100,7 @@ __device__ __forceinline__ bool hit_torus2d(F3 pos, F3 dir, float inner, float o
 
 // Disk shading, ray.wgsl:612-663 (the part of hit_black_hole after the disk won).
 template <bool COUNT>
-__device__ __noinline__ void shade_disk(const FrameParams& P, F3 pos, F3 dir, float t, float total_distance, Hit& rs,
+__device__ __forceinline__ void shade_disk(const FrameParams& P, F3 pos, F3 dir, float t, float total_distance, Hit& rs,
                                         unsigned long long* cnt) {
     F3 bpos = ld3(P.bh);
     F3 ip = pos + dir * t;
@@ -143,13 +143,32 @@ __device__ __noinline__ void shade_disk(const FrameParams& P, F3 pos, F3 dir, fl
 }
 
 // hit_black_hole, ray.wgsl:598-666: horizon sphere (radius 1, colour 0) vs. disk.
+//
+// The shader evaluates both intersections on every integrator step.  Here a step first checks, from
+// quantities the literal tests compute anyway (oc.oc and the signed plane distance), whether the
+// segment (t_min, t_max = step] can reach the horizon or the disk at all; if it cannot, the quadratic
+// (sqrt + 2 divisions) and the plane division are skipped.  The culls are conservative by >= 1 %:
+//   horizon: a hit needs |oc| <= 1 + t|d| with t < step, |d| <= 1 + 2e-7   -> skip when |oc| > 1.05 + 1.05 step
+//   disk:    t = fl(numer/denom) < step with |denom| <= |n||d|(1 + 4e-7)  -> skip when |numer| > 1.01 |n| step,
+//            and the hit point must lie within `outer` of the centre       -> skip when |oc| > outer + 0.05 + 1.05 step
+// so a skipped test is one whose literal evaluation returns "no hit": results are unchanged bit for bit
+// (checked against the oracle, which always evaluates the literal tests).
 template <bool COUNT>
 __device__ __forceinline__ void hit_black_hole(const FrameParams& P, F3 pos, F3 dir, float t_min, float t_max,
                                                float total_distance, Hit& rs, unsigned long long* cnt) {
-    F3 bpos = ld3(P.bh);
+    const F3 bpos = ld3(P.bh);
+    const F3 oc = pos - bpos;
+    const float oc2 = dot(oc, oc);
+    const float reach = 1.05f * t_max + 0.05f;
+    const float hr = 1.0f + reach, dr = P.outer + reach;
     float ts = t_max, td = t_max;
-    bool hs = hit_sphere(pos, dir, 1.0f, bpos, t_min, t_max, ts);
-    bool hd = hit_torus2d(pos, dir, P.inner, P.outer, bpos, ld3(P.bn), t_min, t_max, td);
+    bool hs = false, hd = false;
+    if (oc2 <= hr * hr) hs = hit_sphere(pos, dir, 1.0f, bpos, t_min, t_max, ts);
+    if (oc2 <= dr * dr) {
+        const F3 bn = ld3(P.bn);
+        const float numer = dot(bpos - pos, bn);
+        if (fabsf(numer) <= (1.01f * t_max) * P.bn_len) hd = hit_torus2d(pos, dir, P.inner, P.outer, bpos, bn, t_min, t_max, td);
+    }
     rs.hit = hs; rs.t = hs ? ts : t_max; rs.color = f3(0.0f, 0.0f, 0.0f); rs.opacity = hs ? 1.0f : 0.0f;
     if (hd && td < rs.t) {
         rs.hit = true; rs.t = td;
@@ -277,9 +296,9 @@ __device__ constexpr float DB1 = KF(37.0 / 378.0 - 2825.0 / 27648.0), DB2 = KF(0
                            DB5 = KF(0.0 - 277.0 / 14336.0), DB6 = KF(512.0 / 1771.0 - 1.0 / 4.0);
 
 // next_ray_rk, ray.wgsl:405-465.  The retry loop (425-451) cannot change h and is run once.
-__device__ __forceinline__ void next_ray_rk(F3 bpos, F3& pos, F3& dir, float& h_io) {
+// `dist` = length(pos - bpos), carried from the previous step's exit test (same operands, same value).
+__device__ __forceinline__ void next_ray_rk(F3 bpos, F3& pos, F3& dir, float& h_io, float dist) {
     const F3 p0 = pos, d0 = dir;
-    const float dist = length(p0 - bpos);
     const float lc = length(cross(p0, d0));
     const float h2 = lc * lc;
     const float c = -1.5f * h2;
@@ -302,10 +321,9 @@ __device__ __forceinline__ void next_ray_rk(F3 bpos, F3& pos, F3& dir, float& h_
 }
 
 // next_ray_euler, ray.wgsl:467-480.
-__device__ __forceinline__ void next_ray_euler(F3 bpos, F3& pos, F3& dir, float step) {
+__device__ __forceinline__ void next_ray_euler(F3 bpos, F3& pos, F3& dir, float step, float dist) {
     const float lc = length(cross(pos, dir));
     const float h2 = lc * lc;
-    const float dist = length(pos - bpos);
     const float c = -1.5f * h2;
     const float r = 1.0f / pow5(dist);
     dir = normalize(dir + f_acc(pos, bpos, c, r) * step);
@@ -400,10 +418,15 @@ __global__ __launch_bounds__(256) void classify_kernel(const FrameParams P, cons
 // trace: ray.wgsl:269-285 + 482-596
 // ------------------------------------------------------------------------------------------
 enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3 };
-#define BHRAY_REL_BATCH 16
+#ifndef BHRAY_REL_BATCH
+#define BHRAY_REL_BATCH 16       // integrator steps between refill / flat / epilogue phases
+#endif
+#ifndef BHRAY_TRACE_WAVES
+#define BHRAY_TRACE_WAVES 4      // waves per SIMD the trace kernel is register-budgeted for (<=128 VGPRs)
+#endif
 
 template <int METHOD, bool MODELS, bool COUNT>
-__global__ __launch_bounds__(256) void trace_kernel(const FrameParams P, const LevelParams L, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(256, BHRAY_TRACE_WAVES) void trace_kernel(const FrameParams P, const LevelParams L, const uint32_t* __restrict__ queue,
                                                     const uint32_t* __restrict__ qcount_p, uint32_t* __restrict__ qhead,
                                                     Counters64* __restrict__ counters, int* __restrict__ err_flag) {
     const int lane = threadIdx.x & 63;
@@ -420,6 +443,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const FrameParams P, const L
     float rkh = 0.0f;
     F3 color = f3(0, 0, 0);
     float amount = 1.0f, step = P.step_size, closest = P.ray_distance;
+    float dist_c = P.ray_distance;        // length(integrator position - bpos), carried between steps
     int it = 0;
     bool hit = false;
     bool exhausted = false;
@@ -450,6 +474,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const FrameParams P, const L
                     cpos = cam; cdir = rdir; ppos = cam; pdir = rdir;
                     rkpos = cam; rkdir = rdir; rkh = P.step_size;
                     color = f3(0, 0, 0); amount = 1.0f; step = P.step_size; closest = P.ray_distance;
+                    dist_c = P.ray_distance;
                     it = 0; hit = false;
                     mode = P.relativity0 ? M_REL : M_FLAT;
                     if (COUNT) cnt[3]++;
@@ -485,10 +510,11 @@ __global__ __launch_bounds__(256) void trace_kernel(const FrameParams P, const L
                         mode = M_FINISH;                                   // break (no increment)
                     } else {
                         bool chit = false; Hit crs = rs;
-                        if (hs && ths < rs.t) { cpos = cpos + cdir * ths; mode = M_REL; }
+                        if (hs && ths < rs.t) { cpos = cpos + cdir * ths; mode = M_REL; if (METHOD == 0) dist_c = distance(cpos, bpos); }
                         else { chit = rs.hit; }
                         if (chit) {
                             cpos = cpos + pdir * crs.t;
+                            if (METHOD == 0) dist_c = distance(cpos, bpos);
                             const F3 cc = f3(clamp_(crs.color.x, 0.0f, 1.0f), clamp_(crs.color.y, 0.0f, 1.0f), clamp_(crs.color.z, 0.0f, 1.0f));
                             color = color + cc * (amount * crs.opacity);
                             amount *= 1.0f - crs.opacity;
@@ -537,12 +563,13 @@ __global__ __launch_bounds__(256) void trace_kernel(const FrameParams P, const L
                     if (COUNT) cnt[4]++;
                     ppos = cpos; pdir = cdir;
                     if (METHOD == 0) {
-                        next_ray_euler(bpos, cpos, cdir, step);
+                        next_ray_euler(bpos, cpos, cdir, step, dist_c);
                     } else {
-                        next_ray_rk(bpos, rkpos, rkdir, rkh);
+                        next_ray_rk(bpos, rkpos, rkdir, rkh, dist_c);
                         cpos = rkpos; cdir = rkdir; step = rkh;
                     }
                     const float cd = distance(cpos, bpos);
+                    dist_c = cd;                       // Euler: cpos is the integrator position; RK: cpos == rkpos here
                     if (cd < closest) closest = cd;
                     pdir = cdir;
                     Hit crs;
@@ -557,6 +584,7 @@ __global__ __launch_bounds__(256) void trace_kernel(const FrameParams P, const L
                     }
                     if (crs.hit) {
                         cpos = cpos + pdir * crs.t;
+                        if (METHOD == 0) dist_c = distance(cpos, bpos);
                         const F3 cc = f3(clamp_(crs.color.x, 0.0f, 1.0f), clamp_(crs.color.y, 0.0f, 1.0f), clamp_(crs.color.z, 0.0f, 1.0f));
                         color = color + cc * (amount * crs.opacity);
                         amount *= 1.0f - crs.opacity;

@@ -61,7 +61,8 @@ class BhrayConfig(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("levels", C.c_uint32),
                 ("level_w", C.c_uint32 * MAX_LEVELS), ("level_h", C.c_uint32 * MAX_LEVELS),
                 ("crop_x", C.c_uint32), ("crop_y", C.c_uint32), ("frame_w", C.c_uint32), ("frame_h", C.c_uint32),
-                ("row_rank", C.c_uint32), ("row_world", C.c_uint32), ("stripe_rows", C.c_uint32), ("flags", C.c_uint32)]
+                ("row_rank", C.c_uint32), ("row_world", C.c_uint32), ("stripe_rows", C.c_uint32), ("flags", C.c_uint32),
+                ("frames_in_flight", C.c_uint32)]
 
     def sizes(self):
         return [(int(self.level_w[i]), int(self.level_h[i])) for i in range(self.levels)]
@@ -109,8 +110,8 @@ SYMBOLS = {
     "bhray_local_row_index": (C.c_int, [vp, u32, P(u32)]),
     "bhray_hdr_device_ptr": (C.c_int, [vp, P(vp), P(sz)]),
     "bhray_bind_output": (C.c_int, [vp, vp, sz]),
-    "bhray_get_stream": (C.c_int, [vp, P(vp)]),
-    "bhray_set_stream": (C.c_int, [vp, vp]),
+    "bhray_wait_stream": (C.c_int, [vp, vp]),
+    "bhray_signal_stream": (C.c_int, [vp, vp]),
     "bhray_get_counters": (C.c_int, [vp, P(BhrayCounters)]),
     "bhray_get_level_counters": (C.c_int, [vp, u32, P(BhrayCounters)]),
     "bhray_get_timing": (C.c_int, [vp, P(BhrayTiming)]),

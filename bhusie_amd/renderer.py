@@ -32,12 +32,14 @@ def ladder_for_frame(frame=(1920, 1080), multiplier=3, levels=4) -> BhrayConfig:
 
 
 class RayPass:
-    def __init__(self, cfg: BhrayConfig, device=0, counters=False, timing=False, row_rank=0, row_world=1, stripe_rows=27):
+    def __init__(self, cfg: BhrayConfig, device=0, counters=False, timing=False, row_rank=0, row_world=1, stripe_rows=27,
+                 frames_in_flight=0):
         cfg = BhrayConfig.from_buffer_copy(bytes(cfg))
         cfg.struct_size = C.sizeof(BhrayConfig)
         cfg.device = device
         cfg.flags = (F_COUNTERS if counters else 0) | (F_TIMING if timing else 0)
         cfg.row_rank, cfg.row_world, cfg.stripe_rows = row_rank, row_world, stripe_rows
+        cfg.frames_in_flight = frames_in_flight
         self.cfg = cfg
         h = C.c_void_p()
         check(lib().bhray_create(C.byref(cfg), C.byref(h)))
@@ -118,13 +120,13 @@ class RayPass:
     def bind_output(self, ptr, nbytes):
         check(lib().bhray_bind_output(self._h, C.c_void_p(ptr), nbytes), self._h)
 
-    def stream(self):
-        s = C.c_void_p()
-        check(lib().bhray_get_stream(self._h, C.byref(s)), self._h)
-        return s.value
+    def wait_stream(self, s):
+        """The next render starts after everything enqueued so far on hipStream_t `s`."""
+        check(lib().bhray_wait_stream(self._h, C.c_void_p(s)), self._h)
 
-    def set_stream(self, s):
-        check(lib().bhray_set_stream(self._h, C.c_void_p(s)), self._h)
+    def signal_stream(self, s):
+        """Work enqueued on hipStream_t `s` from now on starts after the last render."""
+        check(lib().bhray_signal_stream(self._h, C.c_void_p(s)), self._h)
 
     def counters(self) -> dict:
         c = BhrayCounters()

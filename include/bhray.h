@@ -137,6 +137,7 @@ typedef struct bhray_model_desc {
  * Context configuration
  * ---------------------------------------------------------------------------------------- */
 #define BHRAY_MAX_LEVELS 8
+#define BHRAY_MAX_FRAMES_IN_FLIGHT 8
 #define BHRAY_BVH_STACK  64            /* reference: 19 whole nodes, no overflow check (ray.wgsl:292) */
 
 enum {                                  /* bhray_config.flags */
@@ -163,6 +164,7 @@ typedef struct bhray_config {
     uint32_t frame_w, frame_h;
     uint32_t row_rank, row_world, stripe_rows;
     uint32_t flags;
+    uint32_t frames_in_flight;          /* 0 = default (2); 1 = strictly one frame at a time  */
 } bhray_config;
 
 /* Reference ladder rule `r ← r·m − (m−1)` (mod.rs:177-205): fills level_w/h[0..levels).    */
@@ -218,15 +220,24 @@ uint32_t bhray_local_rows(const bhray_ctx* ctx);
 /* frame row index of packed row i (0 ≤ i < local_rows).                                      */
 int bhray_local_row_index(const bhray_ctx* ctx, uint32_t i, uint32_t* frame_row);
 
-/* Zero-copy consumers (sky pass, RCCL gather).  The output buffer holds
- * local_rows × frame_w × 4 f32.  bhray_bind_output lets the caller supply device memory
- * (e.g. a slice of the gather buffer) that subsequent renders write into; NULL restores the
- * ctx-owned buffer.                                                                          */
+/* Zero-copy consumers (sky pass, RCCL gather).  An output buffer holds local_rows × frame_w × 4
+ * f32.  bhray_hdr_device_ptr returns the buffer of the most recently enqueued frame.
+ * bhray_bind_output makes the NEXT bhray_render write into caller-supplied device memory (e.g. a
+ * slice of a gather buffer); it applies to that one frame's slot until re-bound, NULL restores the
+ * ctx-owned buffer.                                                                           */
 int bhray_hdr_device_ptr(bhray_ctx* ctx, void** dev_ptr, size_t* bytes);
 int bhray_bind_output(bhray_ctx* ctx, void* dev_ptr, size_t bytes);
-/* The hipStream_t all work is enqueued on; bhray_set_stream(NULL) restores the ctx's own.   */
-int bhray_get_stream(bhray_ctx* ctx, void** hip_stream);
-int bhray_set_stream(bhray_ctx* ctx, void* hip_stream);
+
+/* Frames in flight.  The ladder levels of ONE frame are dependent launches, and the coarse levels
+ * are far too small to fill 256 CUs (level 0 is ~3 k rays), so a ctx keeps `frames_in_flight`
+ * frame slots, each with its own HIP stream and level/queue buffers; consecutive bhray_render
+ * calls go to consecutive slots and overlap on the device (the reference's swap chain runs with
+ * desired_maximum_frame_latency = 2, mod.rs:101).  Ordering against the caller's own streams:
+ *   bhray_wait_stream(ctx, s)    the NEXT bhray_render starts after everything enqueued on s so far
+ *   bhray_signal_stream(ctx, s)  work enqueued on s from now on starts after the LAST bhray_render
+ * `s` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the legacy stream.  */
+int bhray_wait_stream(bhray_ctx* ctx, void* hip_stream);
+int bhray_signal_stream(bhray_ctx* ctx, void* hip_stream);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement

@@ -196,7 +196,7 @@ def test_gpu_against_committed_golden_mesh(tmp_path):
         T.assert_parity(rp.read_hdr(), g[f"frame{method}"], f"golden mesh frame {method}")
 
 
-def test_1920x1080_bench_config_matches_oracle_on_sampled_rows():
+def test_1920x1080_bench_config_matches_oracle():
     """configs[1] at full size: the 1920x1080 window of the 73x41 x3 x4 ladder; the oracle renders the whole
     ladder once (a few seconds on 8 cores) and every pixel is compared."""
     tex = T.textures()
@@ -205,7 +205,8 @@ def test_1920x1080_bench_config_matches_oracle_on_sampled_rows():
     rp = run_gpu(cfg, *u, tex)
     got = rp.read_hdr()
     assert got.shape == (1080, 1920, 4)
-    want = O.render_ladder(T.oracle_scene(*u, tex), cfg.sizes())[-1][:, 12:12 + 1920]
+    cx, cy = int(cfg.crop_x), int(cfg.crop_y)
+    want = O.render_ladder(T.oracle_scene(*u, tex), cfg.sizes())[-1][cy:cy + 1080, cx:cx + 1920]
     T.assert_parity(got, want, "1920x1080 window")
     # idempotence: rendering again gives the same bytes
     rp.render()
