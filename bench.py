@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--max-iterations", type=int, default=2000)
     ap.add_argument("--stripe-rows", type=int, default=27)
-    ap.add_argument("--frames-in-flight", type=int, default=2)
+    ap.add_argument("--frames-in-flight", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -217,6 +217,15 @@ def main():
         bytes_per_launch = algorithmic_bytes_trace(counters) * frames / launches
         achieved_gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         flops_per_frame = algorithmic_flops(counters, 1)
+        # HBM traffic of the same kernel from the committed PMC passes (profiles/collect.sh: rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE, separate passes of this command); null when no summary is present
+        traffic, traffic_note = None, None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath) and args.workload == "disk" and world == 1:
+            tj = json.load(open(tpath))
+            traffic = round(tj["bytes_per_launch_corrected"], 1)
+            traffic_note = (f"PMC (profiles/{tj['tag']}_pmc.json): FETCH_SIZE {tj['FETCH_SIZE_KB_per_launch']:.0f} KB x2 (gfx950 correction) + "
+                            f"WRITE_SIZE {tj['WRITE_SIZE_KB_per_launch']:.0f} KB per launch; raw sum {tj['bytes_per_launch_raw']:.0f} B")
         valu_tflops = flops_per_frame * frames / (tm.trace_ms * 1e-3) / 1e12 if tm.trace_ms > 0 else 0.0
         out = {
             "metric": "Mrays/sec at 1920x1080 adaptive-RK4; 1/2/4/8 MI355X + % HBM roofline",
@@ -234,7 +243,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": "trace_kernel", "achieved": round(achieved_gbs, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": None,
+                "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_note": traffic_note,
                 "avg_launch_ms": round(avg_ms, 5), "launches": int(tm.trace_launches),
                 "algorithmic_bytes_per_launch": round(bytes_per_launch, 1),
                 "note": "VALU-bound f32 ODE march (SURVEY.md F8): algorithmic HBM traffic is tiny; see `valu` for the binding roofline",

@@ -7,6 +7,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -76,6 +77,7 @@ struct bhray_ctx {
     uint64_t frame_counter = 0, timing_begin = 0;
     int* d_err = nullptr;
     int num_cus = 256;
+    int bpc_override = 0;                  // BHRAY_TRACE_BLOCKS_PER_CU (tuning experiments only)
     bool rendered = false;
     std::string err;
 };
@@ -297,7 +299,8 @@ int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
     hipDeviceProp_t prop;
     CHK(hipGetDeviceProperties(&prop, c->device));
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    const uint32_t nslots = cfg->frames_in_flight ? cfg->frames_in_flight : 2;
+    if (const char* e = getenv("BHRAY_TRACE_BLOCKS_PER_CU")) c->bpc_override = atoi(e);
+    const uint32_t nslots = cfg->frames_in_flight ? cfg->frames_in_flight : 3;
     c->cfg.frames_in_flight = nslots;
     c->slots.resize(nslots);
     CHK(hipEventCreateWithFlags(&c->wait_ev, hipEventDisableTiming));
@@ -513,7 +516,12 @@ int bhray_render(bhray_ctx* c) {
     HIPCHK(c, hipMemsetAsync(S.d_qctl, 0, 2 * BHRAY_MAX_LEVELS * sizeof(uint32_t), st));
     if (count) HIPCHK(c, hipMemsetAsync(S.d_counters, 0, BHRAY_MAX_LEVELS * sizeof(Counters64), st));
     hipEvent_t* fev = timing ? &c->events[(size_t)(c->frame_counter % BHRAY_TIMING_RING) * nl * 3] : nullptr;
-    const int bpc = trace_blocks_per_cu(P.method, P.model_count > 0, count);
+    // Persistent trace grid: (resident blocks per CU) x CUs.  With several frames in flight one block
+    // slot per CU is left free, so that the small (latency-bound) levels of the next frame can run
+    // beside the large last level of this one instead of queueing behind it.
+    int bpc = trace_blocks_per_cu(P.method, P.model_count > 0, count);
+    if (c->slots.size() > 1 && bpc > 1) bpc -= 1;
+    if (c->bpc_override > 0) bpc = c->bpc_override;
     const int grid = c->num_cus * bpc;
     for (uint32_t l = 0; l < nl; l++) {
         Level& Lv = c->levels[l];

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/prof_<tag>/ (written by profiles/collect.sh on the GPU box) into the committed
+summaries: profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.json and profiles/pmc_traffic.json
+(read by bench.py for roofline.traffic)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(root, "profiles")
+
+
+def find(sub, suffix):
+    g = glob.glob(os.path.join(src, sub, "**", f"*{suffix}"), recursive=True)
+    return g[0] if g else None
+
+
+stats = find("stats", "kernel_stats.csv")
+if stats:
+    shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+
+
+def per_kernel(sub):
+    f = find(sub, "counter_collection.csv")
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    if not f:
+        return out
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0]
+        out[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        out[name]["_dur_ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    return out
+
+
+summary = {}
+for sub in ("fetch", "write", "sq", "sq2"):
+    for k, cs in per_kernel(sub).items():
+        if "bhray" not in k:
+            continue
+        d = summary.setdefault(k, {})
+        for c, v in cs.items():
+            if c == "_dur_ns":
+                d.setdefault("launches_" + sub, len(v))
+                d.setdefault("avg_dur_us_" + sub, sum(v) / len(v) / 1e3)
+            else:
+                d[c + "_avg_per_launch"] = sum(v) / len(v)
+json.dump(summary, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
+
+# roofline.traffic for the dominant kernel (non-counter trace kernel, RK, no mesh unless only mesh ran)
+cands = [k for k in summary if "trace_kernel" in k and "FETCH_SIZE_avg_per_launch" in summary[k] and "WRITE_SIZE_avg_per_launch" in summary[k]]
+cands.sort(key=lambda k: -summary[k].get("launches_fetch", 0))
+if cands:
+    k = cands[0]
+    fetch_kb, write_kb = summary[k]["FETCH_SIZE_avg_per_launch"], summary[k]["WRITE_SIZE_avg_per_launch"]
+    traffic = {
+        "kernel": k, "tag": tag,
+        "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
+        # MI355X_MICROARCH.md §HBM: FETCH_SIZE = TCC_EA0_RDREQ x 64 B under-counts 128 B requests by 2x on gfx950
+        # (calibrated there for wide coalesced streams); WRITE_SIZE is uncalibrated.  Both forms are kept.
+        "bytes_per_launch_raw": (fetch_kb + write_kb) * 1024.0,
+        "bytes_per_launch_corrected": (2.0 * fetch_kb + write_kb) * 1024.0,
+        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of the same bench command, averaged over all launches of the kernel",
+    }
+    json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+    print(json.dumps(traffic, indent=1))
+bl = os.path.join(src, "bench_lines.jsonl")
+if os.path.exists(bl):
+    shutil.copy(bl, os.path.join(dst, f"{tag}_bench_lines.jsonl"))
+print(open(os.path.join(dst, f"{tag}_kernel_stats.csv")).read()[:1500] if stats else "no stats")
