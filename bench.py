@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--stripe-rows", type=int, default=27)
     ap.add_argument("--frames-in-flight", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--readback", action="store_true", help="also copy every frame to host memory (PCIe-inclusive; never the headline)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -157,6 +158,8 @@ def main():
     def step(k):
         if not distributed:
             rp.render()
+            if args.readback:
+                rp.read_hdr()
             return
         b = k % nbuf
         g = gathers[b]
@@ -239,7 +242,7 @@ def main():
                 "ladder": [list(s) for s in cfg.sizes()], "crop": [int(cfg.crop_x), int(cfg.crop_y)],
                 "step_size": 0.15, "max_iterations": args.max_iterations, "angle_division_threshold": 0.02,
                 "parallelism": f"row-tiled x{world}, stripes of {args.stripe_rows} rows, gather to rank 0" if world > 1 else "single GPU",
-                "frames_in_flight": args.frames_in_flight,
+                "frames_in_flight": args.frames_in_flight, "readback_to_host": bool(args.readback),
             },
             "roofline": {
                 "bound": "hbm", "kernel": "trace_kernel", "achieved": round(achieved_gbs, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
