@@ -23,6 +23,10 @@ import os
 import sys
 import time
 
+# Frames in flight run on separate HIP streams; ROCm maps streams onto 4 hardware queues by default, so 4+ streams
+# would serialise pairwise.  Must be set before the HIP runtime initialises (libbhray also sets it when it is loaded).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -103,8 +107,9 @@ def main():
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--max-iterations", type=int, default=2000)
     ap.add_argument("--stripe-rows", type=int, default=27)
-    ap.add_argument("--frames-in-flight", type=int, default=3)
+    ap.add_argument("--frames-in-flight", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-distributed", action="store_true", help="run the N>1 code path (process group, gather) even at world size 1")
     ap.add_argument("--readback", action="store_true", help="also copy every frame to host memory (PCIe-inclusive; never the headline)")
     args = ap.parse_args()
 
@@ -113,13 +118,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    distributed = world > 1
+    distributed = world > 1 or args.force_distributed
 
     torch = dist = None
     if distributed:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        if "RANK" not in os.environ:             # --force-distributed without a launcher
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"))
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import bhusie_amd as B

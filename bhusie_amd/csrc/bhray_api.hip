@@ -21,6 +21,11 @@ using namespace bhray;
 
 namespace {
 
+// Frame slots run on separate HIP streams; ROCm maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues, so
+// 4+ slots would serialise pairwise.  Raise the default when the library is loaded (no effect if the caller set it or
+// the HIP runtime is already initialised).
+__attribute__((constructor)) void bhray_env_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 thread_local std::string g_create_error;
 
 struct Level {                      // geometry of one ladder level (shared by all frame slots)
@@ -300,7 +305,7 @@ int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
     CHK(hipGetDeviceProperties(&prop, c->device));
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = getenv("BHRAY_TRACE_BLOCKS_PER_CU")) c->bpc_override = atoi(e);
-    const uint32_t nslots = cfg->frames_in_flight ? cfg->frames_in_flight : 3;
+    const uint32_t nslots = cfg->frames_in_flight ? cfg->frames_in_flight : 4;
     c->cfg.frames_in_flight = nslots;
     c->slots.resize(nslots);
     CHK(hipEventCreateWithFlags(&c->wait_ev, hipEventDisableTiming));

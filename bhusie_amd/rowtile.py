@@ -56,9 +56,8 @@ class FrameGather:
     def gather(self, async_op: bool = False):
         """Collective over all ranks.  Returns the work handle (or None)."""
         import torch.distributed as dist
-        if self.world == 1:
-            if self.rank == self.dst:
-                self.blocks[0] = self.local
+        if self.world == 1 and not dist.is_initialized():
+            self.blocks[0] = self.local
             return None
         return dist.gather(self.local, self.blocks if self.rank == self.dst else None, dst=self.dst,
                            group=self.group, async_op=async_op)

@@ -164,7 +164,7 @@ typedef struct bhray_config {
     uint32_t frame_w, frame_h;
     uint32_t row_rank, row_world, stripe_rows;
     uint32_t flags;
-    uint32_t frames_in_flight;          /* 0 = default (3); 1 = strictly one frame at a time  */
+    uint32_t frames_in_flight;          /* 0 = default (4); 1 = strictly one frame at a time  */
 } bhray_config;
 
 /* Reference ladder rule `r ← r·m − (m−1)` (mod.rs:177-205): fills level_w/h[0..levels).    */
