@@ -66,7 +66,7 @@ def build_scene(args):
     model = None
     if args.workload == "mesh":
         import tempfile
-        obj = assets.sphere_mesh_obj(320, 320, radius=8.0, bump=0.15, seed=3)      # 204 160 triangles
+        obj = assets.icosphere_mesh_obj(7, radius=8.0, bump=0.15, seed=3)          # 327 680 triangles, leaves <= 2
         with tempfile.NamedTemporaryFile("w", suffix=".obj", delete=False) as f:
             f.write(obj)
             path = f.name
@@ -245,7 +245,7 @@ def main():
             "config": {
                 "workload": ("configs[2]: " if args.workload == "mesh" else "configs[1]: ")
                 + f"{args.width}x{args.height} adaptive RK (Cash-Karp), accretion disk + adaptive background grid"
-                + (" + BVH mesh (204160-triangle OBJ) at (-10,0,30)" if args.workload == "mesh" else ""),
+                + (" + BVH mesh (327680-triangle icosphere OBJ) at (-10,0,30)" if args.workload == "mesh" else ""),
                 "ladder": [list(s) for s in cfg.sizes()], "crop": [int(cfg.crop_x), int(cfg.crop_y)],
                 "step_size": 0.15, "max_iterations": args.max_iterations, "angle_division_threshold": 0.02,
                 "parallelism": f"row-tiled x{world}, stripes of {args.stripe_rows} rows, gather to rank 0" if world > 1 else "single GPU",

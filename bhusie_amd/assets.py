@@ -120,3 +120,43 @@ def sphere_mesh_obj(n_lat: int = 24, n_lon: int = 32, radius: float = 8.0, bump:
     else:
         lines += ["f %d %d %d" % f for f in faces]
     return "\n".join(lines) + "\n"
+
+
+def icosphere_mesh_obj(level: int = 6, radius: float = 8.0, bump: float = 0.15, seed: int = 3, with_normals: bool = True) -> str:
+    """OBJ text of a subdivided icosahedron (20 * 4**level triangles, near-uniform like a scanned mesh) with seeded
+    radial noise.  level 6 = 81 920 triangles, level 7 = 327 680 (within the reference's 524 288-entry capacities)."""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    V = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                  [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], dtype=np.float64)
+    V /= np.linalg.norm(V, axis=1, keepdims=True)
+    F = np.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2], [10, 7, 6], [7, 1, 8],
+                  [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11], [6, 2, 10], [8, 6, 7], [9, 8, 1]], dtype=np.int64)
+    for _ in range(level):
+        e = np.concatenate([F[:, [0, 1]], F[:, [1, 2]], F[:, [2, 0]]])
+        es = np.sort(e, axis=1)
+        key = es[:, 0] * (len(V) + 1) + es[:, 1]
+        uniq, inv = np.unique(key, return_inverse=True)
+        a, b = uniq // (len(V) + 1), uniq % (len(V) + 1)
+        mid = V[a] + V[b]
+        mid /= np.linalg.norm(mid, axis=1, keepdims=True)
+        base = len(V)
+        V = np.concatenate([V, mid])
+        n = len(F)
+        m01, m12, m20 = base + inv[:n], base + inv[n:2 * n], base + inv[2 * n:]
+        F = np.concatenate([np.stack([F[:, 0], m01, m20], 1), np.stack([F[:, 1], m12, m01], 1),
+                            np.stack([F[:, 2], m20, m12], 1), np.stack([m01, m12, m20], 1)])
+    # smooth seeded relief (a scanned statue is smooth at the triangle scale; per-vertex white noise makes spikes
+    # that defeat the reference's midpoint-of-bounds BVH split and leaves hundreds of triangles per leaf)
+    ph = [((_hash_u32(np.array([seed * 131 + k], dtype=np.uint32))[0] & 0xFFFF) / 65535.0) * 6.283185307 for k in range(6)]
+    disp = (np.sin(3.0 * V[:, 0] + ph[0]) * np.sin(4.0 * V[:, 1] + ph[1]) + 0.5 * np.sin(7.0 * V[:, 2] + ph[2]) * np.sin(5.0 * V[:, 0] + ph[3])
+            + 0.25 * np.sin(13.0 * V[:, 1] + ph[4]) * np.sin(11.0 * V[:, 2] + ph[5])) / 1.75
+    rr = radius * (1.0 + bump * disp)
+    P = V * rr[:, None]
+    lines = ["# synthetic seeded icosphere", "o icosphere"]
+    lines += ["v %.6f %.6f %.6f" % tuple(v) for v in P]
+    if with_normals:
+        lines += ["vn %.6f %.6f %.6f" % tuple(n) for n in V]
+        lines += ["f %d//%d %d//%d %d//%d" % (a, a, b, b, c, c) for a, b, c in (F + 1)]
+    else:
+        lines += ["f %d %d %d" % tuple(f) for f in (F + 1)]
+    return "\n".join(lines) + "\n"
