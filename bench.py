@@ -24,8 +24,8 @@ import sys
 import time
 
 # Frames in flight run on separate HIP streams; ROCm maps streams onto 4 hardware queues by default, so 4+ streams
-# would serialise pairwise.  Must be set before the HIP runtime initialises (libbhray also sets it when it is loaded).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# would serialise pairwise (measured: 8 queues are not enough once the N>1 path adds its side streams and RCCL's).  Must be set before the HIP runtime initialises (libbhray also sets it when it is loaded).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "64")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -107,9 +107,10 @@ def main():
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--max-iterations", type=int, default=2000)
     ap.add_argument("--stripe-rows", type=int, default=27)
-    ap.add_argument("--frames-in-flight", type=int, default=6)
+    ap.add_argument("--frames-in-flight", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-distributed", action="store_true", help="run the N>1 code path (process group, gather) even at world size 1")
+    ap.add_argument("--emulate-world", type=int, default=0, help="single process renders only rank 0's row tiles of an N-way partition (sizing experiments)")
     ap.add_argument("--readback", action="store_true", help="also copy every frame to host memory (PCIe-inclusive; never the headline)")
     args = ap.parse_args()
 
@@ -137,7 +138,7 @@ def main():
     dev = local_rank if distributed else 0
 
     def make_pass(**kw):
-        rp = B.RayPass(cfg, device=dev, row_rank=rank, row_world=world, stripe_rows=args.stripe_rows, **kw)
+        rp = B.RayPass(cfg, device=dev, row_rank=rank, row_world=(args.emulate_world or world), stripe_rows=args.stripe_rows, **kw)
         rp.set_textures(*tex)
         if model is not None:
             rp.upload_model(model)

@@ -24,7 +24,7 @@ namespace {
 // Frame slots run on separate HIP streams; ROCm maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues, so
 // 4+ slots would serialise pairwise.  Raise the default when the library is loaded (no effect if the caller set it or
 // the HIP runtime is already initialised).
-__attribute__((constructor)) void bhray_env_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+__attribute__((constructor)) void bhray_env_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 thread_local std::string g_create_error;
 

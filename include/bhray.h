@@ -137,7 +137,7 @@ typedef struct bhray_model_desc {
  * Context configuration
  * ---------------------------------------------------------------------------------------- */
 #define BHRAY_MAX_LEVELS 8
-#define BHRAY_MAX_FRAMES_IN_FLIGHT 8
+#define BHRAY_MAX_FRAMES_IN_FLIGHT 32
 #define BHRAY_BVH_STACK  64            /* reference: 19 whole nodes, no overflow check (ray.wgsl:292) */
 
 enum {                                  /* bhray_config.flags */
