@@ -216,6 +216,17 @@ def main():
         elapsed = float(t.item())
 
     tm = rp.timing()
+    # the same kernels with nothing else on the device (one frame at a time): clean per-launch durations
+    iso = None
+    if not distributed:
+        rp1 = make_pass(timing=True, frames_in_flight=1)
+        for _ in range(3):
+            rp1.render()
+        rp1.sync(); rp1.timing()
+        for _ in range(10):
+            rp1.render(); rp1.sync()
+        iso = rp1.timing()
+        rp1.close()
     if rank == 0:
         pixels = args.width * args.height
         ms_per_step = elapsed / args.steps * 1e3
@@ -237,7 +248,16 @@ def main():
             traffic = round(tj["bytes_per_launch_corrected"], 1)
             traffic_note = (f"PMC (profiles/{tj['tag']}_pmc.json): FETCH_SIZE {tj['FETCH_SIZE_KB_per_launch']:.0f} KB x2 (gfx950 correction) + "
                             f"WRITE_SIZE {tj['WRITE_SIZE_KB_per_launch']:.0f} KB per launch; raw sum {tj['bytes_per_launch_raw']:.0f} B")
-        valu_tflops = flops_per_frame * frames / (tm.trace_ms * 1e-3) / 1e12 if tm.trace_ms > 0 else 0.0
+        valu_tflops = flops_per_frame / (ms_per_step * 1e-3) / 1e12 * (world if world > 1 else 1) / max(1, world)   # device-level: flops per frame / wall per frame
+        iso_d = None
+        if iso is not None and iso.trace_launches:
+            iso_ms = iso.trace_ms / iso.trace_launches
+            iso_gbs = bytes_per_launch / (iso_ms * 1e-3) / 1e9
+            iso_d = {"avg_launch_ms": round(iso_ms, 5), "launches": int(iso.trace_launches), "achieved": round(iso_gbs, 4),
+                     "frac": round(iso_gbs / HBM_PEAK_GBS, 6),
+                     "level_trace_ms": [round(iso.level_trace_ms[i] / max(1, iso.frames), 5) for i in range(args.levels)],
+                     "valu_tflops": round(flops_per_frame * iso.frames / (iso.trace_ms * 1e-3) / 1e12, 4),
+                     "note": "same kernels, one frame in flight, nothing else on the device (matches rocprofv3 --stats of `bench.py --frames-in-flight 1`)"}
         out = {
             "metric": "Mrays/sec at 1920x1080 adaptive-RK4; 1/2/4/8 MI355X + % HBM roofline",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -257,11 +277,15 @@ def main():
                 "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_note": traffic_note,
                 "avg_launch_ms": round(avg_ms, 5), "launches": int(tm.trace_launches),
                 "algorithmic_bytes_per_launch": round(bytes_per_launch, 1),
+                "concurrency": f"{args.frames_in_flight} frames in flight: launch durations in the timed region include the kernels they overlap with",
+                "isolated": iso_d,
                 "note": "VALU-bound f32 ODE march (SURVEY.md F8): algorithmic HBM traffic is tiny; see `valu` for the binding roofline",
             },
             "valu": {"achieved": round(valu_tflops, 4), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(valu_tflops / VALU_PEAK_TFLOPS, 6),
-                     "algorithmic_flops_per_frame": flops_per_frame},
+                     "algorithmic_flops_per_frame": flops_per_frame,
+                     "note": "algorithmic flops per frame / wall time per frame (device-level rate over the timed region); peak = FMA rate, "
+                             "the numerics contract forbids contraction, so the reachable ceiling for this instruction mix is ~1/2 of it"},
             "pass_ms": {"event_total": round(tm.total_ms / frames, 5), "trace": round(tm.trace_ms / frames, 5),
                         "classify": round(tm.classify_ms / frames, 5),
                         "level_trace": [round(tm.level_trace_ms[i] / frames, 5) for i in range(args.levels)]},

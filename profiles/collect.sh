@@ -6,12 +6,13 @@
 #   4. PMC pass: SQ instruction/cycle counters
 # Outputs go to gpurun_out/prof_<tag>/ ; profiles/summarize.py turns them into profiles/<tag>_*.{csv,json}.
 TAG=${1:-r01}
-ARGS=${2:-"--steps 30 --warmup 5 --no-cpu-baseline"}
+ARGS=${2:-"--steps 64 --warmup 16 --no-cpu-baseline"}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $ROOT/bench.py $ARGS > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_f1 -o bench -- python $ROOT/bench.py $ARGS --frames-in-flight 1 > $OUT/stats_f1.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o bench -- python $ROOT/bench.py $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o bench -- python $ROOT/bench.py $ARGS > $OUT/write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -o bench -- python $ROOT/bench.py $ARGS > $OUT/sq.log 2>&1

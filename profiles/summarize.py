@@ -24,6 +24,9 @@ def find(sub, suffix):
 stats = find("stats", "kernel_stats.csv")
 if stats:
     shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+stats1 = find("stats_f1", "kernel_stats.csv")
+if stats1:
+    shutil.copy(stats1, os.path.join(dst, f"{tag}_kernel_stats_1frame_in_flight.csv"))
 
 
 def per_kernel(sub):
