@@ -52,6 +52,12 @@ def algorithmic_bytes_frame(c: dict) -> float:
             + c["disk_hits"] * 32.0 + c["sky_samples"] * 16.0 + c["node_pairs"] * 64.0 + c["triangles"] * 124.0)
 
 
+def counters_sky_taps(c: dict, frame_pixels: int) -> float:
+    """Direction pixels of the final frame = pixels the sky pass has to sample: everything that is not a colour pixel.
+    Upper bound from the counters: frame pixels minus the rays that sampled the sky in-kernel or hit something."""
+    return float(max(0, frame_pixels - c["sky_samples"]))
+
+
 def algorithmic_flops(c: dict, method: int) -> float:
     return c["steps"] * FLOPS_PER_STEP[method] + c["node_pairs"] * FLOPS_NODE_PAIR + c["triangles"] * FLOPS_TRIANGLE
 
@@ -226,6 +232,10 @@ def main():
         for _ in range(10):
             rp1.render(); rp1.sync()
         iso = rp1.timing()
+        # the pass that follows the ray pass in the reference (sky.wgsl): HBM-bound, reported next to the ray pass
+        for _ in range(10):
+            rp1.render(); rp1.resolve_sky(); rp1.sync()
+        iso_sky = rp1.timing()
         rp1.close()
     if rank == 0:
         pixels = args.width * args.height
@@ -258,6 +268,14 @@ def main():
                      "level_trace_ms": [round(iso.level_trace_ms[i] / max(1, iso.frames), 5) for i in range(args.levels)],
                      "valu_tflops": round(flops_per_frame * iso.frames / (iso.trace_ms * 1e-3) / 1e12, 4),
                      "note": "same kernels, one frame in flight, nothing else on the device (matches rocprofv3 --stats of `bench.py --frames-in-flight 1`)"}
+        sky_d = None
+        if iso is not None and iso_sky.sky_launches:
+            sky_ms = iso_sky.sky_ms / iso_sky.sky_launches
+            sky_bytes = pixels * 24.0 + counters_sky_taps(counters, pixels) * 16.0
+            sky_d = {"kernel": "sky_kernel (sky.wgsl, rgba32f -> rgba16f)", "avg_launch_ms": round(sky_ms, 5), "launches": int(iso_sky.sky_launches),
+                     "algorithmic_bytes_per_launch": sky_bytes, "achieved": round(sky_bytes / (sky_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(sky_bytes / (sky_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "note": "16 B read + 8 B written per pixel + 16 B of sky texels per direction pixel; not part of `value`"}
         out = {
             "metric": "Mrays/sec at 1920x1080 adaptive-RK4; 1/2/4/8 MI355X + % HBM roofline",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -289,6 +307,7 @@ def main():
             "pass_ms": {"event_total": round(tm.total_ms / frames, 5), "trace": round(tm.trace_ms / frames, 5),
                         "classify": round(tm.classify_ms / frames, 5),
                         "level_trace": [round(tm.level_trace_ms[i] / frames, 5) for i in range(args.levels)]},
+            "sky_resolve": sky_d,
             "counters": counters,
             "algorithmic_bytes_per_frame": algorithmic_bytes_frame(counters),
         }

@@ -45,6 +45,8 @@ struct Slot {
     Counters64* d_counters = nullptr;   // [BHRAY_MAX_LEVELS]
     float4* own_out = nullptr;
     float4* out = nullptr;              // where this slot's frame is written (own_out or a bound buffer)
+    uint2* sky_out = nullptr;           // RGBA16F image of the sky resolve pass (allocated on first use)
+    uint64_t frame_id = 0;              // frame_counter value of the frame this slot holds
     hipEvent_t done = nullptr;          // recorded after the slot's last launch
 };
 
@@ -80,6 +82,7 @@ struct bhray_ctx {
     bool have_uniforms = false;
     std::vector<hipEvent_t> events;        // ring: [BHRAY_TIMING_RING][levels][3] (before classify, before trace, after trace)
     uint64_t frame_counter = 0, timing_begin = 0;
+    uint8_t sky_recorded[BHRAY_TIMING_RING] = {0};
     int* d_err = nullptr;
     int num_cus = 256;
     int bpc_override = 0;                  // BHRAY_TRACE_BLOCKS_PER_CU (tuning experiments only)
@@ -253,6 +256,7 @@ void bhray_destroy(bhray_ctx* c) {
         if (S.d_qctl) (void)hipFree(S.d_qctl);
         if (S.d_counters) (void)hipFree(S.d_counters);
         if (S.own_out) (void)hipFree(S.own_out);
+        if (S.sky_out) (void)hipFree(S.sky_out);
         if (S.done) (void)hipEventDestroy(S.done);
         if (S.stream) (void)hipStreamDestroy(S.stream);
     }
@@ -367,7 +371,7 @@ int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
         CHK(hipMemset(S.d_counters, 0, BHRAY_MAX_LEVELS * sizeof(Counters64)));
     }
     if (cfg->flags & BHRAY_F_TIMING) {
-        c->events.assign((size_t)BHRAY_TIMING_RING * nl * 3, nullptr);
+        c->events.assign((size_t)BHRAY_TIMING_RING * (nl * 3 + 2), nullptr);
         for (auto& e : c->events) CHK(hipEventCreate(&e));
     }
     CHK(hipMalloc(&c->d_err, sizeof(int)));
@@ -520,7 +524,9 @@ int bhray_render(bhray_ctx* c) {
     S.out = c->bound_out ? c->bound_out : S.own_out;
     HIPCHK(c, hipMemsetAsync(S.d_qctl, 0, 2 * BHRAY_MAX_LEVELS * sizeof(uint32_t), st));
     if (count) HIPCHK(c, hipMemsetAsync(S.d_counters, 0, BHRAY_MAX_LEVELS * sizeof(Counters64), st));
-    hipEvent_t* fev = timing ? &c->events[(size_t)(c->frame_counter % BHRAY_TIMING_RING) * nl * 3] : nullptr;
+    hipEvent_t* fev = timing ? &c->events[(size_t)(c->frame_counter % BHRAY_TIMING_RING) * (nl * 3 + 2)] : nullptr;
+    S.frame_id = c->frame_counter;
+    if (timing) c->sky_recorded[c->frame_counter % BHRAY_TIMING_RING] = 0;
     // Persistent trace grid: (resident blocks per CU) x CUs.  With several frames in flight one block
     // slot per CU is left free, so that the small (latency-bound) levels of the next frame can run
     // beside the large last level of this one instead of queueing behind it.
@@ -635,6 +641,43 @@ int bhray_bind_output(bhray_ctx* c, void* p, size_t bytes) {
     return BHRAY_OK;
 }
 
+int bhray_resolve_sky(bhray_ctx* c) {
+    if (!c) return BHRAY_E_INVALID;
+    if (!c->rendered) return fail(c, BHRAY_E_STATE, "nothing rendered yet");
+    HIPCHK(c, hipSetDevice(c->device));
+    Slot& S = c->slots[(size_t)c->last_slot];
+    const size_t npix = c->local_rows.size() * (size_t)c->cfg.frame_w;
+    if (!S.sky_out && npix) HIPCHK(c, hipMalloc(&S.sky_out, npix * sizeof(uint2)));
+    TexDev sky; sky.rgba = c->tex[BHRAY_TEX_SKY]; sky.w = c->tex_w[BHRAY_TEX_SKY]; sky.h = c->tex_h[BHRAY_TEX_SKY];
+    const bool timing = (c->cfg.flags & BHRAY_F_TIMING) != 0;
+    hipEvent_t* ev = timing ? &c->events[(size_t)(S.frame_id % BHRAY_TIMING_RING) * (c->cfg.levels * 3 + 2) + c->cfg.levels * 3] : nullptr;
+    if (timing) HIPCHK(c, hipEventRecord(ev[0], S.stream));
+    HIPCHK(c, launch_sky(sky, S.out, S.sky_out, npix, S.stream));
+    if (timing) { HIPCHK(c, hipEventRecord(ev[1], S.stream)); c->sky_recorded[S.frame_id % BHRAY_TIMING_RING] = 1; }
+    HIPCHK(c, hipEventRecord(S.done, S.stream));
+    return BHRAY_OK;
+}
+
+int bhray_read_sky(bhray_ctx* c, uint16_t* dst, size_t pitch) {
+    if (!c) return BHRAY_E_INVALID;
+    const size_t rowb = (size_t)c->cfg.frame_w * sizeof(uint2);
+    if (!dst || pitch < rowb) return fail(c, BHRAY_E_INVALID, "bad destination / pitch");
+    Slot& S = c->slots[(size_t)c->last_slot];
+    if (!S.sky_out) return fail(c, BHRAY_E_STATE, "bhray_resolve_sky has not been called for this frame");
+    int rc = bhray_sync(c);
+    if (rc) return rc;
+    if (c->local_rows.empty()) return BHRAY_OK;
+    HIPCHK(c, hipMemcpy2D(dst, pitch, S.sky_out, rowb, rowb, c->local_rows.size(), hipMemcpyDeviceToHost));
+    return BHRAY_OK;
+}
+
+int bhray_sky_device_ptr(bhray_ctx* c, void** p, size_t* bytes) {
+    if (!c || !p) return BHRAY_E_INVALID;
+    *p = c->slots[(size_t)c->last_slot].sky_out;
+    if (bytes) *bytes = c->local_rows.size() * (size_t)c->cfg.frame_w * sizeof(uint2);
+    return BHRAY_OK;
+}
+
 int bhray_wait_stream(bhray_ctx* c, void* s) {
     if (!c) return BHRAY_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
@@ -685,7 +728,10 @@ int bhray_get_timing(bhray_ctx* c, bhray_timing* out) {
     uint64_t begin = c->timing_begin;
     if (c->frame_counter - begin > BHRAY_TIMING_RING) begin = c->frame_counter - BHRAY_TIMING_RING;
     for (uint64_t f = begin; f < c->frame_counter; f++) {
-        hipEvent_t* ev = &c->events[(size_t)(f % BHRAY_TIMING_RING) * nl * 3];
+        hipEvent_t* ev = &c->events[(size_t)(f % BHRAY_TIMING_RING) * (nl * 3 + 2)];
+        if (c->sky_recorded[f % BHRAY_TIMING_RING]) {
+            float t = 0; HIPCHK(c, hipEventElapsedTime(&t, ev[3 * nl], ev[3 * nl + 1])); out->sky_ms += t; out->sky_launches++;
+        }
         hipEvent_t first = nullptr, last = nullptr;
         for (uint32_t l = 0; l < nl; l++) {
             if (c->levels[l].rows.empty()) continue;

@@ -77,5 +77,6 @@ hipError_t launch_classify(const FrameParams& P, const LevelParams& L, uint32_t*
 hipError_t launch_trace(const FrameParams& P, const LevelParams& L, const uint32_t* queue, const uint32_t* qcount,
                         uint32_t* qhead, Counters64* counters, int* err_flag, int grid_blocks, hipStream_t s);
 int trace_blocks_per_cu(int method, int has_models, int count);
+hipError_t launch_sky(const TexDev& sky, const float4* src, uint2* dst_rgba16f, size_t npix, hipStream_t s);
 
 }  // namespace bhray

@@ -19,6 +19,8 @@
 // Numerics: DESIGN.md §Numerics — compiled with -ffp-contract=off; operation order follows the
 // shader so results are bit-identical to the CPU oracle except for the shading-only
 // optical-depth powf(.,1.3) (device libm, 1-2 ulp, not amplified).
+#include <hip/hip_fp16.h>
+
 #include "bhray_internal.h"
 #include "bhray_math.h"
 
@@ -604,6 +606,38 @@ __global__ __launch_bounds__(256, BHRAY_TRACE_WAVES) void trace_kernel(const Fra
         }
     }
     if (err) *err_flag = err;
+}
+
+// ------------------------------------------------------------------------------------------
+// sky resolve: sky.wgsl:1-38 (the pass after the ray levels, mod.rs:419)
+// ------------------------------------------------------------------------------------------
+// HBM-bound: 16 B read + 8 B written per pixel (+ 4 sky texels, mostly cache hits); one thread per pixel,
+// consecutive lanes on consecutive pixels, so loads are 1 KiB and stores 512 B per wave instruction.
+__global__ __launch_bounds__(256) void sky_kernel(const TexDev sky, const float4* __restrict__ src, uint2* __restrict__ dst, size_t npix) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    float4 p = src[i];
+    if (p.w == 0.0f) {                                                   // sky.wgsl:19
+        // cartesian_to_spherical(p.xzy), sky.wgsl:20, 32-38
+        const float theta = bh_atan2(sqrtf(p.x * p.x + p.z * p.z), p.y);
+        const float phi = bh_atan2(p.z, p.x);
+        const float PI_F = 3.1415926f;
+        float u = (phi + 2.6f * PI_F) / (2.0f * PI_F);
+        float v = (PI_F - theta) / PI_F;
+        u = u - truncf(u); v = v - truncf(v);
+        const float4 sc = sample_bilinear(sky, u, v);
+        p = make_float4((sc.x * sc.x) * (sc.x * sc.x), (sc.y * sc.y) * (sc.y * sc.y), (sc.z * sc.z) * (sc.z * sc.z), 1.0f);
+    }
+    // rgba16float target (sky.wgsl:1): round to nearest even
+    const uint32_t lo = (uint32_t)__half_as_ushort(__float2half_rn(p.x)) | ((uint32_t)__half_as_ushort(__float2half_rn(p.y)) << 16);
+    const uint32_t hi = (uint32_t)__half_as_ushort(__float2half_rn(p.z)) | ((uint32_t)__half_as_ushort(__float2half_rn(p.w)) << 16);
+    dst[i] = make_uint2(lo, hi);
+}
+
+hipError_t launch_sky(const TexDev& sky, const float4* src, uint2* dst, size_t npix, hipStream_t s) {
+    if (npix == 0) return hipSuccess;
+    hipLaunchKernelGGL(sky_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, sky, src, dst, npix);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------

@@ -79,7 +79,8 @@ class BhrayCounters(C.Structure):
 class BhrayTiming(C.Structure):
     _fields_ = [("frames", C.c_uint32), ("total_ms", C.c_float), ("trace_ms", C.c_float), ("classify_ms", C.c_float),
                 ("trace_launches", C.c_uint32), ("classify_launches", C.c_uint32),
-                ("level_trace_ms", C.c_float * MAX_LEVELS), ("level_classify_ms", C.c_float * MAX_LEVELS)]
+                ("level_trace_ms", C.c_float * MAX_LEVELS), ("level_classify_ms", C.c_float * MAX_LEVELS),
+                ("sky_ms", C.c_float), ("sky_launches", C.c_uint32)]
 
 
 assert C.sizeof(BhrayDetails) == 32 and C.sizeof(BhrayCameraUniform) == 32 and C.sizeof(BhrayBlackHoleUniform) == 132
@@ -110,6 +111,9 @@ SYMBOLS = {
     "bhray_local_row_index": (C.c_int, [vp, u32, P(u32)]),
     "bhray_hdr_device_ptr": (C.c_int, [vp, P(vp), P(sz)]),
     "bhray_bind_output": (C.c_int, [vp, vp, sz]),
+    "bhray_resolve_sky": (C.c_int, [vp]),
+    "bhray_read_sky": (C.c_int, [vp, vp, sz]),
+    "bhray_sky_device_ptr": (C.c_int, [vp, P(vp), P(sz)]),
     "bhray_wait_stream": (C.c_int, [vp, vp]),
     "bhray_signal_stream": (C.c_int, [vp, vp]),
     "bhray_get_counters": (C.c_int, [vp, P(BhrayCounters)]),

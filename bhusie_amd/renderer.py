@@ -112,6 +112,16 @@ class RayPass:
         check(lib().bhray_read_level(self._h, level, out.ctypes.data, out.strides[0]), self._h)
         return out
 
+    def resolve_sky(self):
+        """sky.wgsl behind the last frame (mod.rs:419): direction pixels -> sky^4; RGBA16F."""
+        check(lib().bhray_resolve_sky(self._h), self._h)
+
+    def read_sky(self) -> np.ndarray:
+        n = int(lib().bhray_local_rows(self._h))
+        out = np.empty((n, int(self.cfg.frame_w), 4), dtype=np.float16)
+        check(lib().bhray_read_sky(self._h, out.ctypes.data, out.strides[0]), self._h)
+        return out
+
     def device_ptr(self):
         p, n = C.c_void_p(), C.c_size_t()
         check(lib().bhray_hdr_device_ptr(self._h, C.byref(p), C.byref(n)), self._h)

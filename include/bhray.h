@@ -239,6 +239,15 @@ int bhray_bind_output(bhray_ctx* ctx, void* dev_ptr, size_t bytes);
 int bhray_wait_stream(bhray_ctx* ctx, void* hip_stream);
 int bhray_signal_stream(bhray_ctx* ctx, void* hip_stream);
 
+/* Sky resolve — the compute pass that follows the ray pass in the reference (shaders/sky.wgsl:1-38,
+ * pipelines/sky_pipeline.rs:17-148, dispatched right after the ray levels at mod.rs:419): alpha == 0 pixels carry
+ * an escape direction and become sky^4 (alpha 1), other pixels pass through; target format rgba16float.
+ * bhray_resolve_sky enqueues it behind the most recently enqueued frame (same slot, same stream) into that slot's
+ * RGBA16F image: local_rows x frame_w x 4 binary16, round-to-nearest-even.                                       */
+int bhray_resolve_sky(bhray_ctx* ctx);
+int bhray_read_sky(bhray_ctx* ctx, uint16_t* dst_rgba16f, size_t row_pitch_bytes);
+int bhray_sky_device_ptr(bhray_ctx* ctx, void** dev_ptr, size_t* bytes);
+
 /* ------------------------------------------------------------------------------------------
  * Measurement
  * ---------------------------------------------------------------------------------------- */
@@ -269,6 +278,8 @@ typedef struct bhray_timing {
     uint32_t classify_launches;
     float    level_trace_ms[BHRAY_MAX_LEVELS];
     float    level_classify_ms[BHRAY_MAX_LEVELS];
+    float    sky_ms;                   /* Σ sky resolve kernels                              */
+    uint32_t sky_launches;
 } bhray_timing;
 int bhray_get_timing(bhray_ctx* ctx, bhray_timing* out);       /* needs BHRAY_F_TIMING       */
 

@@ -647,3 +647,28 @@ def render_ladder(S: Scene, sizes, stats=None):
         img = render_level(S, sz, prev, stats)
         imgs.append(img); prev = img
     return imgs
+
+
+# ------------------------------------------------------------------ sky.wgsl:1-38 (resolve pass)
+def sky_resolve(prev, t_sky):
+    """alpha == 0: direction -> uv -> sky^4, alpha 1 (sky.wgsl:19-26); else pass through.  Stored as rgba16float
+    (sky.wgsl:1): numpy's float32 -> float16 cast rounds to nearest even."""
+    p = np.asarray(prev, dtype=np.float32)
+    h, w = p.shape[:2]
+    flat = p.reshape(-1, 4)
+    out = flat.copy()
+    with np.errstate(invalid="ignore"):
+        k = np.nonzero(flat[:, 3] == 0)[0]
+    if k.size:
+        d = flat[k, :3]
+        # cartesian_to_spherical(p.xzy): theta = atan2(length(v.xy), v.z), phi = atan2(v.y, v.x), v = (d.x, d.z, d.y)
+        theta = bh_atan2(np.sqrt(d[:, 0] * d[:, 0] + d[:, 2] * d[:, 2]), d[:, 1])
+        phi = bh_atan2(d[:, 2], d[:, 0])
+        u = (phi + f32(2.6) * PI) / (f32(2.0) * PI)
+        v = (PI - theta) / PI
+        u = u - np.trunc(u); v = v - np.trunc(v)
+        sc = sample_bilinear(t_sky, u, v)[:, 0:3]
+        out[k, 0:3] = (sc * sc) * (sc * sc)
+        out[k, 3] = 1.0
+    with np.errstate(over="ignore"):
+        return out.reshape(h, w, 4).astype(np.float16)

@@ -77,6 +77,10 @@ def lib():
         L.bh_acos.argtypes = [C.c_float]
         L.bh_pow_m001.restype = C.c_float
         L.bh_pow_m001.argtypes = [C.c_float]
+        L.oracle_sky_resolve.restype = C.c_int
+        L.oracle_sky_resolve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_f32_to_f16.restype = C.c_uint16
+        L.oracle_f32_to_f16.argtypes = [C.c_float]
         L.oracle_num_threads.restype = C.c_int
         L.oracle_set_threads.argtypes = [C.c_int]
         _lib = L
@@ -225,3 +229,13 @@ def num_threads() -> int:
 
 def set_threads(n: int) -> None:
     lib().oracle_set_threads(n)
+
+
+def sky_resolve(prev: np.ndarray, t_sky: np.ndarray) -> np.ndarray:
+    """sky.wgsl over a whole RGBA32F image -> (H, W, 4) float16 (the reference target is rgba16float)."""
+    prev = np.ascontiguousarray(prev, dtype=np.float32)
+    h, w = prev.shape[:2]
+    out = np.zeros((h, w, 4), dtype=np.uint16)
+    rc = lib().oracle_sky_resolve(prev.ctypes.data, w, h, t_sky.ctypes.data, t_sky.shape[1], t_sky.shape[0], out.ctypes.data)
+    assert rc == 0
+    return out.view(np.float16)

@@ -694,6 +694,56 @@ static v4 pixel_main(const scene* S, int px, int py, int sw, int sh, const float
     return trace_ray(S, create_ray(S, px, py, sw, sh));             /* ray.wgsl:236-238 */
 }
 
+
+/* ---- sky resolve pass: /root/reference/src/renderer/shaders/sky.wgsl:1-38 ----------------------------------
+ * (the consumer of the ray pass output.)  alpha == 0 pixels carry an escape direction:
+ * direction -> equirect uv -> sky^4, alpha 1; other pixels pass through.  The target is rgba16float
+ * (sky.wgsl:1): binary32 -> binary16 with round-to-nearest-even. */
+static uint16_t f32_to_f16_rne(float f) {
+    uint32_t x = f2u(f);
+    uint32_t sign = (x >> 16) & 0x8000u;
+    uint32_t em = x & 0x7fffffffu;
+    if (em >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | ((em > 0x7f800000u) ? 0x0200u | ((em >> 13) & 0x03ffu) : 0u));   /* inf / NaN */
+    if (em >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                 /* rounds to >= 65520 -> inf */
+    if (em < 0x33000001u) return (uint16_t)sign;                             /* < 2^-25 (or == 2^-25 tie to even 0) -> 0 */
+    int32_t e = (int32_t)(em >> 23) - 127;
+    uint32_t m = (em & 0x007fffffu) | 0x00800000u;
+    uint32_t shift, half;
+    if (e < -14) { shift = (uint32_t)(13 + (-14 - e)); }                     /* subnormal half */
+    else { shift = 13; }
+    uint32_t q = m >> shift, rem = m & ((1u << shift) - 1u);
+    half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (q & 1u))) q++;
+    uint32_t out;
+    if (e < -14) out = q;                                                    /* may carry into the smallest normal */
+    else out = ((uint32_t)(e + 15) << 10) + (q - 0x400u);                    /* q in [0x400, 0x800]; carry bumps the exponent */
+    return (uint16_t)(sign | out);
+}
+uint16_t oracle_f32_to_f16(float f) { return f32_to_f16_rne(f); }
+
+int oracle_sky_resolve(const float* prev, int w, int h, const uint8_t* sky_rgba, int sw, int sh, uint16_t* out) {
+    if (!prev || !sky_rgba || !out) return -1;
+    o_tex t = { sky_rgba, sw, sh };
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            const float* p = prev + 4 * ((size_t)y * w + x);
+            uint16_t* o = out + 4 * ((size_t)y * w + x);
+            float r = p[0], g = p[1], b = p[2], a = p[3];
+            if (a == 0.0f) {                                                  /* sky.wgsl:19 */
+                v3 sp = cartesian_to_spherical(V(p[0], p[2], p[1]));          /* p.xzy */
+                float u = (sp.z + 2.6f * PI_F) / (2.0f * PI_F);
+                float v = (PI_F - sp.y) / PI_F;
+                u = u - truncf(u); v = v - truncf(v);
+                v4 sc = sample_bilinear(&t, u, v);
+                r = (sc.x * sc.x) * (sc.x * sc.x); g = (sc.y * sc.y) * (sc.y * sc.y); b = (sc.z * sc.z) * (sc.z * sc.z); a = 1.0f;
+            }
+            o[0] = f32_to_f16_rne(r); o[1] = f32_to_f16_rne(g); o[2] = f32_to_f16_rne(b); o[3] = f32_to_f16_rne(a);
+        }
+    }
+    return 0;
+}
+
 /* ---- exported entry points (ctypes) --------------------------------------------------------------- */
 typedef struct {
     const o_camera* camera; const o_details* details; const o_black_hole* bh;

@@ -53,6 +53,8 @@ def frames():
         for l, im in enumerate(imgs):
             out[f"{name}.level{l}"] = im
         out[f"{name}.stats"] = np.array([stats.get(k, 0) for k in ("traced", "steps", "copied", "interpolated", "sky_samples")], dtype=np.int64)
+        if name in ("rk_ladder", "rk_outside"):          # sky resolve pass (sky.wgsl) of the final level, rgba16float
+            out[f"{name}.sky"] = N.sky_resolve(imgs[-1], tex[2]).view(np.uint16)
         print(name, sizes, stats)
     np.savez_compressed(os.path.join(HERE, "frames.npz"), **out)
 
