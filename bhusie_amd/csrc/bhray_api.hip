@@ -54,7 +54,7 @@ struct ModelStore {
     float pos[3] = {0, 0, 0};
     int visible = 0;
     float4* points = nullptr; float4* normals = nullptr; int32_t* triangles = nullptr;
-    float4* nodes = nullptr; int32_t* lookup = nullptr;
+    float4* nodes = nullptr; int32_t* lookup = nullptr; float4* leaf = nullptr;
     int point_count = 0, normal_count = 0, triangle_count = 0, node_count = 0;
     bool loaded = false;
 };
@@ -158,7 +158,7 @@ void derive_frame(const bhray_ctx* c, FrameParams& P) {
         ModelDev& md = P.models[i];
         memcpy(md.pos, m.pos, 12);
         md.visible = (m.loaded && m.triangle_count > 0) ? m.visible : 0;
-        md.points = m.points; md.normals = m.normals; md.triangles = m.triangles; md.nodes = m.nodes; md.lookup = m.lookup;
+        md.points = m.points; md.normals = m.normals; md.triangles = m.triangles; md.nodes = m.nodes; md.lookup = m.lookup; md.leaf = m.leaf;
         md.node_count = m.node_count;
         usable = i + 1;
     }
@@ -184,6 +184,7 @@ void free_model(ModelStore& m) {
     if (m.triangles) (void)hipFree(m.triangles);
     if (m.nodes) (void)hipFree(m.nodes);
     if (m.lookup) (void)hipFree(m.lookup);
+    if (m.leaf) (void)hipFree(m.leaf);
     m = ModelStore();
 }
 
@@ -446,8 +447,42 @@ int bhray_upload_model(bhray_ctx* c, uint32_t mi, const bhray_model_desc* d) {
         HIPCHK(c, hipMemcpy(m.points, d->points, (size_t)d->point_count * 16, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(m.normals, d->normals, (size_t)d->normal_count * 16, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(m.triangles, d->triangles, (size_t)d->triangle_count * 24, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(m.nodes, d->nodes, (size_t)d->node_count * 32, hipMemcpyHostToDevice));
+        // Nodes are re-numbered breadth-first for the device (the builder numbers them depth-first, triangle.rs:239-258):
+        // the top of the tree, which every traversal touches, is then contiguous (cache locality).  Children stay adjacent
+        // and leaf ranges are untouched, so traversal order and results do not change.
+        {
+            std::vector<bhray_node> bfs((size_t)d->node_count);
+            std::vector<int32_t> order; order.reserve((size_t)d->node_count);
+            order.push_back(0);
+            size_t next = 1;
+            for (size_t q = 0; q < order.size(); q++) {
+                const bhray_node& n = d->nodes[(size_t)order[q]];
+                bfs[q] = n;
+                if (n.obj_count == 0) {
+                    if (next + 2 > (size_t)d->node_count) return fail(c, BHRAY_E_INVALID, "malformed BVH (unreachable or shared nodes)");
+                    bfs[q].left_child = (int32_t)next;
+                    order.push_back(n.left_child); order.push_back(n.left_child + 1);
+                    next += 2;
+                }
+            }
+            m.node_count = (int)order.size();
+            HIPCHK(c, hipMemcpy(m.nodes, bfs.data(), order.size() * 32, hipMemcpyHostToDevice));
+        }
         HIPCHK(c, hipMemcpy(m.lookup, d->bvh_lookup, (size_t)d->triangle_count * 4, hipMemcpyHostToDevice));
+        // pre-gathered leaf geometry: slot k holds the points and normals of triangle bvh_lookup[k] (copies, same bits)
+        {
+            std::vector<float> leaf((size_t)d->triangle_count * 24);
+            for (int k = 0; k < d->triangle_count; k++) {
+                const bhray_triangle& t = d->triangles[d->bvh_lookup[k]];
+                const int32_t pi[3] = {t.p1, t.p2, t.p3}, ni[3] = {t.n1, t.n2, t.n3};
+                for (int v = 0; v < 3; v++) {
+                    memcpy(&leaf[(size_t)k * 24 + 4 * v], d->points + 4 * (size_t)pi[v], 16);
+                    memcpy(&leaf[(size_t)k * 24 + 12 + 4 * v], d->normals + 4 * (size_t)ni[v], 16);
+                }
+            }
+            HIPCHK(c, hipMalloc(&m.leaf, leaf.size() * 4));
+            HIPCHK(c, hipMemcpy(m.leaf, leaf.data(), leaf.size() * 4, hipMemcpyHostToDevice));
+        }
     }
     m.loaded = true;
     return BHRAY_OK;

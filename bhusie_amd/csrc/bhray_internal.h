@@ -21,6 +21,7 @@ struct ModelDev {
     const int32_t* triangles;   // 6 ints each
     const float4* nodes;        // 2 float4 per node
     const int32_t* lookup;
+    const float4* leaf;         // pre-gathered leaf geometry: 6 float4 (p1,p2,p3,n1,n2,n3) per bvh_lookup slot
     int node_count;
 };
 

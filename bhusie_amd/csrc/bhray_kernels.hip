@@ -222,45 +222,49 @@ __device__ __forceinline__ bool hit_triangle(F3 pos, F3 dir, float t_min, float 
 // trace_ray_model, ray.wgsl:287-363.  The traversal stack holds node indices (the reference
 // stacks 19 whole nodes and has no overflow check); an overflow raises *err instead of
 // corrupting memory.
+// trace_ray_model, ray.wgsl:287-363.
+// Latency is what matters here (a traversal is a chain of dependent loads executed for a few lanes of a wave), so
+// the data is laid out for ONE round trip per tree level and per leaf:
+//  - an inner node is never re-read: when a child pair is fetched (one 64 B segment — the builder allocates siblings
+//    adjacently, triangle.rs:239-243), the pair's own (left_child, obj_count) words are kept for the child that is
+//    descended into or pushed, because a node's bounds are not needed again once its parent has tested them;
+//  - leaf geometry is pre-gathered at upload into `leaf` (3 points + 3 normals per bvh_lookup slot), removing the
+//    bvh_lookup -> triangle -> point/normal index chain (ray.wgsl:333-343) from the traversal.
+// The reference stacks 19 whole nodes without an overflow check (ray.wgsl:292,327); here the stack holds the two
+// words per node and an overflow raises *err instead of corrupting memory.
 template <bool COUNT>
-__device__ __noinline__ void trace_ray_model(const ModelDev& M, F3 pos, F3 dir, float t_min, float t_max, Hit& closest,
-                                             F3& normal_out, unsigned long long* cnt, int* err) {
+__device__ __noinline__ void trace_ray_model(const ModelDev& M, F3 pos, F3 dir, float t_min, float t_max,
+                                             Hit& closest, F3& normal_out, unsigned long long* cnt, int* err) {
     F3 mpos = ld3(M.pos);
     F3 inv = f3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
     closest.hit = false; closest.t = t_max; closest.color = f3(0, 0, 0); closest.opacity = 0.0f;
     normal_out = f3(0, 0, 0);
-    int node = 0;
-    int stack[BHRAY_BVH_STACK];
+    int contents = __float_as_int(M.nodes[0].w), obj_count = __float_as_int(M.nodes[1].w);     // nodes[0], untested root (ray.wgsl:291)
+    int2 stack[BHRAY_BVH_STACK];
     int sp = 0;
     for (;;) {
-        const float4 n_hi = M.nodes[2 * node + 1];
-        const float4 n_lo = M.nodes[2 * node];
-        const int obj_count = __float_as_int(n_hi.w), contents = __float_as_int(n_lo.w);
         if (obj_count == 0) {
-            int c1 = contents, c2 = contents + 1;
-            // adjacent children: 4 x float4 = one 64 B segment
-            const float4 a_lo = M.nodes[2 * c1], a_hi = M.nodes[2 * c1 + 1];
-            const float4 b_lo = M.nodes[2 * c2], b_hi = M.nodes[2 * c2 + 1];
+            const float4* pair = M.nodes + 2 * (size_t)contents;
+            const float4 a_lo = pair[0], a_hi = pair[1], b_lo = pair[2], b_hi = pair[3];
             if (COUNT) cnt[6]++;
             float d1 = hit_aabb(pos, inv, a_lo, a_hi, mpos);
             float d2 = hit_aabb(pos, inv, b_lo, b_hi, mpos);
-            if (d1 > d2) { float td = d1; d1 = d2; d2 = td; int tc = c1; c1 = c2; c2 = tc; }
+            int2 n1 = make_int2(__float_as_int(a_lo.w), __float_as_int(a_hi.w));
+            int2 n2 = make_int2(__float_as_int(b_lo.w), __float_as_int(b_hi.w));
+            if (d1 > d2) { float td = d1; d1 = d2; d2 = td; int2 tn = n1; n1 = n2; n2 = tn; }
             if (d1 > closest.t) {
                 if (sp == 0) break;
-                node = stack[--sp];
+                --sp; contents = stack[sp].x; obj_count = stack[sp].y;
             } else {
-                node = c1;
+                contents = n1.x; obj_count = n1.y;
                 if (d2 < closest.t) {
-                    if (sp < BHRAY_BVH_STACK) stack[sp++] = c2; else *err = BHRAY_E_BVH_DEPTH;
+                    if (sp < BHRAY_BVH_STACK) stack[sp++] = n2; else *err = BHRAY_E_BVH_DEPTH;
                 }
             }
         } else {
             for (int i = 0; i < obj_count; i++) {
-                const int idx = M.lookup[contents + i];
-                const int32_t* ti = M.triangles + 6 * (size_t)idx;
-                const int p1 = ti[0], p2 = ti[1], p3 = ti[2], q1 = ti[3], q2 = ti[4], q3 = ti[5];
-                const float4 A = M.points[p1], B = M.points[p2], Cc = M.points[p3];
-                const float4 N1 = M.normals[q1], N2 = M.normals[q2], N3 = M.normals[q3];
+                const float4* g = M.leaf + 6 * (size_t)(contents + i);
+                const float4 A = g[0], B = g[1], Cc = g[2], N1 = g[3], N2 = g[4], N3 = g[5];
                 if (COUNT) cnt[7]++;
                 float t; F3 col, nrm;
                 if (hit_triangle(pos, dir, t_min, t_max, f3(A.x, A.y, A.z) + mpos, f3(B.x, B.y, B.z) + mpos,
@@ -270,7 +274,7 @@ __device__ __noinline__ void trace_ray_model(const ModelDev& M, F3 pos, F3 dir, 
                 }
             }
             if (sp == 0) break;
-            node = stack[--sp];
+            --sp; contents = stack[sp].x; obj_count = stack[sp].y;
         }
     }
 }
@@ -423,6 +427,12 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3 };
 #ifndef BHRAY_REL_BATCH
 #define BHRAY_REL_BATCH 16       // integrator steps between refill / flat / epilogue phases
 #endif
+#ifndef BHRAY_FLAT_MIN_LANES
+#define BHRAY_FLAT_MIN_LANES 12    // mesh variant: run the flat/BVH phase when this many lanes wait for it ...
+#endif
+#ifndef BHRAY_FLAT_DEFER
+#define BHRAY_FLAT_DEFER 4         // ... or after this many rounds at the latest
+#endif
 #ifndef BHRAY_TRACE_WAVES
 #define BHRAY_TRACE_WAVES 4      // waves per SIMD the trace kernel is register-budgeted for (<=128 VGPRs)
 #endif
@@ -449,6 +459,7 @@ __global__ __launch_bounds__(256, BHRAY_TRACE_WAVES) void trace_kernel(const Fra
     int it = 0;
     bool hit = false;
     bool exhausted = false;
+    int flat_round = 0;
     unsigned long long cnt[10];
     if (COUNT) { for (int k = 0; k < 10; k++) cnt[k] = 0; }
     int err = 0;
@@ -485,8 +496,18 @@ __global__ __launch_bounds__(256, BHRAY_TRACE_WAVES) void trace_kernel(const Fra
             if (!__any(mode != M_EMPTY)) break;
         }
 
-        // ---- flat-space iterations (ray.wgsl:554-569), one per lane that is in flat space
-        if (__any(mode == M_FLAT)) {
+        // ---- flat-space iterations (ray.wgsl:554-569), one per lane that is in flat space.
+        // With meshes a flat iteration is a BVH traversal executed by the whole wave for the few lanes that need it,
+        // so those lanes are batched: the phase runs when enough of them wait, when nobody is integrating, or at the
+        // latest every BHRAY_FLAT_DEFER-th round.  Each ray still sees its own iterations in order: results are unchanged.
+        bool run_flat = true;
+        if (MODELS) {
+            const unsigned long long mf = __ballot(mode == M_FLAT);
+            flat_round++;
+            run_flat = mf != 0ull && (__popcll(mf) >= BHRAY_FLAT_MIN_LANES || !__any(mode == M_REL) || flat_round >= BHRAY_FLAT_DEFER);
+            if (run_flat) flat_round = 0;
+        }
+        if (run_flat && __any(mode == M_FLAT)) {
             if (mode == M_FLAT) {
                 if (it >= P.max_iter) {
                     mode = M_FINISH;
