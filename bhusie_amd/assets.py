@@ -160,3 +160,13 @@ def icosphere_mesh_obj(level: int = 6, radius: float = 8.0, bump: float = 0.15, 
     else:
         lines += ["f %d %d %d" % tuple(f) for f in (F + 1)]
     return "\n".join(lines) + "\n"
+
+
+def reference_disk_texture(size: int = 1000) -> np.ndarray:
+    """The reference's own disk texture, regenerated: its asset tool perlin/src/main.rs restated in C++ behind the C ABI
+    (bhray_generate_disk_texture).  size=1000 reproduces src/renderer/textures/disk.png up to libm rounding."""
+    from ._lib import lib
+    from .layouts import check
+    out = np.zeros((size, size, 4), dtype=np.uint8)
+    check(lib().bhray_generate_disk_texture(size, out.ctypes.data))
+    return out

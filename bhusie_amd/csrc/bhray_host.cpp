@@ -374,3 +374,85 @@ int bhray_load_model(const char* path, bhray_model** out) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// perlin/src/main.rs:1-148 — the disk-texture generator (offline asset tool of the reference)
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+inline uint32_t rotl16(uint32_t v) { return (v << 16) | (v >> 16); }
+
+// random_gradient, main.rs:6-24
+inline void random_gradient(uint32_t ix, uint32_t iy, float& gx, float& gy) {
+    uint32_t a = ix, b = iy;
+    a *= 3284157443u;
+    b ^= rotl16(a);
+    b *= 1911520717u;
+    a ^= rotl16(b);
+    a *= 2048419325u;
+    const float random = (float)a * (3.14159265358979323846f / (float)0xFFFFFFFFu);   // PI / (!(0u32 >> 1)) as f32
+    gx = cosf(random); gy = sinf(random);
+}
+inline float dot_grid_gradient(uint32_t ix, uint32_t iy, float x, float y) {            // main.rs:26-33
+    float gx, gy; random_gradient(ix, iy, gx, gy);
+    const float dx = x - (float)ix, dy = y - (float)iy;
+    return dx * gx + dy * gy;
+}
+inline float interpolate(float a0, float a1, float w) {                                  // main.rs:35-38
+    return (a1 - a0) * ((w * (w * 6.0f - 15.0f) + 10.0f) * w * w * w) + a0;
+}
+inline float perlin(float x, float y) {                                                  // main.rs:40-58
+    const uint32_t x0 = (uint32_t)floorf(x), x1 = x0 + 1, y0 = (uint32_t)floorf(y), y1 = y0 + 1;
+    const float sx = x - (float)x0, sy = y - (float)y0;
+    const float ix0 = interpolate(dot_grid_gradient(x0, y0, x, y), dot_grid_gradient(x1, y0, x, y), sx);
+    const float ix1 = interpolate(dot_grid_gradient(x0, y1, x, y), dot_grid_gradient(x1, y1, x, y), sx);
+    return interpolate(ix0, ix1, sy) * 0.5f + 0.5f;
+}
+inline uint8_t as_u8(float v) { return !(v == v) ? 0 : (v <= 0.0f ? 0 : (v >= 255.0f ? 255 : (uint8_t)v)); }            // Rust `as u8`
+inline uint32_t as_u32(float v) { return !(v == v) ? 0u : (v <= 0.0f ? 0u : (v >= 4294967295.0f ? 0xFFFFFFFFu : (uint32_t)v)); }
+
+// value[x * h + y] like ImageBuffer::put_pixel(x, y)
+std::vector<uint8_t> generate(uint32_t w, uint32_t h, uint32_t density) {                // main.rs:61-77
+    std::vector<uint8_t> buf((size_t)w * h);
+    const float d = (float)density / (float)w;
+    for (uint32_t x = 0; x < w; x++)
+        for (uint32_t y = 0; y < h; y++) buf[(size_t)x * h + y] = as_u8(perlin((float)x * d, (float)y * d) * 256.0f);
+    return buf;
+}
+std::vector<uint8_t> spiral(const std::vector<uint8_t>& buf, uint32_t w, uint32_t h, float amount, float power) {      // main.rs:79-110
+    std::vector<uint8_t> out((size_t)w * h);
+    const float PI = 3.14159265358979323846f;
+    for (uint32_t x = 0; x < w; x++)
+        for (uint32_t y = 0; y < h; y++) {
+            float rx = ((float)x / (float)w) * 2.0f - 1.0f, ry = ((float)y / (float)h) * 2.0f - 1.0f;
+            const float r = sqrtf(rx * rx + ry * ry);
+            float theta = atan2f(ry, rx);
+            theta = fmodf(theta + PI + powf(r, power) * PI * amount, 2.0f * PI) - PI;
+            rx = r * cosf(theta); ry = r * sinf(theta);
+            const uint32_t nx = as_u32((rx * 0.5f + 0.5f) * (float)w) % w, ny = as_u32((ry * 0.5f + 0.5f) * (float)h) % h;
+            out[(size_t)x * h + y] = buf[(size_t)nx * h + ny];
+        }
+    return out;
+}
+std::vector<uint8_t> merge(const std::vector<uint8_t>& a, const std::vector<uint8_t>& b, float amount) {              // main.rs:113-131
+    std::vector<uint8_t> out(a.size());
+    for (size_t i = 0; i < a.size(); i++) out[i] = as_u8((float)a[i] * amount + (float)b[i] * (1.0f - amount));
+    return out;
+}
+
+}  // namespace
+
+extern "C" int bhray_generate_disk_texture(uint32_t size, uint8_t* rgba8_out) {          // main(), main.rs:133-147
+    if (!rgba8_out || size < 2 || size > 16384) return BHRAY_E_INVALID;
+    const uint32_t dens[4] = {4, 20, 50, 100};
+    std::vector<uint8_t> sp[4];
+    for (int i = 0; i < 4; i++) sp[i] = spiral(generate(size, size, dens[i]), size, size, 2.0f, 0.5f);
+    const std::vector<uint8_t> m3 = merge(merge(merge(sp[3], sp[2], 0.5f), sp[1], 0.5f), sp[0], 0.5f);
+    for (uint32_t y = 0; y < size; y++)
+        for (uint32_t x = 0; x < size; x++) {
+            const uint8_t v = m3[(size_t)x * size + y];
+            uint8_t* o = rgba8_out + 4 * ((size_t)y * size + x);
+            o[0] = v; o[1] = v; o[2] = v; o[3] = v;
+        }
+    return BHRAY_OK;
+}

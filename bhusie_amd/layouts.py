@@ -134,6 +134,7 @@ SYMBOLS = {
     "bhray_model_set_transform": (C.c_int, [vp, P(C.c_float), i32]),
     "bhray_model_pack_uniform": (C.c_int, [vp, vp, sz]),
     "bhray_load_model": (C.c_int, [C.c_char_p, P(vp)]),
+    "bhray_generate_disk_texture": (C.c_int, [u32, vp]),
 }
 
 

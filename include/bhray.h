@@ -323,6 +323,12 @@ int  bhray_model_pack_uniform(const bhray_model* m, void* dst, size_t size);
  * flat-normal fallback, then build_bvh.                                                      */
 int  bhray_load_model(const char* obj_path, bhray_model** out);
 
+/* Disk-texture generator — the reference's offline asset tool perlin/src/main.rs:1-148 (hash-gradient Perlin noise at
+ * densities 4/20/50/100, spiral warp (amount 2, power 0.5), pairwise 0.5 merges), whose shipped output is
+ * src/renderer/textures/disk.png (binding 9).  Writes size x size RGBA8 with the value replicated into all four
+ * channels, ready for bhray_set_texture(BHRAY_TEX_DISK).  size = 1000 reproduces disk.png up to libm rounding.     */
+int bhray_generate_disk_texture(uint32_t size, uint8_t* rgba8_out);
+
 #ifdef __cplusplus
 }
 #endif

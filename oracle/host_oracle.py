@@ -12,6 +12,8 @@ What is restated (binary32 arithmetic via numpy.float32 scalars, operation order
   * load_model                       src/renderer/model.rs:7-87  (tobj 4.0.2 default options,
       Cargo.lock:2951: no triangulation, separate position / normal index streams)
   * ModelUniform::update byte image  src/renderer/triangle.rs:268-325
+  * the disk-texture generator       perlin/src/main.rs:1-148 — the one place where the reference
+      itself supplies a checkable artefact: its output src/renderer/textures/disk.png
 
 Only tests/ (and fixture generators) import this; the product never does.
 """
@@ -278,3 +280,81 @@ def load_model(text: str) -> Model:
                         n1 + normal_offset, n2 + normal_offset, n3 + normal_offset])
     m.build_bvh()
     return m
+
+
+# ---------------------------------------------------------------- perlin/src/main.rs (offline asset tool)
+def _random_gradient(ix, iy):
+    """perlin/src/main.rs:6-24: integer hash (wrapping_mul, rotate_left by 16) -> angle in [0, pi] -> (cos, sin)."""
+    a = ix.astype(np.uint32); b = iy.astype(np.uint32)
+    a = a * np.uint32(3284157443)
+    b = b ^ ((a << np.uint32(16)) | (a >> np.uint32(16)))
+    b = b * np.uint32(1911520717)
+    a = a ^ ((b << np.uint32(16)) | (b >> np.uint32(16)))
+    a = a * np.uint32(2048419325)
+    k = f32(f32(np.pi) / f32(4294967295))            # PI / (!(0u32 >> 1)) as f32   (u32::MAX as f32 = 2^32)
+    rnd = a.astype(np.float32) * k
+    return np.cos(rnd).astype(np.float32), np.sin(rnd).astype(np.float32)
+
+
+def _dot_grid_gradient(ix, iy, x, y):                # main.rs:26-33
+    gx, gy = _random_gradient(ix, iy)
+    dx = x - ix.astype(np.float32); dy = y - iy.astype(np.float32)
+    return dx * gx + dy * gy
+
+
+def _interpolate(a0, a1, w):                         # main.rs:35-38
+    return (a1 - a0) * ((w * (w * f32(6.0) - f32(15.0)) + f32(10.0)) * w * w * w) + a0
+
+
+def _perlin(x, y):                                   # main.rs:40-58
+    x0 = np.floor(x).astype(np.uint32); y0 = np.floor(y).astype(np.uint32)
+    x1 = x0 + np.uint32(1); y1 = y0 + np.uint32(1)
+    sx = x - x0.astype(np.float32); sy = y - y0.astype(np.float32)
+    ix0 = _interpolate(_dot_grid_gradient(x0, y0, x, y), _dot_grid_gradient(x1, y0, x, y), sx)
+    ix1 = _interpolate(_dot_grid_gradient(x0, y1, x, y), _dot_grid_gradient(x1, y1, x, y), sx)
+    return _interpolate(ix0, ix1, sy) * f32(0.5) + f32(0.5)
+
+
+def _as_u8(v):                                       # Rust `as u8` from f32: truncation, saturating, NaN -> 0
+    v = np.nan_to_num(v, nan=0.0)
+    return np.clip(np.trunc(v), 0, 255).astype(np.uint8)
+
+
+def _generate(w, h, density):                        # main.rs:61-77 (value[x, y]; image row = y)
+    d = f32(f32(density) / f32(w))
+    xs, ys = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32), indexing="ij")
+    return _as_u8(_perlin(xs * d, ys * d) * f32(256.0))            # indexed [x, y]
+
+
+def _spiral(buf, amount, power):                     # main.rs:79-110
+    w, h = buf.shape
+    xs, ys = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32), indexing="ij")
+    rx = (xs / f32(w)) * f32(2.0) - f32(1.0); ry = (ys / f32(h)) * f32(2.0) - f32(1.0)
+    r = np.sqrt(rx * rx + ry * ry).astype(np.float32)
+    theta = np.arctan2(ry, rx).astype(np.float32)
+    PI = f32(np.pi)
+    t = theta + PI + np.power(r, f32(power)).astype(np.float32) * PI * f32(amount)
+    theta = np.fmod(t, f32(2.0) * PI).astype(np.float32) - PI        # Rust % on f32 = fmod
+    rx = r * np.cos(theta).astype(np.float32); ry = r * np.sin(theta).astype(np.float32)
+    nx = _as_u32((rx * f32(0.5) + f32(0.5)) * f32(w)) % np.uint32(w)
+    ny = _as_u32((ry * f32(0.5) + f32(0.5)) * f32(h)) % np.uint32(h)
+    return buf[nx, ny]
+
+
+def _as_u32(v):
+    v = np.nan_to_num(v, nan=0.0)
+    return np.clip(np.trunc(v), 0, 4294967295).astype(np.uint32)
+
+
+def _merge(b1, b2, amount):                          # main.rs:113-131
+    a = f32(amount)
+    return _as_u8(b1.astype(np.float32) * a + b2.astype(np.float32) * (f32(1.0) - a))
+
+
+def perlin_disk(size: int = 1000) -> np.ndarray:
+    """main(): four noise octaves (density 4, 20, 50, 100), each spiral-warped (amount 2, power 0.5), merged pairwise at 0.5
+    (main.rs:133-147).  Returns (size, size, 4) uint8 with the value replicated into R, G, B and A, image row = y."""
+    sp = [_spiral(_generate(size, size, d), 2.0, 0.5) for d in (4, 20, 50, 100)]
+    m = _merge(_merge(_merge(sp[3], sp[2], 0.5), sp[1], 0.5), sp[0], 0.5)
+    img = m.T                                        # buffer.put_pixel(x, y) -> row y, column x
+    return np.ascontiguousarray(np.repeat(img[:, :, None], 4, axis=2))
