@@ -721,6 +721,12 @@ int bhray_wait_stream(bhray_ctx* c, void* s) {
     return BHRAY_OK;
 }
 
+int bhray_next_stream(bhray_ctx* c, void** s) {
+    if (!c || !s) return BHRAY_E_INVALID;
+    *s = (void*)c->slots[(size_t)(c->frame_counter % c->slots.size())].stream;
+    return BHRAY_OK;
+}
+
 int bhray_signal_stream(bhray_ctx* c, void* s) {
     if (!c) return BHRAY_E_INVALID;
     if (!c->rendered) return BHRAY_OK;

@@ -116,6 +116,7 @@ SYMBOLS = {
     "bhray_sky_device_ptr": (C.c_int, [vp, P(vp), P(sz)]),
     "bhray_wait_stream": (C.c_int, [vp, vp]),
     "bhray_signal_stream": (C.c_int, [vp, vp]),
+    "bhray_next_stream": (C.c_int, [vp, P(vp)]),
     "bhray_get_counters": (C.c_int, [vp, P(BhrayCounters)]),
     "bhray_get_level_counters": (C.c_int, [vp, u32, P(BhrayCounters)]),
     "bhray_get_timing": (C.c_int, [vp, P(BhrayTiming)]),

@@ -134,6 +134,12 @@ class RayPass:
         """The next render starts after everything enqueued so far on hipStream_t `s`."""
         check(lib().bhray_wait_stream(self._h, C.c_void_p(s)), self._h)
 
+    def next_stream(self) -> int:
+        """hipStream_t (as int) of the slot the next render will use."""
+        s = C.c_void_p()
+        check(lib().bhray_next_stream(self._h, C.byref(s)), self._h)
+        return s.value
+
     def signal_stream(self, s):
         """Work enqueued on hipStream_t `s` from now on starts after the last render."""
         check(lib().bhray_signal_stream(self._h, C.c_void_p(s)), self._h)

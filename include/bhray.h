@@ -238,6 +238,9 @@ int bhray_bind_output(bhray_ctx* ctx, void* dev_ptr, size_t bytes);
  * `s` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the legacy stream.  */
 int bhray_wait_stream(bhray_ctx* ctx, void* hip_stream);
 int bhray_signal_stream(bhray_ctx* ctx, void* hip_stream);
+/* The hipStream_t of the slot the NEXT bhray_render will use.  A caller that enqueues its own work for that frame on
+ * this stream (e.g. wraps it as torch.cuda.ExternalStream and issues the RCCL gather there) needs no extra ordering.  */
+int bhray_next_stream(bhray_ctx* ctx, void** hip_stream);
 
 /* Sky resolve — the compute pass that follows the ray pass in the reference (shaders/sky.wgsl:1-38,
  * pipelines/sky_pipeline.rs:17-148, dispatched right after the ray levels at mod.rs:419): alpha == 0 pixels carry
