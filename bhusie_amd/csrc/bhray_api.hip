@@ -41,6 +41,8 @@ struct Slot {
     hipStream_t stream = nullptr;
     std::vector<float4*> level_out;     // [levels-1] full-size images of the non-final levels
     std::vector<uint32_t*> queue;       // [levels]
+    std::vector<float4*> spec_out;      // speculative mode: traced images of levels 1..S-1 (level 0 traces straight into level_out[0])
+    uint32_t* spec_queue = nullptr;     // speculative mode: merged, level-tagged queue of levels 0..S-1
     uint32_t* d_qctl = nullptr;         // [2*levels]: qcount[l], qhead[l]
     Counters64* d_counters = nullptr;   // [BHRAY_MAX_LEVELS]
     float4* own_out = nullptr;
@@ -221,7 +223,7 @@ int bhray_ladder_from_base(uint32_t base_w, uint32_t base_h, uint32_t m, uint32_
     if (!cfg || levels < 1 || levels > BHRAY_MAX_LEVELS || base_w < 2 || base_h < 2 || m < 2) return BHRAY_E_INVALID;
     uint64_t w = base_w, h = base_h;
     for (uint32_t i = 0; i < levels; i++) {
-        if (w > 65535 || h > 65535) return BHRAY_E_INVALID;          // queue entries pack (y<<16)|x
+        if (w > 32767 || h > 32767) return BHRAY_E_INVALID;          // queue entries pack tag<<30 | y<<15 | x
         cfg->level_w[i] = (uint32_t)w; cfg->level_h[i] = (uint32_t)h;
         w = w * m - (m - 1); h = h * m - (m - 1);                    // mod.rs:203-204
     }
@@ -254,6 +256,8 @@ void bhray_destroy(bhray_ctx* c) {
     for (Slot& S : c->slots) {
         for (auto p : S.level_out) if (p) (void)hipFree(p);
         for (auto p : S.queue) if (p) (void)hipFree(p);
+        for (auto p : S.spec_out) if (p) (void)hipFree(p);
+        if (S.spec_queue) (void)hipFree(S.spec_queue);
         if (S.d_qctl) (void)hipFree(S.d_qctl);
         if (S.d_counters) (void)hipFree(S.d_counters);
         if (S.own_out) (void)hipFree(S.own_out);
@@ -279,7 +283,7 @@ int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
     if (cfg->struct_size != sizeof(bhray_config)) return fail(nullptr, BHRAY_E_INVALID, "bhray_config.struct_size mismatch");
     if (cfg->levels < 1 || cfg->levels > BHRAY_MAX_LEVELS) return fail(nullptr, BHRAY_E_INVALID, "levels out of range");
     for (uint32_t i = 0; i < cfg->levels; i++)
-        if (cfg->level_w[i] < 2 || cfg->level_h[i] < 2 || cfg->level_w[i] > 65535 || cfg->level_h[i] > 65535)
+        if (cfg->level_w[i] < 2 || cfg->level_h[i] < 2 || cfg->level_w[i] > 32767 || cfg->level_h[i] > 32767)
             return fail(nullptr, BHRAY_E_INVALID, "level %u size %ux%u unsupported", i, cfg->level_w[i], cfg->level_h[i]);
     const uint32_t lw = cfg->level_w[cfg->levels - 1], lh = cfg->level_h[cfg->levels - 1];
     if (cfg->frame_w < 1 || cfg->frame_h < 1 || cfg->crop_x + cfg->frame_w > lw || cfg->crop_y + cfg->frame_h > lh)
@@ -287,6 +291,8 @@ int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
     if (cfg->row_world < 1 || cfg->row_rank >= cfg->row_world || cfg->stripe_rows < 1)
         return fail(nullptr, BHRAY_E_INVALID, "bad row partition");
     if (cfg->frames_in_flight > BHRAY_MAX_FRAMES_IN_FLIGHT) return fail(nullptr, BHRAY_E_INVALID, "frames_in_flight > %d", BHRAY_MAX_FRAMES_IN_FLIGHT);
+    if (cfg->speculative_levels == 1 || cfg->speculative_levels > BHRAY_MAX_SPEC_LEVELS || (cfg->speculative_levels && cfg->speculative_levels >= cfg->levels))
+        return fail(nullptr, BHRAY_E_INVALID, "speculative_levels must be 0 or 2..min(%d, levels-1)", BHRAY_MAX_SPEC_LEVELS);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(nullptr, BHRAY_E_NO_DEVICE, "no HIP device visible (libbhray has no CPU path)");
@@ -360,6 +366,21 @@ int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
                 CHK(hipMemset(S.level_out[l], 0xFF, npix * sizeof(float4)));      // NaN: "never rendered"
             }
             if (L.queue_cap) CHK(hipMalloc(&S.queue[l], L.queue_cap * sizeof(uint32_t)));
+        }
+        if (cfg->speculative_levels) {
+            const uint32_t ns = cfg->speculative_levels;
+            S.spec_out.assign(ns, nullptr);
+            size_t cap = 0;
+            for (uint32_t l = 0; l < ns; l++) {
+                const Level& L = c->levels[l];
+                cap += L.queue_cap;
+                if (l > 0) {
+                    const size_t npix = (size_t)L.w * (size_t)L.h;
+                    CHK(hipMalloc(&S.spec_out[l], npix * sizeof(float4)));
+                    CHK(hipMemset(S.spec_out[l], 0xFF, npix * sizeof(float4)));
+                }
+            }
+            if (cap) CHK(hipMalloc(&S.spec_queue, cap * sizeof(uint32_t)));
         }
         if (c->out_bytes) {
             CHK(hipMalloc(&S.own_out, c->out_bytes));
@@ -569,11 +590,11 @@ int bhray_render(bhray_ctx* c) {
     if (c->slots.size() > 1 && bpc > 1) bpc -= 1;
     if (c->bpc_override > 0) bpc = c->bpc_override;
     const int grid = c->num_cus * bpc;
-    for (uint32_t l = 0; l < nl; l++) {
-        Level& Lv = c->levels[l];
-        if (Lv.rows.empty()) continue;
+    SpecLevels none; memset(&none, 0, sizeof none);
+    auto level_params = [&](uint32_t l, LevelParams& L) {
+        const Level& Lv = c->levels[l];
         const bool last = (l == nl - 1);
-        LevelParams L; memset(&L, 0, sizeof L);
+        memset(&L, 0, sizeof L);
         L.w = Lv.w; L.h = Lv.h;
         if (l == 0) { L.pw = 1; L.ph = 1; L.rx = 1.0f; L.ry = 1.0f; L.prev = nullptr; }
         else {
@@ -589,11 +610,48 @@ int bhray_render(bhray_ctx* c) {
             L.out = S.level_out[l]; L.out_pitch = Lv.w; L.out_x0 = 0; L.rowmap = nullptr; L.x0 = 0; L.x1 = Lv.w;
         }
         L.rows = Lv.d_rows; L.nrows = (int)Lv.rows.size();
+    };
+    const uint32_t ns = c->cfg.speculative_levels;
+    uint32_t first_normal = 0;
+    if (ns) {
+        // (1) every needed pixel of levels 0..ns-1 into ONE level-tagged queue, (2) one trace launch over it,
+        // (3) classify levels 1..ns-1 against the traced images.  Queue control words of level 0 serve the merged queue.
+        uint32_t* qcount = S.d_qctl; uint32_t* qhead = qcount + 1;
+        SpecLevels SL; memset(&SL, 0, sizeof SL);
+        SL.n = (int)ns;
+        if (timing) HIPCHK(c, hipEventRecord(fev[0], st));
+        for (uint32_t l = 0; l < ns; l++) {
+            const Level& Lv = c->levels[l];
+            SL.l[l].w = Lv.w; SL.l[l].h = Lv.h; SL.l[l].out = (l == 0) ? S.level_out[0] : S.spec_out[l]; SL.l[l].out_pitch = Lv.w;
+            if (Lv.rows.empty()) continue;
+            LevelParams L; level_params(l, L);
+            L.pw = 1; L.ph = 1; L.prev = nullptr; L.tag = (int)l;                            // "base case": every pixel is traced
+            HIPCHK(c, launch_classify(P, L, S.spec_queue, qcount, nullptr, st));
+        }
+        if (timing) HIPCHK(c, hipEventRecord(fev[1], st));
+        LevelParams L0; level_params(0, L0);
+        HIPCHK(c, launch_trace(P, L0, SL, S.spec_queue, qcount, qhead, count ? S.d_counters : nullptr, c->d_err, grid, st));
+        if (timing) HIPCHK(c, hipEventRecord(fev[2], st));
+        for (uint32_t l = 1; l < ns; l++) {
+            if (timing) HIPCHK(c, hipEventRecord(fev[3 * l + 0], st));
+            if (!c->levels[l].rows.empty()) {
+                LevelParams L; level_params(l, L);
+                L.spec = S.spec_out[l];
+                HIPCHK(c, launch_classify(P, L, nullptr, S.d_qctl + 2 * l, count ? S.d_counters + l : nullptr, st));
+            }
+            if (timing) { HIPCHK(c, hipEventRecord(fev[3 * l + 1], st)); HIPCHK(c, hipEventRecord(fev[3 * l + 2], st)); }
+        }
+        first_normal = ns;
+    }
+    for (uint32_t l = first_normal; l < nl; l++) {
+        Level& Lv = c->levels[l];
+        if (Lv.rows.empty()) continue;
+        LevelParams L; level_params(l, L);
         uint32_t* qcount = S.d_qctl + 2 * l; uint32_t* qhead = qcount + 1;
         if (timing) HIPCHK(c, hipEventRecord(fev[3 * l + 0], st));
         HIPCHK(c, launch_classify(P, L, S.queue[l], qcount, count ? S.d_counters + l : nullptr, st));
         if (timing) HIPCHK(c, hipEventRecord(fev[3 * l + 1], st));
-        HIPCHK(c, launch_trace(P, L, S.queue[l], qcount, qhead, count ? S.d_counters + l : nullptr, c->d_err, grid, st));
+        HIPCHK(c, launch_trace(P, L, none, S.queue[l], qcount, qhead, count ? S.d_counters + l : nullptr, c->d_err, grid, st));
         if (timing) HIPCHK(c, hipEventRecord(fev[3 * l + 2], st));
     }
     HIPCHK(c, hipEventRecord(S.done, st));

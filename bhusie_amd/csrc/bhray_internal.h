@@ -68,14 +68,20 @@ struct LevelParams {
     const int32_t* rows;   // rows to compute (sorted), nrows entries
     int nrows;
     int x0, x1;            // columns to compute
+    int tag;               // speculative mode: level id stored in bits 30-31 of the queue entries
+    const float4* spec;    // speculative mode: already traced pixels of this level; a pixel that needs tracing copies from here
 };
+
+// Speculative tracing of several levels in one launch: per-level geometry and destination, selected by the entry's tag.
+struct SpecLevel { int w, h; float4* out; int out_pitch; };
+struct SpecLevels { int n; SpecLevel l[BHRAY_MAX_SPEC_LEVELS]; };   // n == 0: one level, described by LevelParams
 
 struct Counters64 { unsigned long long v[10]; };   // order = bhray_counters
 
 // launchers (bhray_kernels.hip)
 hipError_t launch_classify(const FrameParams& P, const LevelParams& L, uint32_t* queue, uint32_t* qcount,
                            Counters64* counters, hipStream_t s);
-hipError_t launch_trace(const FrameParams& P, const LevelParams& L, const uint32_t* queue, const uint32_t* qcount,
+hipError_t launch_trace(const FrameParams& P, const LevelParams& L, const SpecLevels& SL, const uint32_t* queue, const uint32_t* qcount,
                         uint32_t* qhead, Counters64* counters, int* err_flag, int grid_blocks, hipStream_t s);
 int trace_blocks_per_cu(int method, int has_models, int count);
 hipError_t launch_sky(const TexDev& sky, const float4* src, uint2* dst_rgba16f, size_t npix, hipStream_t s);

@@ -401,6 +401,10 @@ __global__ __launch_bounds__(256) void classify_kernel(const FrameParams P, cons
                 }
             }
         }
+        if (need_trace && L.spec) {                  // speculative mode: the traced value already exists
+            L.out[out_index(L, x, y)] = L.spec[(size_t)y * (size_t)L.w + (size_t)x];
+            need_trace = false;
+        }
     }
     // wave-ballot compaction: one atomic per wave, lanes keep tile order
     const unsigned long long m = __ballot(need_trace);
@@ -408,7 +412,7 @@ __global__ __launch_bounds__(256) void classify_kernel(const FrameParams P, cons
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(qcount, (uint32_t)__popcll(m));
         base = __builtin_amdgcn_readfirstlane(base);
-        if (need_trace) queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)y << 16) | (uint32_t)x;
+        if (need_trace) queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)L.tag << 30) | ((uint32_t)y << 15) | (uint32_t)x;
     }
     if (COUNT) {
         const unsigned long long mv = __ballot(valid), m0 = __ballot(kind == 0), m1 = __ballot(kind == 1);
@@ -438,7 +442,7 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3 };
 #endif
 
 template <int METHOD, bool MODELS, bool COUNT>
-__global__ __launch_bounds__(256, BHRAY_TRACE_WAVES) void trace_kernel(const FrameParams P, const LevelParams L, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(256, BHRAY_TRACE_WAVES) void trace_kernel(const FrameParams P, const LevelParams L, const SpecLevels SL, const uint32_t* __restrict__ queue,
                                                     const uint32_t* __restrict__ qcount_p, uint32_t* __restrict__ qhead,
                                                     Counters64* __restrict__ counters, int* __restrict__ err_flag) {
     const int lane = threadIdx.x & 63;
@@ -477,12 +481,20 @@ __global__ __launch_bounds__(256, BHRAY_TRACE_WAVES) void trace_kernel(const Fra
                 const uint32_t idx = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
                 if (mode == M_EMPTY && idx < qcount) {
                     pix = queue[idx];
-                    const int px = (int)(pix & 0xffffu), py = (int)(pix >> 16);
+                    const int px = (int)(pix & 0x7fffu), py = (int)((pix >> 15) & 0x7fffu);
+                    // level geometry: the launch's level, or (speculative multi-level launch) the entry's tagged level
+                    int lw = L.w, lh = L.h;
+                    if (SL.n > 0) {
+                        const int lv = (int)(pix >> 30);
+                        lw = SL.l[0].w; lh = SL.l[0].h;
+#pragma unroll
+                        for (int q = 1; q < BHRAY_MAX_SPEC_LEVELS; q++) if (lv == q) { lw = SL.l[q].w; lh = SL.l[q].h; }
+                    }
                     // create_ray, ray.wgsl:269-285 (right/up/fwd_ff hoisted to the host, bit-identical)
-                    const int sm = (L.w - 1) < (L.h - 1) ? (L.w - 1) : (L.h - 1);
+                    const int sm = (lw - 1) < (lh - 1) ? (lw - 1) : (lh - 1);
                     const float increment = 1.0f / (float)sm;
-                    const float posx = (2.0f * ((float)px - (float)(L.w - 1) * 0.5f)) * increment;
-                    const float posy = (2.0f * ((float)py - (float)(L.h - 1) * 0.5f)) * increment;
+                    const float posx = (2.0f * ((float)px - (float)(lw - 1) * 0.5f)) * increment;
+                    const float posy = (2.0f * ((float)py - (float)(lh - 1) * 0.5f)) * increment;
                     rdir = normalize((ld3(P.right) * posx + ld3(P.up) * posy) + ld3(P.fwd_ff));
                     cpos = cam; cdir = rdir; ppos = cam; pdir = rdir;
                     rkpos = cam; rkdir = rdir; rkh = P.step_size;
@@ -571,7 +583,18 @@ __global__ __launch_bounds__(256, BHRAY_TRACE_WAVES) void trace_kernel(const Fra
                 } else {
                     o = make_float4(cdir.x, cdir.y, cdir.z, 0.0f);
                 }
-                L.out[out_index(L, (int)(pix & 0xffffu), (int)(pix >> 16))] = o;
+                {
+                    const int ox = (int)(pix & 0x7fffu), oy = (int)((pix >> 15) & 0x7fffu);
+                    if (SL.n > 0) {
+                        const int lv = (int)(pix >> 30);
+                        float4* dst = SL.l[0].out; int pitch = SL.l[0].out_pitch;
+#pragma unroll
+                        for (int q = 1; q < BHRAY_MAX_SPEC_LEVELS; q++) if (lv == q) { dst = SL.l[q].out; pitch = SL.l[q].out_pitch; }
+                        dst[(size_t)oy * (size_t)pitch + (size_t)ox] = o;
+                    } else {
+                        L.out[out_index(L, ox, oy)] = o;
+                    }
+                }
                 mode = M_EMPTY;
             }
         }
@@ -676,22 +699,22 @@ hipError_t launch_classify(const FrameParams& P, const LevelParams& L, uint32_t*
 }
 
 template <int METHOD, bool MODELS>
-static hipError_t launch_trace_t(const FrameParams& P, const LevelParams& L, const uint32_t* queue, const uint32_t* qcount,
+static hipError_t launch_trace_t(const FrameParams& P, const LevelParams& L, const SpecLevels& SL, const uint32_t* queue, const uint32_t* qcount,
                                  uint32_t* qhead, Counters64* counters, int* err_flag, int grid_blocks, hipStream_t s) {
-    if (counters) hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, true>), dim3(grid_blocks), dim3(256), 0, s, P, L, queue, qcount, qhead, counters, err_flag);
-    else hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, false>), dim3(grid_blocks), dim3(256), 0, s, P, L, queue, qcount, qhead, counters, err_flag);
+    if (counters) hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, true>), dim3(grid_blocks), dim3(256), 0, s, P, L, SL, queue, qcount, qhead, counters, err_flag);
+    else hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, false>), dim3(grid_blocks), dim3(256), 0, s, P, L, SL, queue, qcount, qhead, counters, err_flag);
     return hipGetLastError();
 }
 
-hipError_t launch_trace(const FrameParams& P, const LevelParams& L, const uint32_t* queue, const uint32_t* qcount,
+hipError_t launch_trace(const FrameParams& P, const LevelParams& L, const SpecLevels& SL, const uint32_t* queue, const uint32_t* qcount,
                         uint32_t* qhead, Counters64* counters, int* err_flag, int grid_blocks, hipStream_t s) {
     const bool models = P.model_count > 0;
     if (P.method == 0) {
-        return models ? launch_trace_t<0, true>(P, L, queue, qcount, qhead, counters, err_flag, grid_blocks, s)
-                      : launch_trace_t<0, false>(P, L, queue, qcount, qhead, counters, err_flag, grid_blocks, s);
+        return models ? launch_trace_t<0, true>(P, L, SL, queue, qcount, qhead, counters, err_flag, grid_blocks, s)
+                      : launch_trace_t<0, false>(P, L, SL, queue, qcount, qhead, counters, err_flag, grid_blocks, s);
     }
-    return models ? launch_trace_t<1, true>(P, L, queue, qcount, qhead, counters, err_flag, grid_blocks, s)
-                  : launch_trace_t<1, false>(P, L, queue, qcount, qhead, counters, err_flag, grid_blocks, s);
+    return models ? launch_trace_t<1, true>(P, L, SL, queue, qcount, qhead, counters, err_flag, grid_blocks, s)
+                  : launch_trace_t<1, false>(P, L, SL, queue, qcount, qhead, counters, err_flag, grid_blocks, s);
 }
 
 int trace_blocks_per_cu(int method, int has_models, int count) {

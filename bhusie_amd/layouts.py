@@ -62,7 +62,7 @@ class BhrayConfig(C.Structure):
                 ("level_w", C.c_uint32 * MAX_LEVELS), ("level_h", C.c_uint32 * MAX_LEVELS),
                 ("crop_x", C.c_uint32), ("crop_y", C.c_uint32), ("frame_w", C.c_uint32), ("frame_h", C.c_uint32),
                 ("row_rank", C.c_uint32), ("row_world", C.c_uint32), ("stripe_rows", C.c_uint32), ("flags", C.c_uint32),
-                ("frames_in_flight", C.c_uint32)]
+                ("frames_in_flight", C.c_uint32), ("speculative_levels", C.c_uint32)]
 
     def sizes(self):
         return [(int(self.level_w[i]), int(self.level_h[i])) for i in range(self.levels)]

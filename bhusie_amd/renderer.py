@@ -33,13 +33,14 @@ def ladder_for_frame(frame=(1920, 1080), multiplier=3, levels=4) -> BhrayConfig:
 
 class RayPass:
     def __init__(self, cfg: BhrayConfig, device=0, counters=False, timing=False, row_rank=0, row_world=1, stripe_rows=27,
-                 frames_in_flight=0):
+                 frames_in_flight=0, speculative_levels=0):
         cfg = BhrayConfig.from_buffer_copy(bytes(cfg))
         cfg.struct_size = C.sizeof(BhrayConfig)
         cfg.device = device
         cfg.flags = (F_COUNTERS if counters else 0) | (F_TIMING if timing else 0)
         cfg.row_rank, cfg.row_world, cfg.stripe_rows = row_rank, row_world, stripe_rows
         cfg.frames_in_flight = frames_in_flight
+        cfg.speculative_levels = speculative_levels
         self.cfg = cfg
         h = C.c_void_p()
         check(lib().bhray_create(C.byref(cfg), C.byref(h)))

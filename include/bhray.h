@@ -138,6 +138,7 @@ typedef struct bhray_model_desc {
  * ---------------------------------------------------------------------------------------- */
 #define BHRAY_MAX_LEVELS 8
 #define BHRAY_MAX_FRAMES_IN_FLIGHT 32
+#define BHRAY_MAX_SPEC_LEVELS 4
 #define BHRAY_BVH_STACK  64            /* reference: 19 whole nodes, no overflow check (ray.wgsl:292) */
 
 enum {                                  /* bhray_config.flags */
@@ -150,6 +151,13 @@ enum {                                  /* bhray_config.flags */
  * The delivered frame is the window [crop_x, crop_x+frame_w) × [crop_y, crop_y+frame_h) of
  * the last level; pixels outside it (and coarse pixels no window pixel depends on) are not
  * computed.  With crop = 0 and frame = last level size this is exactly the reference.
+ *
+ * Speculative levels.  The ladder is a chain of dependent launches whose coarse levels are latency-bound (a level
+ * takes as long as its longest ray, however few rays it has).  With speculative_levels = S the pixels of levels
+ * 0..S-1 are all traced in ONE launch before any of them is classified; classification then selects, per pixel, the
+ * copy / the interpolation / the already traced value exactly as the shader would.  Same pixels, fewer dependent
+ * launches, more rays traced (bhray_counters then count the speculative work).  Meant for small per-GPU frames
+ * (row-tiled multi-GPU); off by default.
  *
  * Row partition (multi-GPU row tiling): frame row r belongs to partition
  * (r / stripe_rows) % row_world; this ctx renders only rows of partition row_rank and packs
@@ -165,6 +173,7 @@ typedef struct bhray_config {
     uint32_t row_rank, row_world, stripe_rows;
     uint32_t flags;
     uint32_t frames_in_flight;          /* 0 = default (4); 1 = strictly one frame at a time  */
+    uint32_t speculative_levels;        /* 0 = off; S>=2: trace EVERY needed pixel of levels 0..S-1 in one launch   */
 } bhray_config;
 
 /* Reference ladder rule `r ← r·m − (m−1)` (mod.rs:177-205): fills level_w/h[0..levels).    */

@@ -242,3 +242,36 @@ def test_sky_resolve_pass_bit_exact():
     rp2 = run_gpu(cfg, *u, tex, row_rank=1, row_world=2, stripe_rows=9)
     rp2.resolve_sky()
     assert np.array_equal(rp2.read_sky().view(np.uint16), want.view(np.uint16)[rp2.local_rows()])
+
+
+@pytest.mark.parametrize("method,spec", [(1, 2), (1, 3), (0, 3)])
+def test_speculative_levels_give_identical_frames(method, spec):
+    """bhray_config.speculative_levels: levels 0..S-1 traced in one launch, then classified — every level image and the
+    frame must equal the normal ladder's bit for bit (and hence the oracle's within the usual bar)."""
+    tex = T.textures()
+    u = T.uniforms(integration_method=method)
+    cfg = B.ladder_from_base((24, 14), 3, 4)                # 24x14 -> 70x40 -> 208x118 -> 622x352
+    normal = run_gpu(cfg, *u, tex)
+    fast = run_gpu(cfg, *u, tex, speculative_levels=spec, counters=True)
+    for l in range(4):
+        assert np.array_equal(normal.read_level(l), fast.read_level(l), equal_nan=True), f"level {l}"
+    assert np.array_equal(normal.read_hdr(), fast.read_hdr())
+    want = O.render_ladder(T.oracle_scene(*u, tex), cfg.sizes())
+    T.assert_parity(fast.read_hdr(), want[-1], "speculative frame")
+    c = fast.counters()
+    assert c["traced"] >= sum(w * h for w, h in cfg.sizes()[:spec])          # all pixels of the speculated levels were traced
+
+
+def test_speculative_levels_with_crop_rows_and_mesh(tmp_path):
+    tex = T.textures()
+    model = _mesh_model(tmp_path, 12, 16)
+    cam = B.Camera(position=(0.0, 0.0, -40.0), forward=(-0.11914522, 0.0, 0.99287683), fov=1.2)
+    u = T.uniforms(camera=cam, integration_method=1, model_count=1)
+    cfg = B.ladder_for_frame((200, 110), 3, 3)
+    full = run_gpu(cfg, *u, tex, model=model).read_hdr()
+    for rank in range(2):
+        rp = run_gpu(cfg, *u, tex, model=model, row_rank=rank, row_world=2, stripe_rows=9, speculative_levels=2, frames_in_flight=2)
+        rp.render(); rp.render()                              # slots are reused: still the same bytes
+        assert np.array_equal(rp.read_hdr(), full[rp.local_rows()])
+    with pytest.raises(B.BhrayError):
+        B.RayPass(cfg, device=0, speculative_levels=3)         # must leave at least the last level to the normal path
