@@ -837,9 +837,9 @@ int bhray_get_timing(bhray_ctx* c, bhray_timing* out) {
             float a = 0, b = 0;
             HIPCHK(c, hipEventElapsedTime(&a, ev[3 * l], ev[3 * l + 1]));
             HIPCHK(c, hipEventElapsedTime(&b, ev[3 * l + 1], ev[3 * l + 2]));
-            out->classify_ms += a; out->trace_ms += b;
-            out->level_classify_ms[l] += a; out->level_trace_ms[l] += b;
-            out->classify_launches++; out->trace_launches++;
+            const bool spec_classified = c->cfg.speculative_levels && l >= 1 && l < c->cfg.speculative_levels;   // no trace launch of its own
+            out->classify_ms += a; out->level_classify_ms[l] += a; out->classify_launches++;
+            if (!spec_classified) { out->trace_ms += b; out->level_trace_ms[l] += b; out->trace_launches++; }
             if (!first) first = ev[3 * l];
             last = ev[3 * l + 2];
         }
