@@ -442,7 +442,7 @@ int bhray_upload_model(bhray_ctx* c, uint32_t mi, const bhray_model_desc* d) {
             return fail(c, BHRAY_E_INVALID, "triangle %d has an index out of range", i);
         if (d->bvh_lookup[i] < 0 || d->bvh_lookup[i] >= d->triangle_count) return fail(c, BHRAY_E_INVALID, "bvh_lookup[%d] out of range", i);
     }
-    for (int i = 0; i < d->node_count; i++) {
+    for (int i = 0; i < d->node_count && d->triangle_count > 0; i++) {     // an empty model's root is (0 children, 0 objects): never traversed
         const bhray_node& n = d->nodes[i];
         if (n.obj_count < 0) return fail(c, BHRAY_E_INVALID, "node %d: negative obj_count", i);
         if (n.obj_count == 0) {
@@ -687,10 +687,10 @@ int bhray_local_row_index(const bhray_ctx* c, uint32_t i, uint32_t* frame_row) {
 int bhray_read_hdr(bhray_ctx* c, float* dst, size_t pitch) {
     if (!c) return BHRAY_E_INVALID;
     const size_t rowb = (size_t)c->cfg.frame_w * sizeof(float4);
+    if (c->local_rows.empty()) return bhray_sync(c);              // this partition owns no rows: nothing to copy
     if (!dst || pitch < rowb) return fail(c, BHRAY_E_INVALID, "bad destination / pitch");
     int rc = bhray_sync(c);
     if (rc) return rc;
-    if (c->local_rows.empty()) return BHRAY_OK;
     HIPCHK(c, hipMemcpy2D(dst, pitch, c->slots[(size_t)c->last_slot].out, rowb, rowb, c->local_rows.size(), hipMemcpyDeviceToHost));
     return BHRAY_OK;
 }
@@ -754,6 +754,7 @@ int bhray_resolve_sky(bhray_ctx* c) {
 int bhray_read_sky(bhray_ctx* c, uint16_t* dst, size_t pitch) {
     if (!c) return BHRAY_E_INVALID;
     const size_t rowb = (size_t)c->cfg.frame_w * sizeof(uint2);
+    if (c->local_rows.empty()) return bhray_sync(c);
     if (!dst || pitch < rowb) return fail(c, BHRAY_E_INVALID, "bad destination / pitch");
     Slot& S = c->slots[(size_t)c->last_slot];
     if (!S.sky_out) return fail(c, BHRAY_E_STATE, "bhray_resolve_sky has not been called for this frame");

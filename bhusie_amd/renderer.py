@@ -104,7 +104,7 @@ class RayPass:
     def read_hdr(self) -> np.ndarray:
         n = int(lib().bhray_local_rows(self._h))
         out = np.empty((n, int(self.cfg.frame_w), 4), dtype=np.float32)
-        check(lib().bhray_read_hdr(self._h, out.ctypes.data, out.strides[0]), self._h)
+        check(lib().bhray_read_hdr(self._h, out.ctypes.data, int(self.cfg.frame_w) * 16), self._h)
         return out
 
     def read_level(self, level: int) -> np.ndarray:
@@ -120,7 +120,7 @@ class RayPass:
     def read_sky(self) -> np.ndarray:
         n = int(lib().bhray_local_rows(self._h))
         out = np.empty((n, int(self.cfg.frame_w), 4), dtype=np.float16)
-        check(lib().bhray_read_sky(self._h, out.ctypes.data, out.strides[0]), self._h)
+        check(lib().bhray_read_sky(self._h, out.ctypes.data, int(self.cfg.frame_w) * 8), self._h)
         return out
 
     def device_ptr(self):

@@ -1,0 +1,144 @@
+"""-m gpu: edge cases and a seeded fuzz sweep of the uniform space the reference's UI exposes
+(src/ui/render_settings.rs, black_hole_settings.rs, camera_settings.rs — SURVEY.md §5), HIP vs oracle.
+
+NaN handling is part of the contract (compare-select clamp/min/max): where the shader's own arithmetic
+produces NaN (e.g. pow of a negative disk density when the hole is off-origin, ray.wgsl:619-623; feather 0 -> 0/0,
+ray.wgsl:548) both sides must produce NaN in the same pixels."""
+import numpy as np
+import pytest
+
+import bhusie_amd as B
+from oracle import oracle as O
+from tests import common as T
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_frame(cfg, u, tex, **kw):
+    rp = B.RayPass(cfg, device=0, **kw)
+    rp.set_textures(*tex)
+    rp.set_uniforms(*u)
+    rp.render()
+    return rp
+
+
+def check(got, want, what):
+    assert got.shape == want.shape
+    gn, wn = np.isnan(got), np.isnan(want)
+    assert np.array_equal(gn, wn), f"{what}: NaN pixels differ ({int(gn.sum())} vs {int(wn.sum())})"
+    ok = ~wn.any(axis=-1)
+    gi, wi = np.isinf(got[ok]), np.isinf(want[ok])
+    assert np.array_equal(gi, wi) and np.array_equal(got[ok][gi], want[ok][wi]), f"{what}: infinities differ"
+    fin = ok & np.isfinite(want).all(axis=-1)
+    assert np.array_equal(got[..., 3][fin], want[..., 3][fin]), f"{what}: classes differ"
+    e = T.rel_err(got[fin], want[fin])
+    assert float(e.max(initial=0.0)) <= T.REL_TOL, f"{what}: max rel err {float(e.max()):.3g}"
+    d = fin & (want[..., 3] == 0)
+    assert np.array_equal(got[d], want[d]), f"{what}: direction pixels not bit-identical"
+
+
+def test_tiny_and_ragged_frames():
+    tex = T.textures()
+    for base, levels, method in (((2, 2), 1, 0), ((2, 3), 2, 1), ((5, 2), 3, 1), ((9, 7), 2, 0), ((3, 17), 2, 1)):
+        u = T.uniforms(integration_method=method)
+        cfg = B.ladder_from_base(base, 3, levels)
+        rp = gpu_frame(cfg, u, tex)
+        want = O.render_ladder(T.oracle_scene(*u, tex), cfg.sizes())
+        check(rp.read_hdr(), want[-1], f"base {base} x{levels}")
+
+
+def test_single_pixel_window_and_empty_partitions():
+    tex = T.textures()
+    u = T.uniforms(integration_method=1)
+    cfg = B.ladder_from_base((8, 6), 3, 3)                       # 8x6 -> 22x16 -> 64x46
+    want = O.render_ladder(T.oracle_scene(*u, tex), cfg.sizes())[-1]
+    for (cx, cy, fw, fh) in ((0, 0, 1, 1), (63, 45, 1, 1), (10, 7, 5, 1), (31, 0, 1, 46)):
+        c = B.BhrayConfig.from_buffer_copy(bytes(cfg))
+        c.crop_x, c.crop_y, c.frame_w, c.frame_h = cx, cy, fw, fh
+        got = gpu_frame(c, u, tex).read_hdr()
+        check(got, want[cy:cy + fh, cx:cx + fw], f"window {cx},{cy} {fw}x{fh}")
+    # more ranks than stripes: some ranks own no rows and must render nothing without error
+    rows_seen = []
+    for rank in range(4):
+        rp = gpu_frame(cfg, u, tex, row_rank=rank, row_world=4, stripe_rows=27)
+        rows = rp.local_rows()
+        rows_seen += rows.tolist()
+        out = rp.read_hdr()
+        assert out.shape == (len(rows), 64, 4)
+        if len(rows):
+            check(out, want[rows], f"rank {rank}")
+    assert sorted(rows_seen) == list(range(46))
+
+
+def test_iteration_limit_classes():
+    """`hit || i <= 5` (ray.wgsl:583): tiny iteration limits turn escaping rays into colour pixels."""
+    tex = T.textures()
+    cfg = B.ladder_from_base((16, 9), 3, 2)
+    for mi in (0, 1, 5, 6, 7, 40):
+        for method in (0, 1):
+            u = T.uniforms(integration_method=method, max_iterations=mi)
+            want = O.render_ladder(T.oracle_scene(*u, tex), cfg.sizes())
+            check(gpu_frame(cfg, u, tex).read_hdr(), want[-1], f"max_iterations {mi} method {method}")
+            if mi <= 5:
+                assert np.all(want[-1][..., 3] == 1.0)
+
+
+def test_degenerate_uniforms_propagate_nan_identically():
+    tex = T.textures()
+    cfg = B.ladder_from_base((24, 14), 3, 2)
+    cases = {
+        "hole off origin (negative density -> pow NaN, ray.wgsl:619-623)": dict(bh=B.BlackHole(position=(4.0, -2.0, 1.0))),
+        "feather 0 (0/0 in the exit blend, ray.wgsl:546-548)": dict(bh=B.BlackHole(feather_amount=0.0)),
+        "inner > outer disk": dict(bh=B.BlackHole(accretion_disk_inner=8.0, accretion_disk_outer=4.0)),
+        "sphere smaller than the disk": dict(bh=B.BlackHole(relativity_sphere_radius=6.0), cam=B.Camera(position=(0.0, 1.0, -5.0))),
+        "camera on the horizon side": dict(cam=B.Camera(position=(0.0, 0.0, -1.5))),
+        "zero forward vector": dict(cam=B.Camera(forward=(0.0, 0.0, 0.0))),
+        "forward parallel to plane_up": dict(cam=B.Camera(forward=(0.0, -1.0, 0.0))),
+        "large time (range reduction of sin/cos)": dict(time=7321.25),
+        "step size limits of the UI": dict(step_size=1.0),
+        "fine steps": dict(step_size=0.005, max_iterations=300),
+    }
+    for name, kw in cases.items():
+        for method in (0, 1):
+            det = {k: v for k, v in kw.items() if k not in ("bh", "cam")}
+            u = T.uniforms(camera=kw.get("cam"), black_hole=kw.get("bh"), integration_method=method, **det)
+            want = O.render_ladder(T.oracle_scene(*u, tex), cfg.sizes())
+            check(gpu_frame(cfg, u, tex).read_hdr(), want[-1], f"{name} / method {method}")
+
+
+def test_one_texel_textures_and_empty_model():
+    tex = tuple(np.full((1, 1, 4), v, dtype=np.uint8) for v in (200, 128, 64))
+    u = T.uniforms(integration_method=1, model_count=1)
+    cfg = B.ladder_from_base((16, 9), 3, 2)
+    rp = B.RayPass(cfg, device=0)
+    rp.set_textures(*tex)
+    m = B.Model(); m.build_bvh()                                  # no triangles
+    rp.upload_model(m)
+    rp.set_uniforms(*u)
+    rp.render()
+    want = O.render_ladder(T.oracle_scene(*T.uniforms(integration_method=1, model_count=0), tex), cfg.sizes())
+    check(rp.read_hdr(), want[-1], "1x1 textures, empty model")
+
+
+def test_fuzz_uniform_space():
+    """40 seeded random points of the UI's parameter space (ranges from src/ui/*_settings.rs)."""
+    tex = T.textures()
+    rng = np.random.default_rng(20260928)
+    cfg = B.ladder_from_base((20, 12), 3, 2)
+    for k in range(40):
+        pos = rng.normal(size=3) * np.array([6.0, 4.0, 6.0]) + np.array([0.0, 0.0, -16.0])
+        fwd = -pos + rng.normal(size=3) * 4.0
+        fwd = fwd / np.linalg.norm(fwd)
+        cam = B.Camera(position=tuple(pos), forward=tuple(fwd), fov=float(rng.uniform(0.3, 2.2)))
+        inner = float(rng.uniform(1.2, 4.0))
+        bh = B.BlackHole(accretion_disk_rotation=tuple(rng.uniform(-1.5, 1.5, size=3)), accretion_disk_inner=inner,
+                         accretion_disk_outer=inner + float(rng.uniform(1.0, 12.0)), rotation_speed=float(rng.uniform(0, 10)),
+                         relativity_sphere_radius=float(rng.uniform(8.0, 40.0)), show_disk_texture=int(rng.integers(0, 2)),
+                         show_red_shift=int(rng.integers(0, 2)), feather_amount=float(rng.uniform(0.05, 1.0)))
+        method = int(rng.integers(0, 2))
+        u = T.uniforms(camera=cam, black_hole=bh, integration_method=method, step_size=float(rng.uniform(0.05, 0.6)),
+                       max_iterations=int(rng.integers(50, 900)), angle_division_threshold=float(rng.uniform(0.0, 0.2)),
+                       time=float(rng.uniform(0, 100)))
+        want = O.render_ladder(T.oracle_scene(*u, tex), cfg.sizes())
+        rp = gpu_frame(cfg, u, tex, speculative_levels=0)
+        check(rp.read_hdr(), want[-1], f"fuzz case {k} (method {method})")
