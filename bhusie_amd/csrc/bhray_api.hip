@@ -583,11 +583,11 @@ int bhray_render(bhray_ctx* c) {
     hipEvent_t* fev = timing ? &c->events[(size_t)(c->frame_counter % BHRAY_TIMING_RING) * (nl * 3 + 2)] : nullptr;
     S.frame_id = c->frame_counter;
     if (timing) c->sky_recorded[c->frame_counter % BHRAY_TIMING_RING] = 0;
-    // Persistent trace grid: (resident blocks per CU) x CUs.  With several frames in flight one block
-    // slot per CU is left free, so that the small (latency-bound) levels of the next frame can run
-    // beside the large last level of this one instead of queueing behind it.
+    // Persistent trace grid: (resident blocks per CU) x CUs.  With several frames in flight each launch takes only
+    // half of the block slots: the kernels of the other frames fill the rest, and a wave of a half-size grid pulls
+    // more than one load of rays, so the refill keeps its lanes busy (+4 % at 16 slots).
     int bpc = trace_blocks_per_cu(P.method, P.model_count > 0, count);
-    if (c->slots.size() > 1 && bpc > 1) bpc -= 1;
+    if (c->slots.size() > 1 && bpc > 1) bpc = bpc / 2 > 1 ? bpc / 2 : 1;     // measured: 2 of 4 blocks per CU is best at 8-16 slots
     if (c->bpc_override > 0) bpc = c->bpc_override;
     const int grid = c->num_cus * bpc;
     SpecLevels none; memset(&none, 0, sizeof none);
