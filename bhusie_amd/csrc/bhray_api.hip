@@ -142,6 +142,7 @@ void derive_frame(const bhray_ctx* c, FrameParams& P) {
     P.up[0] = up.x; P.up[1] = up.y; P.up[2] = up.z;
     P.fwd_ff[0] = fwd_ff.x; P.fwd_ff[1] = fwd_ff.y; P.fwd_ff[2] = fwd_ff.z;
     P.ray_distance = distance(cpos, bpos);
+    P.ray_distance_f = fdistance(cpos, bpos);
     P.relativity0 = P.ray_distance < bh.relativity_sphere_radius ? 1 : 0;
     P.bh[0] = bpos.x; P.bh[1] = bpos.y; P.bh[2] = bpos.z;
     memcpy(P.bn, bh.normal, 12);

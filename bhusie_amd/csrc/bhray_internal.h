@@ -35,6 +35,7 @@ struct FrameParams {
     float up[3];           // normalize(cross(forward, right))
     float fwd_ff[3];       // forward * (1 / tan(fov/2))
     float ray_distance;    // distance(camera.position, black_hole.position)  (ray.wgsl:511,555)
+    float ray_distance_f;  // the same with the integrator's fused dot (N7): `dist` of a ray's first step
     int relativity0;       // ray_distance < relativity_radius                (ray.wgsl:488)
     // black hole (ray.wgsl:112-123)
     float bh[3];

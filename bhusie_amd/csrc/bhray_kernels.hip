@@ -301,39 +301,39 @@ __device__ constexpr float DB1 = KF(37.0 / 378.0 - 2825.0 / 27648.0), DB2 = KF(0
                            DB3 = KF(250.0 / 621.0 - 18575.0 / 48384.0), DB4 = KF(125.0 / 594.0 - 13525.0 / 55296.0),
                            DB5 = KF(0.0 - 277.0 / 14336.0), DB6 = KF(512.0 / 1771.0 - 1.0 / 4.0);
 
-// next_ray_rk, ray.wgsl:405-465.  The retry loop (425-451) cannot change h and is run once.
-// `dist` = length(pos - bpos), carried from the previous step's exit test (same operands, same value).
+// next_ray_rk, ray.wgsl:405-465.  The retry loop (425-451) cannot change h and is run once.  N7: fused arithmetic.
+// `dist` = flength(pos - bpos), carried from the previous step's exit test (same operands, same value).
 __device__ __forceinline__ void next_ray_rk(F3 bpos, F3& pos, F3& dir, float& h_io, float dist) {
     const F3 p0 = pos, d0 = dir;
-    const float lc = length(cross(p0, d0));
+    const float lc = flength(fcross(p0, d0));
     const float h2 = lc * lc;
     const float c = -1.5f * h2;
     const float r = 1.0f / pow5(dist);
     const float h = h_io;
     const F3 k1 = f_acc(p0, bpos, c, r);
-    const F3 k2 = f_acc(p0 + (k1 * A21) * h, bpos, c, r);
-    const F3 k3 = f_acc(p0 + (k1 * A31 + k2 * A32) * h, bpos, c, r);
-    const F3 k4 = f_acc(p0 + ((k1 * A41 + k2 * A42) + k2 * A43) * h, bpos, c, r);
-    const F3 k5 = f_acc(p0 + (((k1 * A51 + k2 * A52) + k3 * A53) + k4 * A54) * h, bpos, c, r);
-    const F3 k6 = f_acc(p0 + ((((k1 * A61 + k2 * A62) + k3 * A63) + k4 * A64) + k5 * A65) * h, bpos, c, r);
-    const F3 es = ((((k1 * DB1 + k2 * DB2) + k3 * DB3) + k4 * DB4) + k5 * DB5) + k6 * DB6;
+    const F3 k2 = f_acc(fmadd3(k1 * A21, h, p0), bpos, c, r);
+    const F3 k3 = f_acc(fmadd3(lin2(k1, A31, k2, A32), h, p0), bpos, c, r);
+    const F3 k4 = f_acc(fmadd3(fmadd3(k2, A43, lin2(k1, A41, k2, A42)), h, p0), bpos, c, r);
+    const F3 k5 = f_acc(fmadd3(fmadd3(k4, A54, fmadd3(k3, A53, lin2(k1, A51, k2, A52))), h, p0), bpos, c, r);
+    const F3 k6 = f_acc(fmadd3(fmadd3(k5, A65, fmadd3(k4, A64, fmadd3(k3, A63, lin2(k1, A61, k2, A62)))), h, p0), bpos, c, r);
+    const F3 es = fmadd3(k6, DB6, fmadd3(k5, DB5, fmadd3(k4, DB4, fmadd3(k3, DB3, lin2(k1, DB1, k2, DB2)))));
     const F3 e = es * h;
     const float e_max = max_(max_(fabsf(e.x), fabsf(e.y)), fabsf(e.z));
-    const F3 ds = ((((k1 * BA1 + k2 * BA2) + k3 * BA3) + k4 * BA4) + k5 * BA5) + k6 * BA6;
-    dir = normalize(d0 + ds * h);
-    pos = p0 + d0 * h;
+    const F3 ds = fmadd3(k6, BA6, fmadd3(k5, BA5, fmadd3(k4, BA4, fmadd3(k3, BA3, lin2(k1, BA1, k2, BA2)))));
+    dir = fnormalize(fmadd3(ds, h, d0));
+    pos = fmadd3(d0, h, p0);
     if (e_max > 0.00002f) h_io = h * (0.9f * bh_pow_m001(e_max));
     else h_io = h * 1.0001f;
 }
 
-// next_ray_euler, ray.wgsl:467-480.
+// next_ray_euler, ray.wgsl:467-480 (N7).
 __device__ __forceinline__ void next_ray_euler(F3 bpos, F3& pos, F3& dir, float step, float dist) {
-    const float lc = length(cross(pos, dir));
+    const float lc = flength(fcross(pos, dir));
     const float h2 = lc * lc;
     const float c = -1.5f * h2;
     const float r = 1.0f / pow5(dist);
-    dir = normalize(dir + f_acc(pos, bpos, c, r) * step);
-    pos = pos + dir * step;
+    dir = fnormalize(fmadd3(f_acc(pos, bpos, c, r), step, dir));
+    pos = fmadd3(dir, step, pos);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256, BHRAY_TRACE_WAVES) void trace_kernel(const Fra
     float rkh = 0.0f;
     F3 color = f3(0, 0, 0);
     float amount = 1.0f, step = P.step_size, closest = P.ray_distance;
-    float dist_c = P.ray_distance;        // length(integrator position - bpos), carried between steps
+    float dist_c = P.ray_distance_f;      // flength(integrator position - bpos) (N7), carried between steps
     int it = 0;
     bool hit = false;
     bool exhausted = false;
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256, BHRAY_TRACE_WAVES) void trace_kernel(const Fra
                     cpos = cam; cdir = rdir; ppos = cam; pdir = rdir;
                     rkpos = cam; rkdir = rdir; rkh = P.step_size;
                     color = f3(0, 0, 0); amount = 1.0f; step = P.step_size; closest = P.ray_distance;
-                    dist_c = P.ray_distance;
+                    dist_c = P.ray_distance_f;
                     it = 0; hit = false;
                     mode = P.relativity0 ? M_REL : M_FLAT;
                     if (COUNT) cnt[3]++;
@@ -545,11 +545,11 @@ __global__ __launch_bounds__(256, BHRAY_TRACE_WAVES) void trace_kernel(const Fra
                         mode = M_FINISH;                                   // break (no increment)
                     } else {
                         bool chit = false; Hit crs = rs;
-                        if (hs && ths < rs.t) { cpos = cpos + cdir * ths; mode = M_REL; if (METHOD == 0) dist_c = distance(cpos, bpos); }
+                        if (hs && ths < rs.t) { cpos = cpos + cdir * ths; mode = M_REL; if (METHOD == 0) dist_c = fdistance(cpos, bpos); }
                         else { chit = rs.hit; }
                         if (chit) {
                             cpos = cpos + pdir * crs.t;
-                            if (METHOD == 0) dist_c = distance(cpos, bpos);
+                            if (METHOD == 0) dist_c = fdistance(cpos, bpos);
                             const F3 cc = f3(clamp_(crs.color.x, 0.0f, 1.0f), clamp_(crs.color.y, 0.0f, 1.0f), clamp_(crs.color.z, 0.0f, 1.0f));
                             color = color + cc * (amount * crs.opacity);
                             amount *= 1.0f - crs.opacity;
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256, BHRAY_TRACE_WAVES) void trace_kernel(const Fra
                         next_ray_rk(bpos, rkpos, rkdir, rkh, dist_c);
                         cpos = rkpos; cdir = rkdir; step = rkh;
                     }
-                    const float cd = distance(cpos, bpos);
+                    const float cd = fdistance(cpos, bpos);        // N7: the integrator's distance (ray.wgsl:533)
                     dist_c = cd;                       // Euler: cpos is the integrator position; RK: cpos == rkpos here
                     if (cd < closest) closest = cd;
                     pdir = cdir;
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(256, BHRAY_TRACE_WAVES) void trace_kernel(const Fra
                     }
                     if (crs.hit) {
                         cpos = cpos + pdir * crs.t;
-                        if (METHOD == 0) dist_c = distance(cpos, bpos);
+                        if (METHOD == 0) dist_c = fdistance(cpos, bpos);
                         const F3 cc = f3(clamp_(crs.color.x, 0.0f, 1.0f), clamp_(crs.color.y, 0.0f, 1.0f), clamp_(crs.color.z, 0.0f, 1.0f));
                         color = color + cc * (amount * crs.opacity);
                         amount *= 1.0f - crs.opacity;

@@ -3,7 +3,8 @@
 // WGSL operator of /root/reference/src/renderer/shaders/ray.wgsl is one IEEE binary32 operation
 // in source order (the translation unit is compiled with -ffp-contract=off), with
 //   N1 dot = (x*x + y*y) + z*z, N2 vector/scalar = vector * (1/scalar), N3 small integer powers
-//   by multiplication, N5 mix(a,b,t) = a*(1-t) + b*t and compare-select min/max.
+//   by multiplication, N5 mix(a,b,t) = a*(1-t) + b*t and compare-select min/max, and N7: the integrator
+//   alone uses explicit fused multiply-adds (fdot, fcross, fmadd3) — the only FMAs in the product.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,6 +35,14 @@ BH_HD float clamp_(float x, float lo, float hi) { return min_(max_(x, lo), hi); 
 BH_HD float mix_(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 BH_HD F3 mix3(F3 a, F3 b, float t) { return f3(mix_(a.x, b.x, t), mix_(a.y, b.y, t), mix_(a.z, b.z, t)); }
 BH_HD F3 ld3(const float* p) { return f3(p[0], p[1], p[2]); }
+// N7: fused forms, used ONLY by the integrator (f, next_ray_euler, next_ray_rk, exit distance)
+BH_HD float fdot(F3 a, F3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+BH_HD float flength(F3 a) { return sqrtf(fdot(a, a)); }
+BH_HD F3 fnormalize(F3 a) { return div_s(a, flength(a)); }
+BH_HD float fdistance(F3 a, F3 b) { return flength(a - b); }
+BH_HD F3 fcross(F3 a, F3 b) { return f3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))); }
+BH_HD F3 fmadd3(F3 w, float s, F3 v) { return f3(fmaf(w.x, s, v.x), fmaf(w.y, s, v.y), fmaf(w.z, s, v.z)); }   // v + w*s
+BH_HD F3 lin2(F3 a, float ca, F3 b, float cb) { return fmadd3(b, cb, a * ca); }                                 // a*ca + b*cb
 BH_HD uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 BH_HD float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 

@@ -45,6 +45,54 @@ def vcross(a, b):
                      a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]], axis=-1)
 
 
+# ------------------------------------------------------------------ N7: fused multiply-add for the integrator
+def fma32(a, b, c):
+    """round_to_binary32(a*b + c) with ONE rounding, for binary32 inputs.  a*b is exact in binary64 (48-bit significand);
+    the binary64 sum is rounded once more when cast to binary32, which can only go wrong when the binary64 sum sits exactly
+    on a binary32 midpoint while the exact sum does not: TwoSum recovers the lost part and the value is nudged off the tie."""
+    a64 = np.asarray(a, dtype=np.float32).astype(np.float64)
+    b64 = np.asarray(b, dtype=np.float32).astype(np.float64)
+    c64 = np.asarray(c, dtype=np.float32).astype(np.float64)
+    with np.errstate(invalid="ignore", over="ignore"):
+        p = a64 * b64
+        s = p + c64
+        bb = s - p
+        err = (p - (s - bb)) + (c64 - bb)                     # exact: p + c = s + err
+        a64, b64, c64 = np.broadcast_arrays(a64, b64, c64)
+        s = np.array(s, dtype=np.float64)
+        bits = s.view(np.uint64)
+        tie = ((bits & np.uint64(0x1FFFFFFF)) == np.uint64(0x10000000)) & (err != 0) & np.isfinite(s)
+        if np.any(tie):
+            s = np.where(tie, np.nextafter(s, np.where(err > 0, np.inf, -np.inf)), s)
+        return s.astype(np.float32)
+
+
+def fdot(a, b):
+    return fma32(a[..., 2], b[..., 2], fma32(a[..., 1], b[..., 1], a[..., 0] * b[..., 0]))
+
+
+def flen(a):
+    return np.sqrt(fdot(a, a))
+
+
+def fnorm(a):
+    return vdivs(a, flen(a))
+
+
+def fcross(a, b):
+    return np.stack([fma32(a[..., 1], b[..., 2], -(a[..., 2] * b[..., 1])),
+                     fma32(a[..., 2], b[..., 0], -(a[..., 0] * b[..., 2])),
+                     fma32(a[..., 0], b[..., 1], -(a[..., 1] * b[..., 0]))], axis=-1)
+
+
+def fmadd3(w, s_, v):
+    """v + w*s per component, fused; s_ scalar or per-ray array"""
+    s_ = np.asarray(s_, dtype=np.float32)
+    if s_.ndim == 1:
+        s_ = s_[:, None]
+    return fma32(w, s_, v)
+
+
 def fmin(a, b):
     return np.where(b < a, b, a)
 
@@ -467,31 +515,40 @@ def f_acc(S, p, h2, dist):
 
 
 def next_ray_euler(S, pos, dirn, step):
-    lc = vlen(vcross(pos, dirn)); h2 = lc * lc
-    dist = vlen(pos - S.bh_pos)
-    nd = vnorm(dirn + f_acc(S, pos, h2, dist) * step[:, None])
-    npos = pos + nd * step[:, None]
+    lc = flen(fcross(pos, dirn)); h2 = lc * lc
+    dist = flen(pos - S.bh_pos)
+    nd = fnorm(fmadd3(f_acc(S, pos, h2, dist), step, dirn))
+    npos = fmadd3(nd, step, pos)
     return npos, nd
 
 
+def _lin(terms):
+    """sum of k_i * c_i, left to right: first product rounded, the rest fused (N7)"""
+    k, c = terms[0]
+    acc = k * c
+    for k, c in terms[1:]:
+        acc = fma32(k, c, acc)
+    return acc
+
+
 def next_ray_rk(S, pos, dirn, h):
-    dist = vlen(pos - S.bh_pos)
-    lc = vlen(vcross(pos, dirn)); h2 = lc * lc
-    H = h[:, None]
+    dist = flen(pos - S.bh_pos)
+    lc = flen(fcross(pos, dirn)); h2 = lc * lc
     k1 = f_acc(S, pos, h2, dist)
-    k2 = f_acc(S, pos + (k1 * A21) * H, h2, dist)
-    k3 = f_acc(S, pos + (k1 * A31 + k2 * A32) * H, h2, dist)
-    k4 = f_acc(S, pos + ((k1 * A41 + k2 * A42) + k2 * A43) * H, h2, dist)           # a_43*k_2 (sic, ray.wgsl:431)
-    k5 = f_acc(S, pos + (((k1 * A51 + k2 * A52) + k3 * A53) + k4 * A54) * H, h2, dist)
-    k6 = f_acc(S, pos + ((((k1 * A61 + k2 * A62) + k3 * A63) + k4 * A64) + k5 * A65) * H, h2, dist)
-    es = ((((k1 * DB[0] + k2 * DB[1]) + k3 * DB[2]) + k4 * DB[3]) + k5 * DB[4]) + k6 * DB[5]
-    e = es * H
+    k2 = f_acc(S, fmadd3(k1 * A21, h, pos), h2, dist)
+    k3 = f_acc(S, fmadd3(_lin([(k1, A31), (k2, A32)]), h, pos), h2, dist)
+    k4 = f_acc(S, fmadd3(_lin([(k1, A41), (k2, A42), (k2, A43)]), h, pos), h2, dist)          # a_43*k_2 (sic, ray.wgsl:431)
+    k5 = f_acc(S, fmadd3(_lin([(k1, A51), (k2, A52), (k3, A53), (k4, A54)]), h, pos), h2, dist)
+    k6 = f_acc(S, fmadd3(_lin([(k1, A61), (k2, A62), (k3, A63), (k4, A64), (k5, A65)]), h, pos), h2, dist)
+    ks = (k1, k2, k3, k4, k5, k6)
+    es = _lin(list(zip(ks, DB)))
+    e = es * h[:, None]
     ea = np.abs(e)
     e_max = fmax(fmax(ea[:, 0], ea[:, 1]), ea[:, 2])
     # retry loop (ray.wgsl:425-451) cannot change h: run once
-    ds = ((((k1 * BA[0] + k2 * BA[1]) + k3 * BA[2]) + k4 * BA[3]) + k5 * BA[4]) + k6 * BA[5]
-    nd = vnorm(dirn + ds * H)
-    npos = pos + dirn * H                                    # old direction (ray.wgsl:456)
+    ds = _lin(list(zip(ks, BA)))
+    nd = fnorm(fmadd3(ds, h, dirn))
+    npos = fmadd3(dirn, h, pos)                              # old direction (ray.wgsl:456)
     with np.errstate(invalid="ignore"):
         grow = e_max > f32(0.00002)
     nh = np.where(grow, h * (f32(0.9) * bh_pow_m001(np.where(grow, e_max, f32(1.0)))), h * f32(1.0001)).astype(np.float32)
@@ -533,7 +590,7 @@ def trace_rays(S: Scene, origin, direction, stats=None):
                 np_, nd_, nh_ = next_ray_rk(S, rkpos[kr], rkdir[kr], rkh[kr])
                 rkpos[kr] = np_; rkdir[kr] = nd_; rkh[kr] = nh_
                 cpos[kr] = np_; cdir[kr] = nd_; step[kr] = nh_
-            cd = vlen(cpos[kr] - S.bh_pos)
+            cd = flen(cpos[kr] - S.bh_pos)                     # N7: the integrator's distance
             closest[kr] = np.where(cd < closest[kr], cd, closest[kr])
             pdir[kr] = cdir[kr]
             h_, t_, col_, op_ = hit_black_hole(S, ppos[kr], pdir[kr], t_min, step[kr], ray_distance[kr])

@@ -31,6 +31,14 @@
  *       max(a,b) = a<b ? b : a and min(a,b) = b<a ? b : a ; smoothstep per WGSL spec.
  *   N6  untyped WGSL `const` expressions (the Cash–Karp tableau, b_i - b*_i) are evaluated
  *       in binary64 and rounded once to binary32 (naga AbstractFloat const-evaluation).
+ *   N7  the integrator — f, next_ray_euler, next_ray_rk and the exit distance (ray.wgsl:401-480, 533) — is evaluated
+ *       with fused multiply-add, as WGSL permits and GPU shader compilers do (a*b+c contracts to one rounding):
+ *         fdot(a,b)    = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x))
+ *         fcross(a,b)  = (fma(a.y,b.z, -(a.z*b.y)), fma(a.z,b.x, -(a.x*b.z)), fma(a.x,b.y, -(a.y*b.x)))
+ *         v + w*s      = fma(w, s, v) per component            (stage arguments, direction and position updates)
+ *         sum k_i*c_i  = fma(k_n,c_n, ... fma(k_2,c_2, k_1*c_1))  (left to right; first product rounded)
+ *       length / normalize / distance inside the integrator are built on fdot.  Everything else (intersections,
+ *       shading, grid classification, create_ray) keeps N0: no contraction.
  * Deviations from the reference, both unobservable in it:
  *   D1  the RK retry loop (ray.wgsl:425-451) cannot change h, so it never terminates when
  *       e_max > 1 (or NaN); it is executed exactly once here.
@@ -97,6 +105,15 @@ static inline float clampf(float x, float lo, float hi) { return fmin_(fmax_(x, 
 static inline float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 static inline v3 mix3(v3 a, v3 b, float t) { return V(mixf(a.x, b.x, t), mixf(a.y, b.y, t), mixf(a.z, b.z, t)); }
 static inline v3 fromp(const float* p) { return V(p[0], p[1], p[2]); }
+/* N7: fused forms used only by the integrator */
+static inline float fdot(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+static inline float flength(v3 a) { return sqrtf(fdot(a, a)); }
+static inline v3 fnormalize(v3 a) { return divs(a, flength(a)); }
+static inline float fdistance(v3 a, v3 b) { return flength(sub(a, b)); }
+static inline v3 fcross(v3 a, v3 b) {
+    return V(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+static inline v3 fmadd3(v3 w, float s, v3 v) { return V(fmaf(w.x, s, v.x), fmaf(w.y, s, v.y), fmaf(w.z, s, v.z)); }   /* v + w*s */
 static inline float smoothstep(float e0, float e1, float x) {
     float t = clampf((x - e0) / (e1 - e0), 0.0f, 1.0f);
     return t * t * (3.0f - 2.0f * t);
@@ -519,44 +536,47 @@ static inline v3 f_acc(const scene* S, v3 p, float h2, float dist) {
     return divs(num, pow5(dist));
 }
 
-/* ---- ray.wgsl:405-465 next_ray_rk (D1) -------------------------------------------------------- */
+/* ---- ray.wgsl:405-465 next_ray_rk (D1, N7) ---------------------------------------------------- */
+/* sum of scaled vectors, left to right: first product rounded, the rest fused */
+static inline v3 lin2(v3 a, float ca, v3 b, float cb) { return fmadd3(b, cb, muls(a, ca)); }
 static RKState next_ray_rk(const scene* S, RKState st) {
     Ray ray = st.ray;
-    float dist = length(sub(ray.position, fromp(S->bh->position)));
-    float lc = length(cross(ray.position, ray.direction));
+    v3 p0 = ray.position;
+    float dist = flength(sub(p0, fromp(S->bh->position)));
+    float lc = flength(fcross(p0, ray.direction));
     float h2 = lc * lc;
-    v3 dydx = f_acc(S, ray.position, h2, dist);
+    v3 dydx = f_acc(S, p0, h2, dist);
 
     float h = st.h;
     v3 k1 = dydx;
-    v3 k2 = f_acc(S, add(ray.position, muls(muls(k1, a_21), h)), h2, dist);
-    v3 k3 = f_acc(S, add(ray.position, muls(add(muls(k1, a_31), muls(k2, a_32)), h)), h2, dist);
-    v3 k4 = f_acc(S, add(ray.position, muls(add(add(muls(k1, a_41), muls(k2, a_42)), muls(k2, a_43)), h)), h2, dist);
-    v3 k5 = f_acc(S, add(ray.position, muls(add(add(add(muls(k1, a_51), muls(k2, a_52)), muls(k3, a_53)), muls(k4, a_54)), h)), h2, dist);
-    v3 k6 = f_acc(S, add(ray.position, muls(add(add(add(add(muls(k1, a_61), muls(k2, a_62)), muls(k3, a_63)), muls(k4, a_64)), muls(k5, a_65)), h)), h2, dist);
+    v3 k2 = f_acc(S, fmadd3(muls(k1, a_21), h, p0), h2, dist);
+    v3 k3 = f_acc(S, fmadd3(lin2(k1, a_31, k2, a_32), h, p0), h2, dist);
+    v3 k4 = f_acc(S, fmadd3(fmadd3(k2, a_43, lin2(k1, a_41, k2, a_42)), h, p0), h2, dist);            /* a_43*k_2 (sic) */
+    v3 k5 = f_acc(S, fmadd3(fmadd3(k4, a_54, fmadd3(k3, a_53, lin2(k1, a_51, k2, a_52))), h, p0), h2, dist);
+    v3 k6 = f_acc(S, fmadd3(fmadd3(k5, a_65, fmadd3(k4, a_64, fmadd3(k3, a_63, lin2(k1, a_61, k2, a_62)))), h, p0), h2, dist);
 
-    v3 es = add(add(add(add(add(muls(k1, db_1), muls(k2, db_2)), muls(k3, db_3)), muls(k4, db_4)), muls(k5, db_5)), muls(k6, db_6));
+    v3 es = fmadd3(k6, db_6, fmadd3(k5, db_5, fmadd3(k4, db_4, fmadd3(k3, db_3, lin2(k1, db_1, k2, db_2)))));
     v3 e = muls(es, h);
     /* yscal = 1, eps = 1: e/yscal and e_max/eps are exact */
     st.e_max = fmax_(fmax_(fabsf(e.x), fabsf(e.y)), fabsf(e.z));
     /* D1: retry loop body cannot change h (h_temp < h for e_max > 1); executed once. */
 
-    v3 ds = add(add(add(add(add(muls(k1, b_a_1), muls(k2, b_a_2)), muls(k3, b_a_3)), muls(k4, b_a_4)), muls(k5, b_a_5)), muls(k6, b_a_6));
-    st.ray.direction = normalize(add(st.ray.direction, muls(ds, st.h)));
-    st.ray.position = add(st.ray.position, muls(ray.direction, st.h));   /* old direction */
+    v3 ds = fmadd3(k6, b_a_6, fmadd3(k5, b_a_5, fmadd3(k4, b_a_4, fmadd3(k3, b_a_3, lin2(k1, b_a_1, k2, b_a_2)))));
+    st.ray.direction = fnormalize(fmadd3(ds, st.h, st.ray.direction));
+    st.ray.position = fmadd3(ray.direction, st.h, st.ray.position);      /* old direction */
 
     if (st.e_max > 0.00002f) st.h = st.h * (0.9f * bh_pow_m001(st.e_max));
     else st.h = st.h * 1.0001f;
     return st;
 }
 
-/* ---- ray.wgsl:467-480 next_ray_euler ----------------------------------------------------------- */
+/* ---- ray.wgsl:467-480 next_ray_euler (N7) ------------------------------------------------------- */
 static Ray next_ray_euler(const scene* S, Ray ray, float step) {
-    float lc = length(cross(ray.position, ray.direction));
+    float lc = flength(fcross(ray.position, ray.direction));
     float h2 = lc * lc;
-    float dist = length(sub(ray.position, fromp(S->bh->position)));
-    ray.direction = normalize(add(ray.direction, muls(f_acc(S, ray.position, h2, dist), step)));
-    ray.position = add(ray.position, muls(ray.direction, step));
+    float dist = flength(sub(ray.position, fromp(S->bh->position)));
+    ray.direction = fnormalize(fmadd3(f_acc(S, ray.position, h2, dist), step, ray.direction));
+    ray.position = fmadd3(ray.direction, step, ray.position);
     return ray;
 }
 
@@ -591,7 +611,7 @@ static v4 trace_ray(const scene* S, Ray ray) {
                 curr = rk.ray;
                 step_size = rk.h;
             }
-            float cd = distance(curr.position, bpos);
+            float cd = fdistance(curr.position, bpos);                   /* N7: the integrator's distance */
             if (cd < closest_to_bh) closest_to_bh = cd;
             prev.direction = curr.direction;
             crs = hit_ray(S, prev, t_min, step_size, ray_distance, 0, 1);
