@@ -147,6 +147,7 @@ void derive_frame(const bhray_ctx* c, FrameParams& P) {
     P.bh[0] = bpos.x; P.bh[1] = bpos.y; P.bh[2] = bpos.z;
     memcpy(P.bn, bh.normal, 12);
     P.bn_len = length(ld3(bh.normal));
+    P.bn_dot_bh = dot(ld3(bh.normal), bpos);
     P.inner = bh.accretion_disk_inner; P.outer = bh.accretion_disk_outer;
     P.rot_speed = bh.rotation_speed; P.R = bh.relativity_sphere_radius;
     P.show_tex = bh.show_disk_texture; P.show_shift = bh.show_red_shift;

@@ -41,6 +41,7 @@ struct FrameParams {
     float bh[3];
     float bn[3];
     float bn_len;          // length(normal) (host), for the conservative disk cull
+    float bn_dot_bh;       // dot(normal, position) (host), plane offset for the same cull
     float inner, outer, rot_speed, R;
     int show_tex, show_shift;
     float M[9];            // rotation matrix columns c0,c1,c2

@@ -154,22 +154,22 @@ __device__ __forceinline__ void shade_disk(const FrameParams& P, F3 pos, F3 dir,
 //   disk:    t = fl(numer/denom) < step with |denom| <= |n||d|(1 + 4e-7)  -> skip when |numer| > 1.01 |n| step,
 //            and the hit point must lie within `outer` of the centre       -> skip when |oc| > outer + 0.05 + 1.05 step
 // so a skipped test is one whose literal evaluation returns "no hit": results are unchanged bit for bit
-// (checked against the oracle, which always evaluates the literal tests).
+// (checked against the oracle, which always evaluates the literal tests).  The cull quantities are not part of the
+// shader, so they are the cheapest sufficient ones: |oc| is the distance the integrator already carries for this
+// position (`pos_dist`, within a few ulp of the literal |oc|, far inside the margins), and the plane distance is
+// n.b - n.pos with the constant n.b from the host.
 template <bool COUNT>
-__device__ __forceinline__ void hit_black_hole(const FrameParams& P, F3 pos, F3 dir, float t_min, float t_max,
+__device__ __forceinline__ void hit_black_hole(const FrameParams& P, F3 pos, F3 dir, float pos_dist, float t_min, float t_max,
                                                float total_distance, Hit& rs, unsigned long long* cnt) {
     const F3 bpos = ld3(P.bh);
-    const F3 oc = pos - bpos;
-    const float oc2 = dot(oc, oc);
     const float reach = 1.05f * t_max + 0.05f;
-    const float hr = 1.0f + reach, dr = P.outer + reach;
     float ts = t_max, td = t_max;
     bool hs = false, hd = false;
-    if (oc2 <= hr * hr) hs = hit_sphere(pos, dir, 1.0f, bpos, t_min, t_max, ts);
-    if (oc2 <= dr * dr) {
+    if (pos_dist <= 1.0f + reach) hs = hit_sphere(pos, dir, 1.0f, bpos, t_min, t_max, ts);
+    if (pos_dist <= P.outer + reach) {
         const F3 bn = ld3(P.bn);
-        const float numer = dot(bpos - pos, bn);
-        if (fabsf(numer) <= (1.01f * t_max) * P.bn_len) hd = hit_torus2d(pos, dir, P.inner, P.outer, bpos, bn, t_min, t_max, td);
+        const float numer = P.bn_dot_bh - fdot(pos, bn);
+        if (fabsf(numer) <= (1.01f * t_max) * P.bn_len + 1e-4f * P.bn_len) hd = hit_torus2d(pos, dir, P.inner, P.outer, bpos, bn, t_min, t_max, td);
     }
     rs.hit = hs; rs.t = hs ? ts : t_max; rs.color = f3(0.0f, 0.0f, 0.0f); rs.opacity = hs ? 1.0f : 0.0f;
     if (hd && td < rs.t) {
@@ -460,6 +460,7 @@ __global__ __launch_bounds__(256, BHRAY_TRACE_WAVES) void trace_kernel(const Fra
     F3 color = f3(0, 0, 0);
     float amount = 1.0f, step = P.step_size, closest = P.ray_distance;
     float dist_c = P.ray_distance_f;      // flength(integrator position - bpos) (N7), carried between steps
+    float cpos_dist = P.ray_distance_f;   // flength(cpos - bpos): equals dist_c except in RK mode after a hit moved cpos
     int it = 0;
     bool hit = false;
     bool exhausted = false;
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(256, BHRAY_TRACE_WAVES) void trace_kernel(const Fra
                     cpos = cam; cdir = rdir; ppos = cam; pdir = rdir;
                     rkpos = cam; rkdir = rdir; rkh = P.step_size;
                     color = f3(0, 0, 0); amount = 1.0f; step = P.step_size; closest = P.ray_distance;
-                    dist_c = P.ray_distance_f;
+                    dist_c = P.ray_distance_f; cpos_dist = P.ray_distance_f;
                     it = 0; hit = false;
                     mode = P.relativity0 ? M_REL : M_FLAT;
                     if (COUNT) cnt[3]++;
@@ -545,11 +546,12 @@ __global__ __launch_bounds__(256, BHRAY_TRACE_WAVES) void trace_kernel(const Fra
                         mode = M_FINISH;                                   // break (no increment)
                     } else {
                         bool chit = false; Hit crs = rs;
-                        if (hs && ths < rs.t) { cpos = cpos + cdir * ths; mode = M_REL; if (METHOD == 0) dist_c = fdistance(cpos, bpos); }
+                        if (hs && ths < rs.t) { cpos = cpos + cdir * ths; mode = M_REL; cpos_dist = fdistance(cpos, bpos); if (METHOD == 0) dist_c = cpos_dist; }
                         else { chit = rs.hit; }
                         if (chit) {
                             cpos = cpos + pdir * crs.t;
-                            if (METHOD == 0) dist_c = fdistance(cpos, bpos);
+                            cpos_dist = fdistance(cpos, bpos);
+                            if (METHOD == 0) dist_c = cpos_dist;
                             const F3 cc = f3(clamp_(crs.color.x, 0.0f, 1.0f), clamp_(crs.color.y, 0.0f, 1.0f), clamp_(crs.color.z, 0.0f, 1.0f));
                             color = color + cc * (amount * crs.opacity);
                             amount *= 1.0f - crs.opacity;
@@ -608,6 +610,7 @@ __global__ __launch_bounds__(256, BHRAY_TRACE_WAVES) void trace_kernel(const Fra
                 } else {
                     if (COUNT) cnt[4]++;
                     ppos = cpos; pdir = cdir;
+                    const float ppos_dist = cpos_dist;
                     if (METHOD == 0) {
                         next_ray_euler(bpos, cpos, cdir, step, dist_c);
                     } else {
@@ -615,11 +618,11 @@ __global__ __launch_bounds__(256, BHRAY_TRACE_WAVES) void trace_kernel(const Fra
                         cpos = rkpos; cdir = rkdir; step = rkh;
                     }
                     const float cd = fdistance(cpos, bpos);        // N7: the integrator's distance (ray.wgsl:533)
-                    dist_c = cd;                       // Euler: cpos is the integrator position; RK: cpos == rkpos here
+                    dist_c = cd; cpos_dist = cd;                       // Euler: cpos is the integrator position; RK: cpos == rkpos here
                     if (cd < closest) closest = cd;
                     pdir = cdir;
                     Hit crs;
-                    hit_black_hole<COUNT>(P, ppos, pdir, t_min, step, P.ray_distance, crs, cnt);
+                    hit_black_hole<COUNT>(P, ppos, pdir, ppos_dist, t_min, step, P.ray_distance, crs, cnt);
                     if (cd > P.R) {
                         mode = M_FLAT;
                         const float fw = P.R * P.feather;
@@ -630,7 +633,8 @@ __global__ __launch_bounds__(256, BHRAY_TRACE_WAVES) void trace_kernel(const Fra
                     }
                     if (crs.hit) {
                         cpos = cpos + pdir * crs.t;
-                        if (METHOD == 0) dist_c = fdistance(cpos, bpos);
+                        cpos_dist = fdistance(cpos, bpos);
+                        if (METHOD == 0) dist_c = cpos_dist;
                         const F3 cc = f3(clamp_(crs.color.x, 0.0f, 1.0f), clamp_(crs.color.y, 0.0f, 1.0f), clamp_(crs.color.z, 0.0f, 1.0f));
                         color = color + cc * (amount * crs.opacity);
                         amount *= 1.0f - crs.opacity;
