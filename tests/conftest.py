@@ -18,6 +18,7 @@ def _built():
     import __graft_entry__ as g
     so = os.path.join(ROOT, "bhusie_amd", "libbhray.so")
     oso = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
-    if not (os.path.exists(so) and os.path.exists(oso)):
+    exe = os.path.join(ROOT, "bhusie_amd", "bhray_render")
+    if not (os.path.exists(so) and os.path.exists(oso) and os.path.exists(exe)):
         g.build()
     yield

@@ -94,3 +94,13 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, f
+
+
+def test_cpp_host_program_is_built_and_fails_loudly_without_a_gpu(tmp_path):
+    import subprocess
+    exe = os.path.join(ROOT, "bhusie_amd", "bhray_render")
+    assert os.path.exists(exe), "make -C bhusie_amd/csrc builds the C++ host program"
+    if B.lib().bhray_device_count() > 0:
+        pytest.skip("a GPU is present")
+    r = subprocess.run([exe, str(tmp_path / "o.f32")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "no HIP device" in r.stderr

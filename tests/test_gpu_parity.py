@@ -275,3 +275,28 @@ def test_speculative_levels_with_crop_rows_and_mesh(tmp_path):
         assert np.array_equal(rp.read_hdr(), full[rp.local_rows()])
     with pytest.raises(B.BhrayError):
         B.RayPass(cfg, device=0, speculative_levels=3)         # must leave at least the last level to the normal path
+
+
+def test_cpp_host_program_matches_python_host(tmp_path):
+    """bhusie_amd/bhray_render (C++ over host/renderer.hpp: Renderer / RayPipeline / Model mirrors) renders the same bytes as
+    the Python host, and as the oracle within the bar."""
+    import os
+    import subprocess
+    from bhusie_amd import assets
+    exe = os.path.join(os.path.dirname(B.LIB_PATH), "bhray_render")
+    obj = tmp_path / "m.obj"
+    obj.write_text(assets.icosphere_mesh_obj(3, radius=8.0, bump=0.1, seed=4))
+    out = tmp_path / "o.f32"
+    r = subprocess.run([exe, str(out), "--rk", "--base", "24", "14", "--levels", "2", "--disk-size", "64", "--obj", str(obj)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.strip() == "70x40"
+    got = np.fromfile(out, dtype=np.float32).reshape(40, 70, 4)
+    grey = np.full((1, 1, 4), 160, dtype=np.uint8); grey[..., 3] = 255
+    tex = (grey, assets.reference_disk_texture(64), grey)
+    model = B.load_model(str(obj))
+    u = T.uniforms(integration_method=1, model_count=1)
+    rp = run_gpu(B.ladder_from_base((24, 14), 3, 2), *u, tex, model=model)
+    assert np.array_equal(got, rp.read_hdr())
+    want = O.render_ladder(T.oracle_scene(*u, tex, [model.arrays()]), [(24, 14), (70, 40)])
+    T.assert_parity(got, want[-1], "C++ host program")
