@@ -16,9 +16,9 @@
 //                    hot loop contains only the integrator and the per-step horizon/disk test.
 //
 // No MFMA: the path is an f32 ODE march (VALU) plus byte/int texture and BVH reads (HBM/L2).
-// Numerics: DESIGN.md §Numerics — compiled with -ffp-contract=off; operation order follows the
-// shader so results are bit-identical to the CPU oracle except for the shading-only
-// optical-depth powf(.,1.3) (device libm, 1-2 ulp, not amplified).
+// Numerics: DESIGN.md §2 — compiled with -ffp-contract=off; operation order follows the shader, the integrator uses the
+// explicit fused forms of N7, so results are bit-identical to the CPU oracle except for the shading-only optical-depth
+// powf(.,1.3) (device libm, 1-2 ulp, not amplified).
 #include <hip/hip_fp16.h>
 
 #include "bhray_internal.h"
