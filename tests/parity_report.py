@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Runs on an MI355X: renders a set of configurations through the C ABI and through the CPU oracle and writes the parity
 statistics the tests assert on (classes, bit-identical fraction, max / p99.9 relative error per channel) as JSON.
-    python tools/parity_report.py > profiles/r01_parity.json
+    python tests/parity_report.py > profiles/r01_parity.json
 This is test infrastructure (it imports oracle/), not part of the product."""
 import json
 import os
