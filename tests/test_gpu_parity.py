@@ -300,3 +300,18 @@ def test_cpp_host_program_matches_python_host(tmp_path):
     assert np.array_equal(got, rp.read_hdr())
     want = O.render_ladder(T.oracle_scene(*u, tex, [model.arrays()]), [(24, 14), (70, 40)])
     T.assert_parity(got, want[-1], "C++ host program")
+
+
+def test_config1_256x256_euler_single_level():
+    """BASELINE.json configs[0]: 256x256 single frame, Euler integrator, accretion disk only, one level (every pixel traced).
+    The reference's "CPU-runnable plumbing case": here the CPU side is the oracle, the HIP path must match it."""
+    tex = T.textures()
+    u = T.uniforms(integration_method=0, model_count=0)
+    cfg = B.ladder_from_base((256, 256), 3, 1)
+    rp = run_gpu(cfg, *u, tex, counters=True)
+    cnt = O.Counters()
+    want = O.render_level(T.oracle_scene(*u, tex), (256, 256), None, cnt)
+    mx, exact = T.assert_parity(rp.read_hdr(), want, "config 1")
+    d = want[..., 3] == 0
+    assert np.array_equal(rp.read_hdr()[d], want[d])
+    assert rp.counters() == cnt.as_dict() and cnt.traced == 256 * 256 and cnt.copied == 0 and cnt.interpolated == 0
