@@ -18,8 +18,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/bhray.h"
@@ -225,6 +227,113 @@ int bhray_model_build_bvh(bhray_model* m) {
     m->nodes_used = 1;
     m->update_bounds(0);
     m->subdivide_from(0);
+    m->nodes.resize(m->nodes_used);
+    if (m->nodes_used > BHRAY_MAX_MODEL_VERTICES) return BHRAY_E_CAPACITY;
+    return BHRAY_OK;
+}
+
+// Binned SAH builder (not the reference's algorithm; see include/bhray.h).  16 bins over the centroid bounds of the
+// longest axis... of every axis, cost = area(L)*n(L) + area(R)*n(R); falls back to a median split when binning cannot
+// separate the centroids; leaves hold <= 4 triangles.  Children are allocated adjacently and left subtree first, like
+// the reference builder, so the device layout code is shared.
+int bhray_model_build_bvh_sah(bhray_model* m) {
+    if (!m) return BHRAY_E_INVALID;
+    const size_t np = m->points.size() / 4;
+    for (const bhray_triangle& t : m->triangles)
+        if (t.p1 < 0 || t.p2 < 0 || t.p3 < 0 || (size_t)t.p1 >= np || (size_t)t.p2 >= np || (size_t)t.p3 >= np) return BHRAY_E_INVALID;
+    const size_t T = m->triangles.size();
+    m->nodes.clear();
+    m->nodes.resize(1, bhray_node{{0, 0, 0}, 0, {0, 0, 0}, 0});
+    m->bvh_lookup.resize(T);
+    for (size_t i = 0; i < T; i++) m->bvh_lookup[i] = (int32_t)i;
+    std::vector<float> cent(3 * T), tmin(3 * T), tmax(3 * T);
+    for (size_t i = 0; i < T; i++) {
+        const bhray_triangle& t = m->triangles[i];
+        const float* p[3] = {&m->points[4 * (size_t)t.p1], &m->points[4 * (size_t)t.p2], &m->points[4 * (size_t)t.p3]};
+        for (int a = 0; a < 3; a++) {
+            cent[3 * i + a] = (p[0][a] + p[1][a] + p[2][a]) / 3.0f;
+            tmin[3 * i + a] = fminf(p[0][a], fminf(p[1][a], p[2][a]));
+            tmax[3 * i + a] = fmaxf(p[0][a], fmaxf(p[1][a], p[2][a]));
+        }
+    }
+    m->nodes[0].left_child = 0;
+    m->nodes[0].obj_count = (int32_t)T;
+    m->nodes_used = 1;
+    m->update_bounds(0);
+    auto area = [](const float* lo, const float* hi) {
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return (dx < 0 || dy < 0 || dz < 0) ? 0.0f : 2.0f * (dx * dy + dy * dz + dz * dx);
+    };
+    constexpr int BINS = 16;
+    std::vector<size_t> todo;
+    todo.push_back(0);
+    while (!todo.empty()) {
+        const size_t ni = todo.back();
+        todo.pop_back();
+        const int32_t first = m->nodes[ni].left_child, count = m->nodes[ni].obj_count;
+        if (count <= 4) continue;
+        float clo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, chi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+        for (int32_t i = 0; i < count; i++) {
+            const size_t t = (size_t)m->bvh_lookup[(size_t)(first + i)];
+            for (int a = 0; a < 3; a++) { clo[a] = fminf(clo[a], cent[3 * t + a]); chi[a] = fmaxf(chi[a], cent[3 * t + a]); }
+        }
+        int best_axis = -1, best_bin = -1;
+        float best_cost = 3.4e38f;
+        for (int a = 0; a < 3; a++) {
+            const float ext = chi[a] - clo[a];
+            if (!(ext > 0.0f)) continue;
+            int cnt[BINS] = {0};
+            float blo[BINS][3], bhi[BINS][3];
+            for (int b = 0; b < BINS; b++) for (int k = 0; k < 3; k++) { blo[b][k] = 3.4e38f; bhi[b][k] = -3.4e38f; }
+            const float scale = (float)BINS / ext;
+            for (int32_t i = 0; i < count; i++) {
+                const size_t t = (size_t)m->bvh_lookup[(size_t)(first + i)];
+                int b = (int)((cent[3 * t + a] - clo[a]) * scale);
+                b = b < 0 ? 0 : (b > BINS - 1 ? BINS - 1 : b);
+                cnt[b]++;
+                for (int k = 0; k < 3; k++) { blo[b][k] = fminf(blo[b][k], tmin[3 * t + k]); bhi[b][k] = fmaxf(bhi[b][k], tmax[3 * t + k]); }
+            }
+            float llo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, lhi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+            float larea[BINS]; int lcnt[BINS]; int acc = 0;
+            for (int b = 0; b < BINS - 1; b++) {
+                for (int k = 0; k < 3; k++) { llo[k] = fminf(llo[k], blo[b][k]); lhi[k] = fmaxf(lhi[k], bhi[b][k]); }
+                acc += cnt[b]; lcnt[b] = acc; larea[b] = area(llo, lhi);
+            }
+            float rlo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, rhi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+            acc = 0;
+            for (int b = BINS - 1; b >= 1; b--) {
+                for (int k = 0; k < 3; k++) { rlo[k] = fminf(rlo[k], blo[b][k]); rhi[k] = fmaxf(rhi[k], bhi[b][k]); }
+                acc += cnt[b];
+                if (lcnt[b - 1] == 0 || acc == 0) continue;
+                const float cost = larea[b - 1] * (float)lcnt[b - 1] + area(rlo, rhi) * (float)acc;
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
+            }
+        }
+        int32_t mid;
+        if (best_axis >= 0) {
+            const float ext = chi[best_axis] - clo[best_axis], scale = (float)BINS / ext;
+            int32_t i = first, j = first + count - 1;
+            while (i <= j) {
+                const size_t t = (size_t)m->bvh_lookup[(size_t)i];
+                int b = (int)((cent[3 * t + best_axis] - clo[best_axis]) * scale);
+                b = b < 0 ? 0 : (b > BINS - 1 ? BINS - 1 : b);
+                if (b < best_bin) i++;
+                else { std::swap(m->bvh_lookup[(size_t)i], m->bvh_lookup[(size_t)j]); j--; }
+            }
+            mid = i;
+        } else {
+            mid = first + count / 2;                       // all centroids coincide: split the index range
+        }
+        if (mid == first || mid == first + count) mid = first + count / 2;
+        const size_t li = m->nodes_used, ri = m->nodes_used + 1;
+        m->nodes_used += 2;
+        if (m->nodes.size() < m->nodes_used) m->nodes.resize(m->nodes_used, bhray_node{{0, 0, 0}, 0, {0, 0, 0}, 0});
+        m->nodes[li].left_child = first; m->nodes[li].obj_count = mid - first;
+        m->nodes[ri].left_child = mid; m->nodes[ri].obj_count = first + count - mid;
+        m->nodes[ni].left_child = (int32_t)li; m->nodes[ni].obj_count = 0;
+        m->update_bounds(li); m->update_bounds(ri);
+        todo.push_back(ri); todo.push_back(li);
+    }
     m->nodes.resize(m->nodes_used);
     if (m->nodes_used > BHRAY_MAX_MODEL_VERTICES) return BHRAY_E_CAPACITY;
     return BHRAY_OK;

@@ -131,6 +131,7 @@ SYMBOLS = {
     "bhray_model_add_triangle": (C.c_int, [vp, P(BhrayTriangle)]),
     "bhray_model_build_bvh": (C.c_int, [vp]),
     "bhray_model_max_depth": (C.c_int, [vp]),
+    "bhray_model_build_bvh_sah": (C.c_int, [vp]),
     "bhray_model_desc_get": (C.c_int, [vp, P(BhrayModelDesc)]),
     "bhray_model_set_transform": (C.c_int, [vp, P(C.c_float), i32]),
     "bhray_model_pack_uniform": (C.c_int, [vp, vp, sz]),

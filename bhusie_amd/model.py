@@ -40,6 +40,10 @@ class Model:
     def build_bvh(self):
         check(lib().bhray_model_build_bvh(self._h))
 
+    def build_bvh_sah(self):
+        """Binned-SAH builder behind a flag (not the reference's tree; see include/bhray.h)."""
+        check(lib().bhray_model_build_bvh_sah(self._h))
+
     def max_depth(self) -> int:
         return int(lib().bhray_model_max_depth(self._h))
 

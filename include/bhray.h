@@ -327,6 +327,11 @@ int  bhray_model_add_normal(bhray_model* m, const float n[4]);
 int  bhray_model_add_triangle(bhray_model* m, const bhray_triangle* t);
 int  bhray_model_build_bvh(bhray_model* m);                     /* triangle.rs:143-259         */
 int  bhray_model_max_depth(const bhray_model* m);               /* deepest leaf, root = 1      */
+/* Alternative builder behind a flag: binned surface-area-heuristic splits on centroid bounds, same
+ * node / bvh_lookup format, leaves of <= 4 triangles.  NOT the reference's tree: traversal finds the same closest hit,
+ * but rays that hit two triangles at exactly equal t (shared edges) may pick the other one, so frames can differ from the
+ * reference-identical builder in isolated pixels.  Use for speed (shallower, tighter trees), never for parity runs.      */
+int  bhray_model_build_bvh_sah(bhray_model* m);
 int  bhray_model_desc_get(const bhray_model* m, bhray_model_desc* out); /* borrowed pointers   */
 int  bhray_model_set_transform(bhray_model* m, const float position[3], int32_t visible);
 /* Writes the exact ModelUniform image (BHRAY_MODEL_UNIFORM_BYTES) — triangle.rs:308-325.     */

@@ -315,3 +315,24 @@ def test_config1_256x256_euler_single_level():
     d = want[..., 3] == 0
     assert np.array_equal(rp.read_hdr()[d], want[d])
     assert rp.counters() == cnt.as_dict() and cnt.traced == 256 * 256 and cnt.copied == 0 and cnt.interpolated == 0
+
+
+def test_sah_tree_gives_the_same_closest_hits(tmp_path):
+    """The flagged SAH builder changes the tree, not the geometry: the HIP path with the SAH tree matches the oracle run on the
+    SAME tree (traversal semantics), and matches the reference-tree frame except where two triangles are hit at equal t."""
+    tex = T.textures()
+    model = _mesh_model(tmp_path, 24, 32)
+    d = np.array([-0.12, 0.0, 1.0]); d /= np.linalg.norm(d)
+    cam = B.Camera(position=(0.0, 0.0, -40.0), forward=tuple(d), fov=1.2)
+    u = T.uniforms(camera=cam, integration_method=1, model_count=1)
+    cfg = B.ladder_from_base((40, 24), 3, 2)
+    ref_frame = run_gpu(cfg, *u, tex, model=model).read_hdr()
+    model.build_bvh_sah()
+    rp = run_gpu(cfg, *u, tex, model=model, counters=True)
+    got = rp.read_hdr()
+    cnt = O.Counters()
+    want = O.render_ladder(T.oracle_scene(*u, tex, [model.arrays()]), cfg.sizes(), cnt)
+    T.assert_parity(got, want[-1], "SAH tree vs oracle on the same tree")
+    assert rp.counters() == cnt.as_dict()
+    same = (got == ref_frame).all(axis=-1)
+    assert same.mean() > 0.995, same.mean()

@@ -152,3 +152,21 @@ def test_disk_texture_generator_reproduces_reference_disk_png():
         ref = np.array(Image.open(ref_png))
         e = np.abs(cpp.astype(int) - ref.astype(int))
         assert e.max() <= 2 and (e == 0).mean() > 0.9999
+
+
+def test_sah_builder_behind_a_flag_is_a_valid_bvh(tmp_path):
+    """bhray_model_build_bvh_sah (SURVEY.md §8f-2): not the reference's tree, but the same format and invariants;
+    it also repairs the huge leaves the midpoint builder leaves on lattice-like meshes."""
+    text = assets.sphere_mesh_obj(40, 48, radius=7.0, bump=0.2, seed=9)
+    p = tmp_path / "m.obj"; p.write_text(text)
+    m = B.load_model(str(p))
+    ref = m.arrays()
+    ref_leaf_max = int(ref["nodes"]["obj_count"].max())
+    m.build_bvh_sah()
+    a = m.arrays()
+    _check_bvh_invariants(a)
+    assert int(a["nodes"]["obj_count"].max()) <= 4 < ref_leaf_max
+    assert np.array_equal(a["points"], ref["points"]) and np.array_equal(a["triangles"], ref["triangles"])
+    m.build_bvh()                                                   # and back: the reference-identical tree again
+    b = m.arrays()
+    assert b["nodes"].tobytes() == ref["nodes"].tobytes() and np.array_equal(b["bvh_lookup"], ref["bvh_lookup"])
