@@ -305,8 +305,8 @@ __device__ constexpr float DB1 = KF(37.0 / 378.0 - 2825.0 / 27648.0), DB2 = KF(0
 // `dist` = flength(pos - bpos), carried from the previous step's exit test (same operands, same value).
 __device__ __forceinline__ void next_ray_rk(F3 bpos, F3& pos, F3& dir, float& h_io, float dist) {
     const F3 p0 = pos, d0 = dir;
-    const float lc = flength(fcross(p0, d0));
-    const float h2 = lc * lc;
+    const F3 cr = fcross(p0, d0);
+    const float h2 = fdot(cr, cr);                   // N3: pow(length(v), 2.0) = dot(v, v)
     const float c = -1.5f * h2;
     const float r = 1.0f / pow5(dist);
     const float h = h_io;
@@ -328,8 +328,8 @@ __device__ __forceinline__ void next_ray_rk(F3 bpos, F3& pos, F3& dir, float& h_
 
 // next_ray_euler, ray.wgsl:467-480 (N7).
 __device__ __forceinline__ void next_ray_euler(F3 bpos, F3& pos, F3& dir, float step, float dist) {
-    const float lc = flength(fcross(pos, dir));
-    const float h2 = lc * lc;
+    const F3 cr = fcross(pos, dir);
+    const float h2 = fdot(cr, cr);                   // N3: pow(length(v), 2.0) = dot(v, v)
     const float c = -1.5f * h2;
     const float r = 1.0f / pow5(dist);
     dir = fnormalize(fmadd3(f_acc(pos, bpos, c, r), step, dir));

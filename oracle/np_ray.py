@@ -515,7 +515,7 @@ def f_acc(S, p, h2, dist):
 
 
 def next_ray_euler(S, pos, dirn, step):
-    lc = flen(fcross(pos, dirn)); h2 = lc * lc
+    cr = fcross(pos, dirn); h2 = fdot(cr, cr)               # N3: pow(length(v), 2.0) = dot(v, v)
     dist = flen(pos - S.bh_pos)
     nd = fnorm(fmadd3(f_acc(S, pos, h2, dist), step, dirn))
     npos = fmadd3(nd, step, pos)
@@ -533,7 +533,7 @@ def _lin(terms):
 
 def next_ray_rk(S, pos, dirn, h):
     dist = flen(pos - S.bh_pos)
-    lc = flen(fcross(pos, dirn)); h2 = lc * lc
+    cr = fcross(pos, dirn); h2 = fdot(cr, cr)               # N3: pow(length(v), 2.0) = dot(v, v)
     k1 = f_acc(S, pos, h2, dist)
     k2 = f_acc(S, fmadd3(k1 * A21, h, pos), h2, dist)
     k3 = f_acc(S, fmadd3(_lin([(k1, A31), (k2, A32)]), h, pos), h2, dist)

@@ -21,7 +21,8 @@
  *   N1  dot(a,b) = (a.x*b.x + a.y*b.y) + a.z*b.z ; length(v) = sqrt(dot(v,v))
  *   N2  vector / scalar  = vector * (1.0f / scalar)   (one correctly rounded reciprocal)
  *       normalize(v)     = v / length(v) under N2
- *   N3  pow(x, 2.0) = x*x ; pow(x, 4.0) = (x*x)*(x*x) ; pow(x, 5.0) = ((x*x)*(x*x))*x
+ *   N3  pow(x, 2.0) = x*x ; pow(x, 4.0) = (x*x)*(x*x) ; pow(x, 5.0) = ((x*x)*(x*x))*x ;
+ *       pow(length(v), 2.0) = dot(v, v) (ray.wgsl:419,470: the squared length without the round trip through sqrt)
  *   N4  pow(e_max, -0.001), acos, atan2, sin, cos and tan (= sin/cos) use the portable forms bh_*
  *       below, specified to the bit: they steer the trajectory (pow), the copy/interpolate/
  *       trace classification (acos) or texture coordinates, where an ulp is amplified by the
@@ -543,8 +544,8 @@ static RKState next_ray_rk(const scene* S, RKState st) {
     Ray ray = st.ray;
     v3 p0 = ray.position;
     float dist = flength(sub(p0, fromp(S->bh->position)));
-    float lc = flength(fcross(p0, ray.direction));
-    float h2 = lc * lc;
+    v3 cr = fcross(p0, ray.direction);
+    float h2 = fdot(cr, cr);                                     /* N3: pow(length(v), 2.0) = dot(v, v) */
     v3 dydx = f_acc(S, p0, h2, dist);
 
     float h = st.h;
@@ -572,8 +573,8 @@ static RKState next_ray_rk(const scene* S, RKState st) {
 
 /* ---- ray.wgsl:467-480 next_ray_euler (N7) ------------------------------------------------------- */
 static Ray next_ray_euler(const scene* S, Ray ray, float step) {
-    float lc = flength(fcross(ray.position, ray.direction));
-    float h2 = lc * lc;
+    v3 cr = fcross(ray.position, ray.direction);
+    float h2 = fdot(cr, cr);                                     /* N3: pow(length(v), 2.0) = dot(v, v) */
     float dist = flength(sub(ray.position, fromp(S->bh->position)));
     ray.direction = fnormalize(fmadd3(f_acc(S, ray.position, h2, dist), step, ray.direction));
     ray.position = fmadd3(ray.direction, step, ray.position);
