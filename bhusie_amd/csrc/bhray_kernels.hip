@@ -437,12 +437,15 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3 };
 #ifndef BHRAY_FLAT_DEFER
 #define BHRAY_FLAT_DEFER 4         // ... or after this many rounds at the latest
 #endif
+#ifndef BHRAY_TRACE_WAVES_MESH
+#define BHRAY_TRACE_WAVES_MESH 4 // measured on the mesh workload: 3 -> 2190, 4 -> 2487, 2 -> 1746 Mrays/s
+#endif
 #ifndef BHRAY_TRACE_WAVES
 #define BHRAY_TRACE_WAVES 4      // waves per SIMD the trace kernel is register-budgeted for (<=128 VGPRs)
 #endif
 
 template <int METHOD, bool MODELS, bool COUNT>
-__global__ __launch_bounds__(256, BHRAY_TRACE_WAVES) void trace_kernel(const FrameParams P, const LevelParams L, const SpecLevels SL, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : BHRAY_TRACE_WAVES) void trace_kernel(const FrameParams P, const LevelParams L, const SpecLevels SL, const uint32_t* __restrict__ queue,
                                                     const uint32_t* __restrict__ qcount_p, uint32_t* __restrict__ qhead,
                                                     Counters64* __restrict__ counters, int* __restrict__ err_flag) {
     const int lane = threadIdx.x & 63;
