@@ -36,20 +36,37 @@ struct Level {                      // geometry of one ladder level (shared by a
     size_t queue_cap = 0;
 };
 
-// One frame in flight: its own stream, level images, work queues and output buffer.
-struct Slot {
-    hipStream_t stream = nullptr;
+// Resources of one frame: level images, work queues and output buffer.
+struct FrameRes {
     std::vector<float4*> level_out;     // [levels-1] full-size images of the non-final levels
     std::vector<uint32_t*> queue;       // [levels]
     std::vector<float4*> spec_out;      // speculative mode: traced images of levels 1..S-1 (level 0 traces straight into level_out[0])
     uint32_t* spec_queue = nullptr;     // speculative mode: merged, level-tagged queue of levels 0..S-1
-    uint32_t* d_qctl = nullptr;         // [2*levels]: qcount[l], qhead[l]
-    Counters64* d_counters = nullptr;   // [BHRAY_MAX_LEVELS]
+    uint32_t* d_qctl = nullptr;         // [2*BHRAY_MAX_LEVELS]: qcount[l], qhead[l]   (a slice of Slot::d_qctl)
+    Counters64* d_counters = nullptr;   // [BHRAY_MAX_LEVELS]                         (a slice of Slot::d_counters)
     float4* own_out = nullptr;
-    float4* out = nullptr;              // where this slot's frame is written (own_out or a bound buffer)
+    float4* out = nullptr;              // where this frame is written (own_out or a bound buffer)
     uint2* sky_out = nullptr;           // RGBA16F image of the sky resolve pass (allocated on first use)
-    uint64_t frame_id = 0;              // frame_counter value of the frame this slot holds
+    uint64_t frame_id = 0;              // frame_counter value of the frame held here
+};
+
+// One batch in flight: a HIP stream, the frames of the batch (frames_per_batch of them) and the argument block of its
+// launches.  bhray_render stages a frame (host work only); the launches of the whole batch are enqueued when the batch is
+// full or flushed, each launch covering all staged frames.
+struct Slot {
+    hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;          // recorded after the slot's last launch
+    hipEvent_t uploaded = nullptr;      // recorded after the argument block of the slot's batch has been copied to the device
+    bool used = false;                  // `uploaded` has been recorded at least once
+    std::vector<FrameRes> fr;
+    uint32_t pending = 0;               // frames staged and not launched yet
+    int method = 0; bool models = false;   // kernel variant of the staged frames (a batch is homogeneous)
+    uint32_t* d_qctl = nullptr;         // [frames_per_batch][2*BHRAY_MAX_LEVELS]
+    Counters64* d_counters = nullptr;   // [frames_per_batch][BHRAY_MAX_LEVELS]
+    uint8_t* h_args = nullptr;          // pinned staging of the argument block: FrameParams[B], then FrameLaunch[B] per launch
+    uint8_t* d_args = nullptr;
+    size_t args_cap = 0;
+    uint64_t batch_id = 0;              // batch_counter value of the batch this slot holds
 };
 
 struct ModelStore {
@@ -67,8 +84,10 @@ struct bhray_ctx {
     bhray_config cfg{};
     int device = 0;
     std::vector<Level> levels;
-    std::vector<Slot> slots;               // frames in flight
-    int last_slot = 0;                     // slot of the most recently enqueued frame
+    std::vector<Slot> slots;               // batches in flight
+    uint32_t batch = 1;                    // frames per batch
+    int last_slot = 0, last_sub = 0;       // slot / position in its batch of the most recently rendered frame
+    uint64_t batch_counter = 0;            // batches launched so far; the staging slot is batch_counter % slots
     float4* bound_out = nullptr;           // bhray_bind_output: destination of the next frame(s)
     hipEvent_t wait_ev = nullptr;          // bhray_wait_stream: pending dependency of the next render
     bool wait_pending = false;
@@ -83,11 +102,13 @@ struct bhray_ctx {
     bhray_details det{};
     bool have_uniforms = false;
     std::vector<hipEvent_t> events;        // ring: [BHRAY_TIMING_RING][levels][3] (before classify, before trace, after trace)
-    uint64_t frame_counter = 0, timing_begin = 0;
+    uint64_t frame_counter = 0, timing_begin = 0;   // timing_begin: first batch not yet reported by bhray_get_timing
     uint8_t sky_recorded[BHRAY_TIMING_RING] = {0};
+    uint8_t ring_frames[BHRAY_TIMING_RING] = {0};   // frames of the batch held by each timing-ring entry
     int* d_err = nullptr;
     int num_cus = 256;
     int bpc_override = 0;                  // BHRAY_TRACE_BLOCKS_PER_CU (tuning experiments only)
+    int dense_override = -1;               // BHRAY_TRACE_DENSE=0/1 (tuning experiments only)
     bool rendered = false;
     std::string err;
 };
@@ -174,6 +195,8 @@ void derive_frame(const bhray_ctx* c, FrameParams& P) {
     for (int i = 0; i < 3; i++) { t[i]->rgba = c->tex[i]; t[i]->w = c->tex_w[i]; t[i]->h = c->tex_h[i]; }
 }
 
+int launch_batch(bhray_ctx* c);
+
 hipError_t sync_all(bhray_ctx* c) {
     for (Slot& S : c->slots) {
         hipError_t e = hipStreamSynchronize(S.stream);
@@ -256,15 +279,20 @@ void bhray_destroy(bhray_ctx* c) {
     (void)hipSetDevice(c->device);
     for (Slot& S : c->slots) if (S.stream) (void)hipStreamSynchronize(S.stream);
     for (Slot& S : c->slots) {
-        for (auto p : S.level_out) if (p) (void)hipFree(p);
-        for (auto p : S.queue) if (p) (void)hipFree(p);
-        for (auto p : S.spec_out) if (p) (void)hipFree(p);
-        if (S.spec_queue) (void)hipFree(S.spec_queue);
+        for (FrameRes& R : S.fr) {
+            for (auto p : R.level_out) if (p) (void)hipFree(p);
+            for (auto p : R.queue) if (p) (void)hipFree(p);
+            for (auto p : R.spec_out) if (p) (void)hipFree(p);
+            if (R.spec_queue) (void)hipFree(R.spec_queue);
+            if (R.own_out) (void)hipFree(R.own_out);
+            if (R.sky_out) (void)hipFree(R.sky_out);
+        }
         if (S.d_qctl) (void)hipFree(S.d_qctl);
         if (S.d_counters) (void)hipFree(S.d_counters);
-        if (S.own_out) (void)hipFree(S.own_out);
-        if (S.sky_out) (void)hipFree(S.sky_out);
+        if (S.h_args) (void)hipHostFree(S.h_args);
+        if (S.d_args) (void)hipFree(S.d_args);
         if (S.done) (void)hipEventDestroy(S.done);
+        if (S.uploaded) (void)hipEventDestroy(S.uploaded);
         if (S.stream) (void)hipStreamDestroy(S.stream);
     }
     for (Level& L : c->levels) {
@@ -293,6 +321,7 @@ int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
     if (cfg->row_world < 1 || cfg->row_rank >= cfg->row_world || cfg->stripe_rows < 1)
         return fail(nullptr, BHRAY_E_INVALID, "bad row partition");
     if (cfg->frames_in_flight > BHRAY_MAX_FRAMES_IN_FLIGHT) return fail(nullptr, BHRAY_E_INVALID, "frames_in_flight > %d", BHRAY_MAX_FRAMES_IN_FLIGHT);
+    if (cfg->frames_per_batch > BHRAY_MAX_FRAMES_PER_BATCH) return fail(nullptr, BHRAY_E_INVALID, "frames_per_batch > %d", BHRAY_MAX_FRAMES_PER_BATCH);
     if (cfg->speculative_levels == 1 || cfg->speculative_levels > BHRAY_MAX_SPEC_LEVELS || (cfg->speculative_levels && cfg->speculative_levels >= cfg->levels))
         return fail(nullptr, BHRAY_E_INVALID, "speculative_levels must be 0 or 2..min(%d, levels-1)", BHRAY_MAX_SPEC_LEVELS);
     int ndev = 0;
@@ -318,9 +347,12 @@ int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
     CHK(hipGetDeviceProperties(&prop, c->device));
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = getenv("BHRAY_TRACE_BLOCKS_PER_CU")) c->bpc_override = atoi(e);
+    if (const char* e = getenv("BHRAY_TRACE_DENSE")) c->dense_override = atoi(e) != 0;
     const uint32_t nslots = cfg->frames_in_flight ? cfg->frames_in_flight : 4;
     c->cfg.frames_in_flight = nslots;
     c->slots.resize(nslots);
+    c->batch = cfg->frames_per_batch ? cfg->frames_per_batch : 1;
+    c->cfg.frames_per_batch = c->batch;
     CHK(hipEventCreateWithFlags(&c->wait_ev, hipEventDisableTiming));
 
     // rows of the frame owned by this partition
@@ -355,44 +387,56 @@ int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
         }
     }
     c->out_bytes = c->local_rows.size() * (size_t)cfg->frame_w * sizeof(float4);
+    const size_t nlaunch = 3 * (size_t)nl + 2;                            // upper bound of launches per batch
     for (Slot& S : c->slots) {
         CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
         CHK(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
-        S.level_out.assign(nl > 0 ? nl - 1 : 0, nullptr);
-        S.queue.assign(nl, nullptr);
-        for (uint32_t l = 0; l < nl; l++) {
-            const Level& L = c->levels[l];
-            if (l + 1 < nl) {
-                const size_t npix = (size_t)L.w * (size_t)L.h;
-                CHK(hipMalloc(&S.level_out[l], npix * sizeof(float4)));
-                CHK(hipMemset(S.level_out[l], 0xFF, npix * sizeof(float4)));      // NaN: "never rendered"
-            }
-            if (L.queue_cap) CHK(hipMalloc(&S.queue[l], L.queue_cap * sizeof(uint32_t)));
-        }
-        if (cfg->speculative_levels) {
-            const uint32_t ns = cfg->speculative_levels;
-            S.spec_out.assign(ns, nullptr);
-            size_t cap = 0;
-            for (uint32_t l = 0; l < ns; l++) {
+        CHK(hipEventCreateWithFlags(&S.uploaded, hipEventDisableTiming));
+        const size_t B = c->batch;
+        CHK(hipMalloc(&S.d_qctl, B * 2 * BHRAY_MAX_LEVELS * sizeof(uint32_t)));
+        CHK(hipMemset(S.d_qctl, 0, B * 2 * BHRAY_MAX_LEVELS * sizeof(uint32_t)));
+        CHK(hipMalloc(&S.d_counters, B * BHRAY_MAX_LEVELS * sizeof(Counters64)));
+        CHK(hipMemset(S.d_counters, 0, B * BHRAY_MAX_LEVELS * sizeof(Counters64)));
+        S.args_cap = (B * (sizeof(FrameParams) + nlaunch * sizeof(FrameLaunch)) + 15) & ~(size_t)15;
+        CHK(hipHostMalloc((void**)&S.h_args, S.args_cap, hipHostMallocDefault));
+        CHK(hipMalloc(&S.d_args, S.args_cap));
+        S.fr.resize(B);
+        for (size_t k = 0; k < B; k++) {
+            FrameRes& R = S.fr[k];
+            R.d_qctl = S.d_qctl + k * 2 * BHRAY_MAX_LEVELS;
+            R.d_counters = S.d_counters + k * BHRAY_MAX_LEVELS;
+            R.level_out.assign(nl > 0 ? nl - 1 : 0, nullptr);
+            R.queue.assign(nl, nullptr);
+            for (uint32_t l = 0; l < nl; l++) {
                 const Level& L = c->levels[l];
-                cap += L.queue_cap;
-                if (l > 0) {
+                if (l + 1 < nl) {
                     const size_t npix = (size_t)L.w * (size_t)L.h;
-                    CHK(hipMalloc(&S.spec_out[l], npix * sizeof(float4)));
-                    CHK(hipMemset(S.spec_out[l], 0xFF, npix * sizeof(float4)));
+                    CHK(hipMalloc(&R.level_out[l], npix * sizeof(float4)));
+                    CHK(hipMemset(R.level_out[l], 0xFF, npix * sizeof(float4)));      // NaN: "never rendered"
                 }
+                if (L.queue_cap) CHK(hipMalloc(&R.queue[l], L.queue_cap * sizeof(uint32_t)));
             }
-            if (cap) CHK(hipMalloc(&S.spec_queue, cap * sizeof(uint32_t)));
+            if (cfg->speculative_levels) {
+                const uint32_t ns = cfg->speculative_levels;
+                R.spec_out.assign(ns, nullptr);
+                size_t cap = 0;
+                for (uint32_t l = 0; l < ns; l++) {
+                    const Level& L = c->levels[l];
+                    cap += L.queue_cap;
+                    if (l > 0) {
+                        const size_t npix = (size_t)L.w * (size_t)L.h;
+                        CHK(hipMalloc(&R.spec_out[l], npix * sizeof(float4)));
+                        CHK(hipMemset(R.spec_out[l], 0xFF, npix * sizeof(float4)));
+                    }
+                }
+                if (cap) CHK(hipMalloc(&R.spec_queue, cap * sizeof(uint32_t)));
+            }
+            if (c->out_bytes) {
+                CHK(hipMalloc(&R.own_out, c->out_bytes));
+                CHK(hipMemset(R.own_out, 0xFF, c->out_bytes));
+            }
+            R.out = R.own_out;
         }
-        if (c->out_bytes) {
-            CHK(hipMalloc(&S.own_out, c->out_bytes));
-            CHK(hipMemset(S.own_out, 0xFF, c->out_bytes));
-        }
-        S.out = S.own_out;
-        CHK(hipMalloc(&S.d_qctl, 2 * BHRAY_MAX_LEVELS * sizeof(uint32_t)));
-        CHK(hipMemset(S.d_qctl, 0, 2 * BHRAY_MAX_LEVELS * sizeof(uint32_t)));
-        CHK(hipMalloc(&S.d_counters, BHRAY_MAX_LEVELS * sizeof(Counters64)));
-        CHK(hipMemset(S.d_counters, 0, BHRAY_MAX_LEVELS * sizeof(Counters64)));
     }
     if (cfg->flags & BHRAY_F_TIMING) {
         c->events.assign((size_t)BHRAY_TIMING_RING * (nl * 3 + 2), nullptr);
@@ -416,6 +460,7 @@ int bhray_set_texture(bhray_ctx* c, int slot, const uint8_t* rgba8, uint32_t w, 
     if (!c) return BHRAY_E_INVALID;
     if (slot < 0 || slot > 2 || !rgba8 || w < 1 || h < 1 || w > 32768 || h > 32768) return fail(c, BHRAY_E_INVALID, "bad texture arguments");
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc = launch_batch(c); if (rc) return rc; }          // staged frames hold the old texture's address
     HIPCHK(c, sync_all(c));
     uint8_t* d = nullptr;
     const size_t bytes = (size_t)w * h * 4;
@@ -455,6 +500,7 @@ int bhray_upload_model(bhray_ctx* c, uint32_t mi, const bhray_model_desc* d) {
         }
     }
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc = launch_batch(c); if (rc) return rc; }          // staged frames hold the old model's addresses
     HIPCHK(c, sync_all(c));
     ModelStore& m = c->models[mi];
     free_model(m);
@@ -567,33 +613,40 @@ int bhray_set_uniforms(bhray_ctx* c, const void* cam32, const void* bh132, const
     return BHRAY_OK;
 }
 
-int bhray_render(bhray_ctx* c) {
-    if (!c) return BHRAY_E_INVALID;
-    if (!c->have_uniforms) return fail(c, BHRAY_E_STATE, "bhray_set_uniforms has not been called");
+// Enqueues every launch of the batch staged in the current slot: one argument block (FrameParams + per-launch FrameLaunch
+// arrays) copied to the device, then the same launch sequence a single frame needs, each launch covering all staged frames.
+namespace {
+int launch_batch(bhray_ctx* c) {
+    Slot& S = c->slots[(size_t)(c->batch_counter % c->slots.size())];
+    const uint32_t nb = S.pending;
+    if (nb == 0) return BHRAY_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    FrameParams P;
-    derive_frame(c, P);
     const uint32_t nl = c->cfg.levels;
     const bool count = (c->cfg.flags & BHRAY_F_COUNTERS) != 0, timing = (c->cfg.flags & BHRAY_F_TIMING) != 0;
-    const int si = (int)(c->frame_counter % c->slots.size());
-    Slot& S = c->slots[(size_t)si];
     hipStream_t st = S.stream;
-    if (c->wait_pending) { HIPCHK(c, hipStreamWaitEvent(st, c->wait_ev, 0)); c->wait_pending = false; }
-    S.out = c->bound_out ? c->bound_out : S.own_out;
-    HIPCHK(c, hipMemsetAsync(S.d_qctl, 0, 2 * BHRAY_MAX_LEVELS * sizeof(uint32_t), st));
-    if (count) HIPCHK(c, hipMemsetAsync(S.d_counters, 0, BHRAY_MAX_LEVELS * sizeof(Counters64), st));
-    hipEvent_t* fev = timing ? &c->events[(size_t)(c->frame_counter % BHRAY_TIMING_RING) * (nl * 3 + 2)] : nullptr;
-    S.frame_id = c->frame_counter;
-    if (timing) c->sky_recorded[c->frame_counter % BHRAY_TIMING_RING] = 0;
-    // Persistent trace grid: (resident blocks per CU) x CUs.  With several frames in flight each launch takes only
-    // half of the block slots: the kernels of the other frames fill the rest, and a wave of a half-size grid pulls
+    const uint32_t B = c->batch;
+    const FrameParams* dP = (const FrameParams*)S.d_args;
+    size_t args_used = (size_t)B * sizeof(FrameParams);
+    // argument block of the next launch: nb FrameLaunch entries on the host, and their device address
+    auto next_launch = [&](FrameLaunch*& h, const FrameLaunch*& d) {
+        h = (FrameLaunch*)(S.h_args + args_used); d = (const FrameLaunch*)(S.d_args + args_used);
+        args_used += (size_t)nb * sizeof(FrameLaunch);
+        memset(h, 0, (size_t)nb * sizeof(FrameLaunch));
+    };
+    struct Launch { int kind; const FrameLaunch* d; int blocks; bool count; std::vector<int> ev_before, ev_after; };   // kind 0 classify, 1 trace; timing events recorded around it
+    std::vector<Launch> seq;
+    // Persistent trace grid: (resident blocks per CU) x CUs.  With several batches in flight each launch takes only
+    // half of the block slots: the kernels of the other batches fill the rest, and a wave of a half-size grid pulls
     // more than one load of rays, so the refill keeps its lanes busy (+4 % at 16 slots).
-    int bpc = trace_blocks_per_cu(P.method, P.model_count > 0, count);
-    if (c->slots.size() > 1 && bpc > 1) bpc = bpc / 2 > 1 ? bpc / 2 : 1;     // measured: 2 of 4 blocks per CU is best at 8-16 slots
+    // Register budget of the no-mesh trace kernel (bhray_kernels.hip): the dense build when the device is saturated with
+    // rays - a whole frame per ctx and several batches in flight - otherwise the latency build (measured on MI355X:
+    // 1920x1080, 16 slots: 3340 vs 3210 Mrays/s; one slot: 2.13 vs 1.95 ms per frame; 1/8 row tile: 0.106 vs 0.101 ms).
+    const bool dense = c->dense_override >= 0 ? c->dense_override != 0 : (c->slots.size() >= 4 && c->cfg.row_world == 1);
+    int bpc = trace_blocks_per_cu(S.method, S.models, count, dense);
+    if (c->slots.size() > 1 && bpc > 1) bpc = bpc > 4 ? 2 : (bpc / 2 > 1 ? bpc / 2 : 1);     // measured: 2 blocks per CU is best at 8-16 slots
     if (c->bpc_override > 0) bpc = c->bpc_override;
     const int grid = c->num_cus * bpc;
-    SpecLevels none; memset(&none, 0, sizeof none);
-    auto level_params = [&](uint32_t l, LevelParams& L) {
+    auto level_params = [&](const FrameRes& R, uint32_t l, LevelParams& L) {
         const Level& Lv = c->levels[l];
         const bool last = (l == nl - 1);
         memset(&L, 0, sizeof L);
@@ -601,71 +654,142 @@ int bhray_render(bhray_ctx* c) {
         if (l == 0) { L.pw = 1; L.ph = 1; L.rx = 1.0f; L.ry = 1.0f; L.prev = nullptr; }
         else {
             const Level& Pv = c->levels[l - 1];
-            L.pw = Pv.w; L.ph = Pv.h; L.prev = S.level_out[l - 1];
+            L.pw = Pv.w; L.ph = Pv.h; L.prev = R.level_out[l - 1];
             const int sfx = (L.w - 1) / (L.pw - 1), sfy = (L.h - 1) / (L.ph - 1);          // ray.wgsl:185
             L.rx = (float)L.pw / (float)(L.w + (sfx - 1)); L.ry = (float)L.ph / (float)(L.h + (sfy - 1));   // ray.wgsl:187
         }
         if (last) {
-            L.out = S.out; L.out_pitch = (int)c->cfg.frame_w; L.out_x0 = (int)c->cfg.crop_x; L.rowmap = Lv.d_rowmap;
+            L.out = R.out; L.out_pitch = (int)c->cfg.frame_w; L.out_x0 = (int)c->cfg.crop_x; L.rowmap = Lv.d_rowmap;
             L.x0 = (int)c->cfg.crop_x; L.x1 = (int)(c->cfg.crop_x + c->cfg.frame_w);
         } else {
-            L.out = S.level_out[l]; L.out_pitch = Lv.w; L.out_x0 = 0; L.rowmap = nullptr; L.x0 = 0; L.x1 = Lv.w;
+            L.out = R.level_out[l]; L.out_pitch = Lv.w; L.out_x0 = 0; L.rowmap = nullptr; L.x0 = 0; L.x1 = Lv.w;
         }
         L.rows = Lv.d_rows; L.nrows = (int)Lv.rows.size();
     };
+    auto classify_blocks = [&](uint32_t l) {
+        const Level& Lv = c->levels[l];
+        const int span = (l == nl - 1) ? (int)c->cfg.frame_w : Lv.w;
+        const int tiles = ((span + 7) / 8) * (((int)Lv.rows.size() + 7) / 8);
+        return (tiles + 3) / 4;
+    };
     const uint32_t ns = c->cfg.speculative_levels;
     uint32_t first_normal = 0;
-    if (ns) {
+    const bool any_rows = !c->levels[nl - 1].rows.empty();    // a partition without rows has nothing to launch (then no level has rows)
+    if (ns && any_rows) {
         // (1) every needed pixel of levels 0..ns-1 into ONE level-tagged queue, (2) one trace launch over it,
         // (3) classify levels 1..ns-1 against the traced images.  Queue control words of level 0 serve the merged queue.
-        uint32_t* qcount = S.d_qctl; uint32_t* qhead = qcount + 1;
-        SpecLevels SL; memset(&SL, 0, sizeof SL);
-        SL.n = (int)ns;
-        if (timing) HIPCHK(c, hipEventRecord(fev[0], st));
         for (uint32_t l = 0; l < ns; l++) {
-            const Level& Lv = c->levels[l];
-            SL.l[l].w = Lv.w; SL.l[l].h = Lv.h; SL.l[l].out = (l == 0) ? S.level_out[0] : S.spec_out[l]; SL.l[l].out_pitch = Lv.w;
-            if (Lv.rows.empty()) continue;
-            LevelParams L; level_params(l, L);
-            L.pw = 1; L.ph = 1; L.prev = nullptr; L.tag = (int)l;                            // "base case": every pixel is traced
-            HIPCHK(c, launch_classify(P, L, S.spec_queue, qcount, nullptr, st));
-        }
-        if (timing) HIPCHK(c, hipEventRecord(fev[1], st));
-        LevelParams L0; level_params(0, L0);
-        HIPCHK(c, launch_trace(P, L0, SL, S.spec_queue, qcount, qhead, count ? S.d_counters : nullptr, c->d_err, grid, st));
-        if (timing) HIPCHK(c, hipEventRecord(fev[2], st));
-        for (uint32_t l = 1; l < ns; l++) {
-            if (timing) HIPCHK(c, hipEventRecord(fev[3 * l + 0], st));
-            if (!c->levels[l].rows.empty()) {
-                LevelParams L; level_params(l, L);
-                L.spec = S.spec_out[l];
-                HIPCHK(c, launch_classify(P, L, nullptr, S.d_qctl + 2 * l, count ? S.d_counters + l : nullptr, st));
+            FrameLaunch* h; const FrameLaunch* d; next_launch(h, d);
+            for (uint32_t k = 0; k < nb; k++) {
+                const FrameRes& R = S.fr[k];
+                level_params(R, l, h[k].L);
+                h[k].L.pw = 1; h[k].L.ph = 1; h[k].L.prev = nullptr; h[k].L.tag = (int)l;    // "base case": every pixel is traced
+                h[k].queue = R.spec_queue; h[k].qctl = R.d_qctl; h[k].counters = nullptr;
             }
-            if (timing) { HIPCHK(c, hipEventRecord(fev[3 * l + 1], st)); HIPCHK(c, hipEventRecord(fev[3 * l + 2], st)); }
+            seq.push_back({0, d, classify_blocks(l), false, {}, {}});
+            if (l == 0) seq.back().ev_before = {0};
+            if (l == ns - 1) seq.back().ev_after = {1};
+        }
+        {
+            FrameLaunch* h; const FrameLaunch* d; next_launch(h, d);
+            for (uint32_t k = 0; k < nb; k++) {
+                const FrameRes& R = S.fr[k];
+                level_params(R, 0, h[k].L);
+                h[k].SL.n = (int)ns;
+                for (uint32_t l = 0; l < ns; l++) {
+                    const Level& Lv = c->levels[l];
+                    h[k].SL.l[l].w = Lv.w; h[k].SL.l[l].h = Lv.h; h[k].SL.l[l].out = (l == 0) ? R.level_out[0] : R.spec_out[l]; h[k].SL.l[l].out_pitch = Lv.w;
+                }
+                h[k].queue = R.spec_queue; h[k].qctl = R.d_qctl; h[k].counters = count ? R.d_counters : nullptr;
+            }
+            seq.push_back({1, d, grid, count, {}, {2}});
+        }
+        for (uint32_t l = 1; l < ns; l++) {
+            FrameLaunch* h; const FrameLaunch* d; next_launch(h, d);
+            for (uint32_t k = 0; k < nb; k++) {
+                const FrameRes& R = S.fr[k];
+                level_params(R, l, h[k].L);
+                h[k].L.spec = R.spec_out[l];
+                h[k].queue = nullptr; h[k].qctl = R.d_qctl + 2 * l; h[k].counters = count ? R.d_counters + l : nullptr;
+            }
+            seq.push_back({0, d, classify_blocks(l), count, {(int)(3 * l)}, {(int)(3 * l + 1), (int)(3 * l + 2)}});   // no trace launch of its own
         }
         first_normal = ns;
     }
-    for (uint32_t l = first_normal; l < nl; l++) {
-        Level& Lv = c->levels[l];
-        if (Lv.rows.empty()) continue;
-        LevelParams L; level_params(l, L);
-        uint32_t* qcount = S.d_qctl + 2 * l; uint32_t* qhead = qcount + 1;
-        if (timing) HIPCHK(c, hipEventRecord(fev[3 * l + 0], st));
-        HIPCHK(c, launch_classify(P, L, S.queue[l], qcount, count ? S.d_counters + l : nullptr, st));
-        if (timing) HIPCHK(c, hipEventRecord(fev[3 * l + 1], st));
-        HIPCHK(c, launch_trace(P, L, none, S.queue[l], qcount, qhead, count ? S.d_counters + l : nullptr, c->d_err, grid, st));
-        if (timing) HIPCHK(c, hipEventRecord(fev[3 * l + 2], st));
+    for (uint32_t l = first_normal; l < nl && any_rows; l++) {
+        FrameLaunch* h; const FrameLaunch* d; next_launch(h, d);
+        for (uint32_t k = 0; k < nb; k++) {
+            const FrameRes& R = S.fr[k];
+            level_params(R, l, h[k].L);
+            h[k].queue = R.queue[l]; h[k].qctl = R.d_qctl + 2 * l; h[k].counters = count ? R.d_counters + l : nullptr;
+        }
+        seq.push_back({0, d, classify_blocks(l), count, {(int)(3 * l)}, {(int)(3 * l + 1)}});
+        seq.push_back({1, d, grid, count, {}, {(int)(3 * l + 2)}});
+    }
+    if (args_used > S.args_cap) return fail(c, BHRAY_E_STATE, "internal: argument block overflow");
+    // enqueue
+    HIPCHK(c, launch_upload(S.h_args, S.d_args, (args_used + 15) / 16, st));
+    HIPCHK(c, hipEventRecord(S.uploaded, st));
+    HIPCHK(c, hipMemsetAsync(S.d_qctl, 0, (size_t)nb * 2 * BHRAY_MAX_LEVELS * sizeof(uint32_t), st));
+    if (count) HIPCHK(c, hipMemsetAsync(S.d_counters, 0, (size_t)nb * BHRAY_MAX_LEVELS * sizeof(Counters64), st));
+    const size_t ring = (size_t)(c->batch_counter % BHRAY_TIMING_RING);
+    hipEvent_t* fev = timing ? &c->events[ring * (nl * 3 + 2)] : nullptr;
+    if (timing) { c->sky_recorded[ring] = 0; c->ring_frames[ring] = (uint8_t)nb; }
+    for (const Launch& Ln : seq) {
+        if (timing) for (int e : Ln.ev_before) HIPCHK(c, hipEventRecord(fev[e], st));
+        if (Ln.kind == 0) HIPCHK(c, launch_classify(dP, Ln.d, (int)nb, Ln.blocks, Ln.count, st));
+        else HIPCHK(c, launch_trace(dP, Ln.d, (int)nb, S.method, S.models, Ln.count, dense, c->d_err, Ln.blocks, st));
+        if (timing) for (int e : Ln.ev_after) HIPCHK(c, hipEventRecord(fev[e], st));
     }
     HIPCHK(c, hipEventRecord(S.done, st));
-    c->last_slot = si;
+    S.used = true;
+    S.batch_id = c->batch_counter;
+    S.pending = 0;
+    c->batch_counter++;
+    return BHRAY_OK;
+}
+}  // namespace
+
+int bhray_flush(bhray_ctx* c) {
+    if (!c) return BHRAY_E_INVALID;
+    return launch_batch(c);
+}
+
+int bhray_render(bhray_ctx* c) {
+    if (!c) return BHRAY_E_INVALID;
+    if (!c->have_uniforms) return fail(c, BHRAY_E_STATE, "bhray_set_uniforms has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    FrameParams P;
+    derive_frame(c, P);
+    {   // a batch runs one kernel variant: launch what is staged if this frame needs another
+        Slot& S0 = c->slots[(size_t)(c->batch_counter % c->slots.size())];
+        if (S0.pending > 0 && (S0.method != P.method || S0.models != (P.model_count > 0))) { int rc = launch_batch(c); if (rc) return rc; }
+    }
+    const int si = (int)(c->batch_counter % c->slots.size());
+    Slot& S = c->slots[(size_t)si];
+    if (S.pending == 0) {
+        // the slot's previous argument block must have reached the device before the pinned copy is rewritten
+        if (S.used && hipEventQuery(S.uploaded) != hipSuccess) HIPCHK(c, hipEventSynchronize(S.uploaded));
+        S.method = P.method; S.models = P.model_count > 0;
+    }
+    if (c->wait_pending) { HIPCHK(c, hipStreamWaitEvent(S.stream, c->wait_ev, 0)); c->wait_pending = false; }
+    const uint32_t k = S.pending;
+    FrameRes& R = S.fr[k];
+    ((FrameParams*)S.h_args)[k] = P;
+    R.out = c->bound_out ? c->bound_out : R.own_out;
+    R.frame_id = c->frame_counter;
+    S.pending = k + 1;
+    c->last_slot = si; c->last_sub = (int)k;
     c->rendered = true;
     c->frame_counter++;
+    if (S.pending == c->batch) return launch_batch(c);
     return BHRAY_OK;
 }
 
 int bhray_sync(bhray_ctx* c) {
     if (!c) return BHRAY_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc = launch_batch(c); if (rc) return rc; }
     HIPCHK(c, sync_all(c));
     if (c->rendered) {
         int e = 0;
@@ -693,7 +817,7 @@ int bhray_read_hdr(bhray_ctx* c, float* dst, size_t pitch) {
     if (!dst || pitch < rowb) return fail(c, BHRAY_E_INVALID, "bad destination / pitch");
     int rc = bhray_sync(c);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpy2D(dst, pitch, c->slots[(size_t)c->last_slot].out, rowb, rowb, c->local_rows.size(), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy2D(dst, pitch, c->slots[(size_t)c->last_slot].fr[(size_t)c->last_sub].out, rowb, rowb, c->local_rows.size(), hipMemcpyDeviceToHost));
     return BHRAY_OK;
 }
 
@@ -706,14 +830,14 @@ int bhray_read_level(bhray_ctx* c, uint32_t level, float* dst, size_t pitch) {
     int rc = bhray_sync(c);
     if (rc) return rc;
     if (level + 1 < c->cfg.levels) {
-        HIPCHK(c, hipMemcpy2D(dst, pitch, c->slots[(size_t)c->last_slot].level_out[level], rowb, rowb, (size_t)L.h, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy2D(dst, pitch, c->slots[(size_t)c->last_slot].fr[(size_t)c->last_sub].level_out[level], rowb, rowb, (size_t)L.h, hipMemcpyDeviceToHost));
         return BHRAY_OK;
     }
     // last level: scatter the packed window back into a NaN canvas of the full level size
     for (int y = 0; y < L.h; y++) memset((uint8_t*)dst + (size_t)y * pitch, 0xFF, rowb);
     const size_t frb = (size_t)c->cfg.frame_w * sizeof(float4);
     std::vector<uint8_t> tmp(c->local_rows.size() * frb);
-    if (!tmp.empty()) HIPCHK(c, hipMemcpy(tmp.data(), c->slots[(size_t)c->last_slot].out, tmp.size(), hipMemcpyDeviceToHost));
+    if (!tmp.empty()) HIPCHK(c, hipMemcpy(tmp.data(), c->slots[(size_t)c->last_slot].fr[(size_t)c->last_sub].out, tmp.size(), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < c->local_rows.size(); i++) {
         uint8_t* row = (uint8_t*)dst + (size_t)(c->cfg.crop_y + c->local_rows[i]) * pitch + (size_t)c->cfg.crop_x * sizeof(float4);
         memcpy(row, tmp.data() + i * frb, frb);
@@ -723,7 +847,7 @@ int bhray_read_level(bhray_ctx* c, uint32_t level, float* dst, size_t pitch) {
 
 int bhray_hdr_device_ptr(bhray_ctx* c, void** p, size_t* bytes) {
     if (!c || !p) return BHRAY_E_INVALID;
-    *p = c->slots[(size_t)c->last_slot].out; if (bytes) *bytes = c->out_bytes;
+    *p = c->slots[(size_t)c->last_slot].fr[(size_t)c->last_sub].out; if (bytes) *bytes = c->out_bytes;
     return BHRAY_OK;
 }
 
@@ -740,15 +864,18 @@ int bhray_resolve_sky(bhray_ctx* c) {
     if (!c) return BHRAY_E_INVALID;
     if (!c->rendered) return fail(c, BHRAY_E_STATE, "nothing rendered yet");
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc = launch_batch(c); if (rc) return rc; }
     Slot& S = c->slots[(size_t)c->last_slot];
+    FrameRes& R = S.fr[(size_t)c->last_sub];
     const size_t npix = c->local_rows.size() * (size_t)c->cfg.frame_w;
-    if (!S.sky_out && npix) HIPCHK(c, hipMalloc(&S.sky_out, npix * sizeof(uint2)));
+    if (!R.sky_out && npix) HIPCHK(c, hipMalloc(&R.sky_out, npix * sizeof(uint2)));
     TexDev sky; sky.rgba = c->tex[BHRAY_TEX_SKY]; sky.w = c->tex_w[BHRAY_TEX_SKY]; sky.h = c->tex_h[BHRAY_TEX_SKY];
     const bool timing = (c->cfg.flags & BHRAY_F_TIMING) != 0;
-    hipEvent_t* ev = timing ? &c->events[(size_t)(S.frame_id % BHRAY_TIMING_RING) * (c->cfg.levels * 3 + 2) + c->cfg.levels * 3] : nullptr;
+    const size_t ring = (size_t)(S.batch_id % BHRAY_TIMING_RING);
+    hipEvent_t* ev = timing ? &c->events[ring * (c->cfg.levels * 3 + 2) + c->cfg.levels * 3] : nullptr;
     if (timing) HIPCHK(c, hipEventRecord(ev[0], S.stream));
-    HIPCHK(c, launch_sky(sky, S.out, S.sky_out, npix, S.stream));
-    if (timing) { HIPCHK(c, hipEventRecord(ev[1], S.stream)); c->sky_recorded[S.frame_id % BHRAY_TIMING_RING] = 1; }
+    HIPCHK(c, launch_sky(sky, R.out, R.sky_out, npix, S.stream));
+    if (timing) { HIPCHK(c, hipEventRecord(ev[1], S.stream)); c->sky_recorded[ring] = 1; }
     HIPCHK(c, hipEventRecord(S.done, S.stream));
     return BHRAY_OK;
 }
@@ -758,7 +885,7 @@ int bhray_read_sky(bhray_ctx* c, uint16_t* dst, size_t pitch) {
     const size_t rowb = (size_t)c->cfg.frame_w * sizeof(uint2);
     if (c->local_rows.empty()) return bhray_sync(c);
     if (!dst || pitch < rowb) return fail(c, BHRAY_E_INVALID, "bad destination / pitch");
-    Slot& S = c->slots[(size_t)c->last_slot];
+    FrameRes& S = c->slots[(size_t)c->last_slot].fr[(size_t)c->last_sub];
     if (!S.sky_out) return fail(c, BHRAY_E_STATE, "bhray_resolve_sky has not been called for this frame");
     int rc = bhray_sync(c);
     if (rc) return rc;
@@ -769,7 +896,7 @@ int bhray_read_sky(bhray_ctx* c, uint16_t* dst, size_t pitch) {
 
 int bhray_sky_device_ptr(bhray_ctx* c, void** p, size_t* bytes) {
     if (!c || !p) return BHRAY_E_INVALID;
-    *p = c->slots[(size_t)c->last_slot].sky_out;
+    *p = c->slots[(size_t)c->last_slot].fr[(size_t)c->last_sub].sky_out;
     if (bytes) *bytes = c->local_rows.size() * (size_t)c->cfg.frame_w * sizeof(uint2);
     return BHRAY_OK;
 }
@@ -784,7 +911,7 @@ int bhray_wait_stream(bhray_ctx* c, void* s) {
 
 int bhray_next_stream(bhray_ctx* c, void** s) {
     if (!c || !s) return BHRAY_E_INVALID;
-    *s = (void*)c->slots[(size_t)(c->frame_counter % c->slots.size())].stream;
+    *s = (void*)c->slots[(size_t)(c->batch_counter % c->slots.size())].stream;
     return BHRAY_OK;
 }
 
@@ -792,6 +919,7 @@ int bhray_signal_stream(bhray_ctx* c, void* s) {
     if (!c) return BHRAY_E_INVALID;
     if (!c->rendered) return BHRAY_OK;
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc = launch_batch(c); if (rc) return rc; }
     HIPCHK(c, hipStreamWaitEvent((hipStream_t)s, c->slots[(size_t)c->last_slot].done, 0));
     return BHRAY_OK;
 }
@@ -803,7 +931,7 @@ int bhray_get_level_counters(bhray_ctx* c, uint32_t level, bhray_counters* out) 
     int rc = bhray_sync(c);
     if (rc) return rc;
     static_assert(sizeof(bhray_counters) == sizeof(Counters64), "counter layout");
-    HIPCHK(c, hipMemcpy(out, c->slots[(size_t)c->last_slot].d_counters + level, sizeof(Counters64), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out, c->slots[(size_t)c->last_slot].fr[(size_t)c->last_sub].d_counters + level, sizeof(Counters64), hipMemcpyDeviceToHost));
     return BHRAY_OK;
 }
 
@@ -828,10 +956,11 @@ int bhray_get_timing(bhray_ctx* c, bhray_timing* out) {
     memset(out, 0, sizeof *out);
     const uint32_t nl = c->cfg.levels;
     uint64_t begin = c->timing_begin;
-    if (c->frame_counter - begin > BHRAY_TIMING_RING) begin = c->frame_counter - BHRAY_TIMING_RING;
-    for (uint64_t f = begin; f < c->frame_counter; f++) {
-        hipEvent_t* ev = &c->events[(size_t)(f % BHRAY_TIMING_RING) * (nl * 3 + 2)];
-        if (c->sky_recorded[f % BHRAY_TIMING_RING]) {
+    if (c->batch_counter - begin > BHRAY_TIMING_RING) begin = c->batch_counter - BHRAY_TIMING_RING;
+    for (uint64_t f = begin; f < c->batch_counter; f++) {
+        const size_t ring = (size_t)(f % BHRAY_TIMING_RING);
+        hipEvent_t* ev = &c->events[ring * (nl * 3 + 2)];
+        if (c->sky_recorded[ring]) {
             float t = 0; HIPCHK(c, hipEventElapsedTime(&t, ev[3 * nl], ev[3 * nl + 1])); out->sky_ms += t; out->sky_launches++;
         }
         hipEvent_t first = nullptr, last = nullptr;
@@ -847,9 +976,10 @@ int bhray_get_timing(bhray_ctx* c, bhray_timing* out) {
             last = ev[3 * l + 2];
         }
         if (first && last) { float t = 0; HIPCHK(c, hipEventElapsedTime(&t, first, last)); out->total_ms += t; }
-        out->frames++;
+        out->frames += c->ring_frames[ring];
+        out->batches++;
     }
-    c->timing_begin = c->frame_counter;
+    c->timing_begin = c->batch_counter;
     return BHRAY_OK;
 }
 

@@ -25,7 +25,8 @@ struct ModelDev {
     int node_count;
 };
 
-// Everything that is uniform over a frame.  Passed by value (kernarg → SGPRs).
+// Everything that is uniform over a frame.  Lives in HBM (one entry per frame of a batch); the address is wave-uniform,
+// so the members are fetched with scalar loads into SGPRs.
 // Derived members are computed on the host with the SAME binary32 operation sequence the shader
 // performs per pixel (ray.wgsl:270-281, 488, 511), so hoisting them cannot change a bit.
 struct FrameParams {
@@ -80,12 +81,24 @@ struct SpecLevels { int n; SpecLevel l[BHRAY_MAX_SPEC_LEVELS]; };   // n == 0: o
 
 struct Counters64 { unsigned long long v[10]; };   // order = bhray_counters
 
-// launchers (bhray_kernels.hip)
-hipError_t launch_classify(const FrameParams& P, const LevelParams& L, uint32_t* queue, uint32_t* qcount,
-                           Counters64* counters, hipStream_t s);
-hipError_t launch_trace(const FrameParams& P, const LevelParams& L, const SpecLevels& SL, const uint32_t* queue, const uint32_t* qcount,
-                        uint32_t* qhead, Counters64* counters, int* err_flag, int grid_blocks, hipStream_t s);
-int trace_blocks_per_cu(int method, int has_models, int count);
+// One frame's share of one launch.  A launch covers the `nb` frames of a batch: classify uses blockIdx.y as the frame
+// index, the persistent trace blocks start on frame blockIdx.x % nb and move on to the other frames when theirs runs dry.
+struct FrameLaunch {
+    LevelParams L;
+    SpecLevels SL;
+    uint32_t* queue;       // ray queue of this frame and level(s)
+    uint32_t* qctl;        // [0] entries appended (classify), [1] entries taken (trace)
+    Counters64* counters;  // nullptr unless BHRAY_F_COUNTERS
+};
+
+// launchers (bhray_kernels.hip); Pb / Fb are device arrays of nb entries
+hipError_t launch_classify(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int blocks, bool count, hipStream_t s);
+hipError_t launch_trace(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int method, bool models, bool count, bool dense, int* err_flag,
+                        int grid_blocks, hipStream_t s);
+int trace_blocks_per_cu(int method, int has_models, int count, int dense);
+// copies n16 16-byte words from pinned host memory to device memory with a kernel (stays on the compute queue: a DMA copy
+// between the launches of a stream costs a cross-engine handshake each time)
+hipError_t launch_upload(const void* pinned_src, void* dst, size_t n16, hipStream_t s);
 hipError_t launch_sky(const TexDev& sky, const float4* src, uint2* dst_rgba16f, size_t npix, hipStream_t s);
 
 }  // namespace bhray

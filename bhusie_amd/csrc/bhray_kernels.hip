@@ -100,11 +100,41 @@ __device__ __forceinline__ bool hit_torus2d(F3 pos, F3 dir, float inner, float o
     return false;
 }
 
+// Frame uniforms read inside the integrator step loop.  FrameParams lives in HBM and is read with scalar loads; a load that
+// sits behind a branch (disk shading, sphere exit) cannot be hoisted by the compiler - the pointer is not known to be
+// dereferenceable - and an s_load + s_waitcnt inside the loop is fully exposed when a wave runs alone on its SIMD (+10-20 %
+// per coarse-level launch).  The loop's operands are therefore loaded once per frame and pinned in SGPRs.
+struct HotParams {
+    F3 bh, bn;
+    float bn_dot_bh, bn_len, inner, outer, R, ray_distance, feather, rot_speed, time;
+    int max_iter, show_tex, show_shift;
+    float M[9];
+    TexDev disk, temp;
+};
+__device__ __forceinline__ float pin_sgpr(float v) { asm volatile("" : "+s"(v)); return v; }
+__device__ __forceinline__ int pin_sgpr(int v) { asm volatile("" : "+s"(v)); return v; }
+__device__ __forceinline__ const uint8_t* pin_sgpr(const uint8_t* v) { asm volatile("" : "+s"(v)); return v; }
+__device__ __forceinline__ TexDev pin_sgpr(const TexDev& t) { TexDev r; r.rgba = pin_sgpr(t.rgba); r.w = pin_sgpr(t.w); r.h = pin_sgpr(t.h); return r; }
+__device__ __forceinline__ HotParams load_hot(const FrameParams& P) {
+    HotParams H;
+    H.bh = f3(pin_sgpr(P.bh[0]), pin_sgpr(P.bh[1]), pin_sgpr(P.bh[2]));
+    H.bn = f3(pin_sgpr(P.bn[0]), pin_sgpr(P.bn[1]), pin_sgpr(P.bn[2]));
+    H.bn_dot_bh = pin_sgpr(P.bn_dot_bh); H.bn_len = pin_sgpr(P.bn_len);
+    H.inner = pin_sgpr(P.inner); H.outer = pin_sgpr(P.outer); H.R = pin_sgpr(P.R);
+    H.ray_distance = pin_sgpr(P.ray_distance); H.feather = pin_sgpr(P.feather);
+    H.rot_speed = pin_sgpr(P.rot_speed); H.time = pin_sgpr(P.time);
+    H.max_iter = pin_sgpr(P.max_iter); H.show_tex = pin_sgpr(P.show_tex); H.show_shift = pin_sgpr(P.show_shift);
+#pragma unroll
+    for (int k = 0; k < 9; k++) H.M[k] = pin_sgpr(P.M[k]);
+    H.disk = pin_sgpr(P.disk); H.temp = pin_sgpr(P.temp);
+    return H;
+}
+
 // Disk shading, ray.wgsl:612-663 (the part of hit_black_hole after the disk won).
 template <bool COUNT>
-__device__ __forceinline__ void shade_disk(const FrameParams& P, F3 pos, F3 dir, float t, float total_distance, Hit& rs,
+__device__ __forceinline__ void shade_disk(const HotParams& P, F3 pos, F3 dir, float t, float total_distance, Hit& rs,
                                         unsigned long long* cnt) {
-    F3 bpos = ld3(P.bh);
+    F3 bpos = P.bh;
     F3 ip = pos + dir * t;
     float dist = distance(bpos, ip);
     float density = 1.0f - length(div_s(ip, P.outer));
@@ -159,22 +189,22 @@ __device__ __forceinline__ void shade_disk(const FrameParams& P, F3 pos, F3 dir,
 // position (`pos_dist`, within a few ulp of the literal |oc|, far inside the margins), and the plane distance is
 // n.b - n.pos with the constant n.b from the host.
 template <bool COUNT>
-__device__ __forceinline__ void hit_black_hole(const FrameParams& P, F3 pos, F3 dir, float pos_dist, float t_min, float t_max,
+__device__ __forceinline__ void hit_black_hole(const FrameParams& P, const HotParams& H, F3 pos, F3 dir, float pos_dist, float t_min, float t_max,
                                                float total_distance, Hit& rs, unsigned long long* cnt) {
-    const F3 bpos = ld3(P.bh);
+    const F3 bpos = H.bh;
     const float reach = 1.05f * t_max + 0.05f;
     float ts = t_max, td = t_max;
     bool hs = false, hd = false;
     if (pos_dist <= 1.0f + reach) hs = hit_sphere(pos, dir, 1.0f, bpos, t_min, t_max, ts);
-    if (pos_dist <= P.outer + reach) {
-        const F3 bn = ld3(P.bn);
-        const float numer = P.bn_dot_bh - fdot(pos, bn);
-        if (fabsf(numer) <= (1.01f * t_max) * P.bn_len + 1e-4f * P.bn_len) hd = hit_torus2d(pos, dir, P.inner, P.outer, bpos, bn, t_min, t_max, td);
+    if (pos_dist <= H.outer + reach) {
+        const F3 bn = H.bn;
+        const float numer = H.bn_dot_bh - fdot(pos, bn);
+        if (fabsf(numer) <= (1.01f * t_max) * H.bn_len + 1e-4f * H.bn_len) hd = hit_torus2d(pos, dir, H.inner, H.outer, bpos, bn, t_min, t_max, td);
     }
     rs.hit = hs; rs.t = hs ? ts : t_max; rs.color = f3(0.0f, 0.0f, 0.0f); rs.opacity = hs ? 1.0f : 0.0f;
     if (hd && td < rs.t) {
         rs.hit = true; rs.t = td;
-        shade_disk<COUNT>(P, pos, dir, td, total_distance, rs, cnt);
+        shade_disk<COUNT>(H, pos, dir, td, total_distance, rs, cnt);
     }
 }
 
@@ -356,8 +386,13 @@ __device__ __forceinline__ size_t out_index(const LevelParams& L, int x, int y) 
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(256) void classify_kernel(const FrameParams P, const LevelParams L, uint32_t* __restrict__ queue,
-                                                       uint32_t* __restrict__ qcount, Counters64* __restrict__ counters) {
+__global__ __launch_bounds__(256) void classify_kernel(const FrameParams* __restrict__ Pb, const FrameLaunch* __restrict__ Fb) {
+    const FrameParams& P = Pb[blockIdx.y];
+    const FrameLaunch& F = Fb[blockIdx.y];
+    const LevelParams& L = F.L;
+    uint32_t* __restrict__ queue = F.queue;
+    uint32_t* __restrict__ qcount = F.qctl;
+    Counters64* __restrict__ counters = F.counters;
     // one wave = one 8x8 tile; 4 tiles per block side by side in x
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -441,16 +476,33 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3 };
 #define BHRAY_TRACE_WAVES_MESH 4 // measured on the mesh workload: 3 -> 2190, 4 -> 2487, 2 -> 1746 Mrays/s
 #endif
 #ifndef BHRAY_TRACE_WAVES
-#define BHRAY_TRACE_WAVES 4      // waves per SIMD the trace kernel is register-budgeted for (<=128 VGPRs)
+#define BHRAY_TRACE_WAVES 4      // waves per SIMD the trace kernel is register-budgeted for (<=128 VGPRs): the latency build
+#endif
+// The no-mesh kernel is built twice.  Budgeted for 4 waves per SIMD the compiler uses ~99 VGPRs and keeps more of the step's
+// independent chains in flight: a wave that runs alone on its SIMD (coarse ladder levels, one frame in flight, row tiles of a
+// multi-GPU frame) steps 7-15 % faster.  Budgeted for 6 waves (80 VGPRs, no spills) a saturated device gains 4 % (more
+// co-resident launches).  The host picks per ctx (bhray_api.hip).
+#ifndef BHRAY_TRACE_WAVES_DENSE
+#define BHRAY_TRACE_WAVES_DENSE 6
 #endif
 
-template <int METHOD, bool MODELS, bool COUNT>
-__global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : BHRAY_TRACE_WAVES) void trace_kernel(const FrameParams P, const LevelParams L, const SpecLevels SL, const uint32_t* __restrict__ queue,
-                                                    const uint32_t* __restrict__ qcount_p, uint32_t* __restrict__ qhead,
-                                                    Counters64* __restrict__ counters, int* __restrict__ err_flag) {
+template <int METHOD, bool MODELS, bool COUNT, bool DENSE>
+__global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHRAY_TRACE_WAVES_DENSE : BHRAY_TRACE_WAVES)) void trace_kernel(const FrameParams* __restrict__ Pb, const FrameLaunch* __restrict__ Fb, const int nb, int* __restrict__ err_flag) {
     const int lane = threadIdx.x & 63;
-    const uint32_t qcount = *qcount_p;
-    const F3 bpos = ld3(P.bh);
+    int err = 0;
+    // the frames of the batch, starting with this block's own: a block whose frame has run dry helps with the others
+    for (int fi = 0; fi < nb; fi++) {
+    const int fb = (int)((blockIdx.x + (unsigned)fi) % (unsigned)nb);
+    const FrameParams& P = Pb[fb];
+    const FrameLaunch& F = Fb[fb];
+    const LevelParams& L = F.L;
+    const SpecLevels& SL = F.SL;
+    const uint32_t* __restrict__ queue = F.queue;
+    uint32_t* __restrict__ qhead = F.qctl + 1;
+    Counters64* __restrict__ counters = F.counters;
+    const uint32_t qcount = F.qctl[0];
+    const HotParams H = load_hot(P);
+    const F3 bpos = H.bh;
     const F3 cam = ld3(P.cam);
     const float t_max = 1e5f, t_min = 1e-8f;
 
@@ -461,7 +513,7 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : BHRAY_TRACE_
     F3 rkpos = cam, rkdir = f3(0, 0, 1);
     float rkh = 0.0f;
     F3 color = f3(0, 0, 0);
-    float amount = 1.0f, step = P.step_size, closest = P.ray_distance;
+    float amount = 1.0f, step = P.step_size, closest = H.ray_distance;
     float dist_c = P.ray_distance_f;      // flength(integrator position - bpos) (N7), carried between steps
     float cpos_dist = P.ray_distance_f;   // flength(cpos - bpos): equals dist_c except in RK mode after a hit moved cpos
     int it = 0;
@@ -470,7 +522,6 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : BHRAY_TRACE_
     int flat_round = 0;
     unsigned long long cnt[10];
     if (COUNT) { for (int k = 0; k < 10; k++) cnt[k] = 0; }
-    int err = 0;
 
     for (;;) {
         // ---- refill finished lanes from the queue (wave ballot + prefix popcount)
@@ -502,7 +553,7 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : BHRAY_TRACE_
                     rdir = normalize((ld3(P.right) * posx + ld3(P.up) * posy) + ld3(P.fwd_ff));
                     cpos = cam; cdir = rdir; ppos = cam; pdir = rdir;
                     rkpos = cam; rkdir = rdir; rkh = P.step_size;
-                    color = f3(0, 0, 0); amount = 1.0f; step = P.step_size; closest = P.ray_distance;
+                    color = f3(0, 0, 0); amount = 1.0f; step = P.step_size; closest = H.ray_distance;
                     dist_c = P.ray_distance_f; cpos_dist = P.ray_distance_f;
                     it = 0; hit = false;
                     mode = P.relativity0 ? M_REL : M_FLAT;
@@ -525,7 +576,7 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : BHRAY_TRACE_
         }
         if (run_flat && __any(mode == M_FLAT)) {
             if (mode == M_FLAT) {
-                if (it >= P.max_iter) {
+                if (it >= H.max_iter) {
                     mode = M_FINISH;
                 } else {
                     if (COUNT) cnt[5]++;
@@ -544,7 +595,7 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : BHRAY_TRACE_
                         }
                     }
                     float ths = t_max;
-                    const bool hs = hit_sphere(ppos, pdir, P.R, bpos, t_min, t_max, ths);
+                    const bool hs = hit_sphere(ppos, pdir, H.R, bpos, t_min, t_max, ths);
                     if (!hs && !rs.hit) {
                         mode = M_FINISH;                                   // break (no increment)
                     } else {
@@ -608,7 +659,7 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : BHRAY_TRACE_
         for (int k = 0; k < BHRAY_REL_BATCH; k++) {
             if (!__any(mode == M_REL)) break;
             if (mode == M_REL) {
-                if (it >= P.max_iter) {
+                if (it >= H.max_iter) {
                     mode = M_FINISH;
                 } else {
                     if (COUNT) cnt[4]++;
@@ -625,11 +676,11 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : BHRAY_TRACE_
                     if (cd < closest) closest = cd;
                     pdir = cdir;
                     Hit crs;
-                    hit_black_hole<COUNT>(P, ppos, pdir, ppos_dist, t_min, step, P.ray_distance, crs, cnt);
-                    if (cd > P.R) {
+                    hit_black_hole<COUNT>(P, H, ppos, pdir, ppos_dist, t_min, step, H.ray_distance, crs, cnt);
+                    if (cd > H.R) {
                         mode = M_FLAT;
-                        const float fw = P.R * P.feather;
-                        const float fs = P.R - fw;
+                        const float fw = H.R * H.feather;
+                        const float fs = H.R - fw;
                         const float lin = clamp_((closest - fs) / fw, 0.0f, 1.0f);
                         const float m = lin * lin;
                         cdir = mix3(cdir, rdir, m);
@@ -656,6 +707,7 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : BHRAY_TRACE_
             if (lane == 0 && v) atomicAdd(&counters->v[k], v);
         }
     }
+    }   // frames of the batch
     if (err) *err_flag = err;
 }
 
@@ -691,45 +743,57 @@ hipError_t launch_sky(const TexDev& sky, const float4* src, uint2* dst, size_t n
     return hipGetLastError();
 }
 
+// argument-block upload (pinned host memory -> HBM), see launch_upload
+__global__ __launch_bounds__(256) void upload_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+
+hipError_t launch_upload(const void* pinned_src, void* dst, size_t n16, hipStream_t s) {
+    if (n16 == 0) return hipSuccess;
+    hipLaunchKernelGGL(upload_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (const uint4*)pinned_src, (uint4*)dst, n16);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-hipError_t launch_classify(const FrameParams& P, const LevelParams& L, uint32_t* queue, uint32_t* qcount,
-                           Counters64* counters, hipStream_t s) {
-    const int tiles_x = (L.x1 - L.x0 + 7) / 8, tiles_y = (L.nrows + 7) / 8;
-    const int tiles = tiles_x * tiles_y;
-    if (tiles <= 0) return hipSuccess;
-    const int blocks = (tiles + 3) / 4;
-    if (counters) hipLaunchKernelGGL(classify_kernel<true>, dim3(blocks), dim3(256), 0, s, P, L, queue, qcount, counters);
-    else hipLaunchKernelGGL(classify_kernel<false>, dim3(blocks), dim3(256), 0, s, P, L, queue, qcount, counters);
+hipError_t launch_classify(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int blocks, bool count, hipStream_t s) {
+    if (blocks <= 0 || nb <= 0) return hipSuccess;
+    if (count) hipLaunchKernelGGL(classify_kernel<true>, dim3(blocks, nb), dim3(256), 0, s, Pb, Fb);
+    else hipLaunchKernelGGL(classify_kernel<false>, dim3(blocks, nb), dim3(256), 0, s, Pb, Fb);
     return hipGetLastError();
 }
 
-template <int METHOD, bool MODELS>
-static hipError_t launch_trace_t(const FrameParams& P, const LevelParams& L, const SpecLevels& SL, const uint32_t* queue, const uint32_t* qcount,
-                                 uint32_t* qhead, Counters64* counters, int* err_flag, int grid_blocks, hipStream_t s) {
-    if (counters) hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, true>), dim3(grid_blocks), dim3(256), 0, s, P, L, SL, queue, qcount, qhead, counters, err_flag);
-    else hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, false>), dim3(grid_blocks), dim3(256), 0, s, P, L, SL, queue, qcount, qhead, counters, err_flag);
+template <int METHOD, bool MODELS, bool DENSE>
+static hipError_t launch_trace_t(const FrameParams* Pb, const FrameLaunch* Fb, int nb, bool count, int* err_flag, int grid_blocks, hipStream_t s) {
+    if (count) hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, true, DENSE>), dim3(grid_blocks), dim3(256), 0, s, Pb, Fb, nb, err_flag);
+    else hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, false, DENSE>), dim3(grid_blocks), dim3(256), 0, s, Pb, Fb, nb, err_flag);
     return hipGetLastError();
 }
 
-hipError_t launch_trace(const FrameParams& P, const LevelParams& L, const SpecLevels& SL, const uint32_t* queue, const uint32_t* qcount,
-                        uint32_t* qhead, Counters64* counters, int* err_flag, int grid_blocks, hipStream_t s) {
-    const bool models = P.model_count > 0;
-    if (P.method == 0) {
-        return models ? launch_trace_t<0, true>(P, L, SL, queue, qcount, qhead, counters, err_flag, grid_blocks, s)
-                      : launch_trace_t<0, false>(P, L, SL, queue, qcount, qhead, counters, err_flag, grid_blocks, s);
+hipError_t launch_trace(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int method, bool models, bool count, bool dense, int* err_flag,
+                        int grid_blocks, hipStream_t s) {
+    if (nb <= 0) return hipSuccess;
+    if (models) {       // the mesh variant has one register budget
+        return method == 0 ? launch_trace_t<0, true, false>(Pb, Fb, nb, count, err_flag, grid_blocks, s)
+                           : launch_trace_t<1, true, false>(Pb, Fb, nb, count, err_flag, grid_blocks, s);
     }
-    return models ? launch_trace_t<1, true>(P, L, SL, queue, qcount, qhead, counters, err_flag, grid_blocks, s)
-                  : launch_trace_t<1, false>(P, L, SL, queue, qcount, qhead, counters, err_flag, grid_blocks, s);
+    if (method == 0) {
+        return dense ? launch_trace_t<0, false, true>(Pb, Fb, nb, count, err_flag, grid_blocks, s)
+                     : launch_trace_t<0, false, false>(Pb, Fb, nb, count, err_flag, grid_blocks, s);
+    }
+    return dense ? launch_trace_t<1, false, true>(Pb, Fb, nb, count, err_flag, grid_blocks, s)
+                 : launch_trace_t<1, false, false>(Pb, Fb, nb, count, err_flag, grid_blocks, s);
 }
 
-int trace_blocks_per_cu(int method, int has_models, int count) {
+int trace_blocks_per_cu(int method, int has_models, int count, int dense) {
     int n = 0;
     const void* f;
-#define PICK(M, MD, C) (const void*)trace_kernel<M, MD, C>
-    if (method == 0) f = has_models ? (count ? PICK(0, true, true) : PICK(0, true, false)) : (count ? PICK(0, false, true) : PICK(0, false, false));
-    else f = has_models ? (count ? PICK(1, true, true) : PICK(1, true, false)) : (count ? PICK(1, false, true) : PICK(1, false, false));
+#define PICK(M, MD, C, D) (const void*)trace_kernel<M, MD, C, D>
+    if (has_models) f = method == 0 ? (count ? PICK(0, true, true, false) : PICK(0, true, false, false)) : (count ? PICK(1, true, true, false) : PICK(1, true, false, false));
+    else if (dense) f = method == 0 ? (count ? PICK(0, false, true, true) : PICK(0, false, false, true)) : (count ? PICK(1, false, true, true) : PICK(1, false, false, true));
+    else f = method == 0 ? (count ? PICK(0, false, true, false) : PICK(0, false, false, false)) : (count ? PICK(1, false, true, false) : PICK(1, false, false, false));
 #undef PICK
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 256, 0) != hipSuccess || n < 1) n = 2;
     return n;

@@ -62,7 +62,7 @@ class BhrayConfig(C.Structure):
                 ("level_w", C.c_uint32 * MAX_LEVELS), ("level_h", C.c_uint32 * MAX_LEVELS),
                 ("crop_x", C.c_uint32), ("crop_y", C.c_uint32), ("frame_w", C.c_uint32), ("frame_h", C.c_uint32),
                 ("row_rank", C.c_uint32), ("row_world", C.c_uint32), ("stripe_rows", C.c_uint32), ("flags", C.c_uint32),
-                ("frames_in_flight", C.c_uint32), ("speculative_levels", C.c_uint32)]
+                ("frames_in_flight", C.c_uint32), ("speculative_levels", C.c_uint32), ("frames_per_batch", C.c_uint32)]
 
     def sizes(self):
         return [(int(self.level_w[i]), int(self.level_h[i])) for i in range(self.levels)]
@@ -77,7 +77,7 @@ class BhrayCounters(C.Structure):
 
 
 class BhrayTiming(C.Structure):
-    _fields_ = [("frames", C.c_uint32), ("total_ms", C.c_float), ("trace_ms", C.c_float), ("classify_ms", C.c_float),
+    _fields_ = [("frames", C.c_uint32), ("batches", C.c_uint32), ("total_ms", C.c_float), ("trace_ms", C.c_float), ("classify_ms", C.c_float),
                 ("trace_launches", C.c_uint32), ("classify_launches", C.c_uint32),
                 ("level_trace_ms", C.c_float * MAX_LEVELS), ("level_classify_ms", C.c_float * MAX_LEVELS),
                 ("sky_ms", C.c_float), ("sky_launches", C.c_uint32)]
@@ -104,6 +104,7 @@ SYMBOLS = {
     "bhray_set_model_transform": (C.c_int, [vp, u32, P(C.c_float), i32]),
     "bhray_set_uniforms": (C.c_int, [vp, vp, vp, vp]),
     "bhray_render": (C.c_int, [vp]),
+    "bhray_flush": (C.c_int, [vp]),
     "bhray_sync": (C.c_int, [vp]),
     "bhray_read_hdr": (C.c_int, [vp, vp, sz]),
     "bhray_read_level": (C.c_int, [vp, u32, vp, sz]),

@@ -33,7 +33,7 @@ def ladder_for_frame(frame=(1920, 1080), multiplier=3, levels=4) -> BhrayConfig:
 
 class RayPass:
     def __init__(self, cfg: BhrayConfig, device=0, counters=False, timing=False, row_rank=0, row_world=1, stripe_rows=27,
-                 frames_in_flight=0, speculative_levels=0):
+                 frames_in_flight=0, speculative_levels=0, frames_per_batch=0):
         cfg = BhrayConfig.from_buffer_copy(bytes(cfg))
         cfg.struct_size = C.sizeof(BhrayConfig)
         cfg.device = device
@@ -41,6 +41,7 @@ class RayPass:
         cfg.row_rank, cfg.row_world, cfg.stripe_rows = row_rank, row_world, stripe_rows
         cfg.frames_in_flight = frames_in_flight
         cfg.speculative_levels = speculative_levels
+        cfg.frames_per_batch = frames_per_batch
         self.cfg = cfg
         h = C.c_void_p()
         check(lib().bhray_create(C.byref(cfg), C.byref(h)))
@@ -83,6 +84,10 @@ class RayPass:
 
     def render(self):
         check(lib().bhray_render(self._h), self._h)
+
+    def flush(self):
+        """frames_per_batch > 1: enqueue the launches of the frames staged so far."""
+        check(lib().bhray_flush(self._h), self._h)
 
     def sync(self):
         check(lib().bhray_sync(self._h), self._h)

@@ -139,6 +139,7 @@ typedef struct bhray_model_desc {
 #define BHRAY_MAX_LEVELS 8
 #define BHRAY_MAX_FRAMES_IN_FLIGHT 32
 #define BHRAY_MAX_SPEC_LEVELS 4
+#define BHRAY_MAX_FRAMES_PER_BATCH 16
 #define BHRAY_BVH_STACK  64            /* reference: 19 whole nodes, no overflow check (ray.wgsl:292) */
 
 enum {                                  /* bhray_config.flags */
@@ -159,6 +160,13 @@ enum {                                  /* bhray_config.flags */
  * launches, more rays traced (bhray_counters then count the speculative work).  Meant for small per-GPU frames
  * (row-tiled multi-GPU); off by default.
  *
+ * Frame batches.  With frames_per_batch = B > 1, bhray_render only STAGES a frame (uniforms, output binding); the
+ * launches are enqueued once B frames are staged (or bhray_flush / any call that waits for or reads a frame is made),
+ * and every launch then covers the B frames: B times fewer dependent launches per frame and B times more rays per
+ * launch.  Frames of a batch may have different uniforms; pixels are identical to B = 1.  For throughput rendering of
+ * small per-GPU frames (row-tiled multi-GPU, offline sequences); an interactive host keeps B = 1.  A consumer that
+ * orders its own work after a frame through bhray_next_stream must call bhray_flush before enqueueing that work.
+ *
  * Row partition (multi-GPU row tiling): frame row r belongs to partition
  * (r / stripe_rows) % row_world; this ctx renders only rows of partition row_rank and packs
  * them densely, in increasing r, into its output buffer.  row_world = 1 ⇒ the whole frame. */
@@ -174,6 +182,7 @@ typedef struct bhray_config {
     uint32_t flags;
     uint32_t frames_in_flight;          /* 0 = default (4); 1 = strictly one frame at a time  */
     uint32_t speculative_levels;        /* 0 = off; S>=2: trace EVERY needed pixel of levels 0..S-1 in one launch   */
+    uint32_t frames_per_batch;          /* 0/1 = every bhray_render launches; B>1: launches cover B staged frames  */
 } bhray_config;
 
 /* Reference ladder rule `r ← r·m − (m−1)` (mod.rs:177-205): fills level_w/h[0..levels).    */
@@ -217,6 +226,10 @@ int bhray_set_uniforms(bhray_ctx* ctx, const void* camera_uniform_32,
 /* Dispatch — replaces `for rp in ray_pipelines { rp.pass() }` (mod.rs:415-417,
  * ray_pipeline.rs:301-309).  Asynchronous on the ctx stream; levels ordered.                 */
 int bhray_render(bhray_ctx* ctx);
+/* frames_per_batch > 1: enqueue the launches of the frames staged so far (a partial batch).  No-op otherwise.
+ * bhray_sync, the bhray_read_* calls, bhray_resolve_sky, bhray_signal_stream and the texture / model uploads flush
+ * by themselves.                                                                              */
+int bhray_flush(bhray_ctx* ctx);
 int bhray_sync(bhray_ctx* ctx);
 
 /* Output — replaces RayPipeline::output_view (ray_pipeline.rs:297-299): RGBA32F,
@@ -248,7 +261,8 @@ int bhray_bind_output(bhray_ctx* ctx, void* dev_ptr, size_t bytes);
 int bhray_wait_stream(bhray_ctx* ctx, void* hip_stream);
 int bhray_signal_stream(bhray_ctx* ctx, void* hip_stream);
 /* The hipStream_t of the slot the NEXT bhray_render will use.  A caller that enqueues its own work for that frame on
- * this stream (e.g. wraps it as torch.cuda.ExternalStream and issues the RCCL gather there) needs no extra ordering.  */
+ * this stream (e.g. wraps it as torch.cuda.ExternalStream and issues the RCCL gather there) needs no extra ordering
+ * (with frames_per_batch > 1: all frames of a batch share the stream, and the caller flushes before enqueueing). */
 int bhray_next_stream(bhray_ctx* ctx, void** hip_stream);
 
 /* Sky resolve — the compute pass that follows the ray pass in the reference (shaders/sky.wgsl:1-38,
@@ -279,11 +293,12 @@ int bhray_get_counters(bhray_ctx* ctx, bhray_counters* out);   /* needs BHRAY_F_
 int bhray_get_level_counters(bhray_ctx* ctx, uint32_t level, bhray_counters* out);
 
 /* HIP-event timing of every launch (events recorded on the ctx stream).  bhray_get_timing sums
- * over the frames rendered since the previous call (at most BHRAY_TIMING_RING of them).       */
+ * over the batches launched since the previous call (at most BHRAY_TIMING_RING of them).     */
 #define BHRAY_TIMING_RING 128
 typedef struct bhray_timing {
     uint32_t frames;                   /* frames aggregated                                  */
-    float    total_ms;                 /* Σ (first launch → last launch) per frame           */
+    uint32_t batches;                  /* batches aggregated (= frames unless frames_per_batch > 1) */
+    float    total_ms;                 /* Σ (first launch → last launch) per batch           */
     float    trace_ms;                 /* Σ trace kernels                                    */
     float    classify_ms;              /* Σ grid classify kernels                            */
     uint32_t trace_launches;

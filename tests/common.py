@@ -44,3 +44,27 @@ def assert_parity(got, want, what=""):
     e = rel_err(got[fin], want[fin])
     assert float(e.max(initial=0.0)) <= REL_TOL, f"{what}: max rel err {float(e.max()):.3g} > {REL_TOL}"
     return float(e.max(initial=0.0)), float((got[fin] == want[fin]).all(axis=-1).mean()) if fin.any() else 1.0
+
+
+class DeviceBuffer:
+    """A plain HIP allocation for tests that bind their own output memory (no torch: other tests hide the devices from it)."""
+
+    def __init__(self, nbytes: int, fill: int = 0xFF):
+        import ctypes as C
+        self._C = C
+        self.hip = C.CDLL("libamdhip64.so")
+        self.nbytes = nbytes
+        self.ptr = C.c_void_p()
+        assert self.hip.hipMalloc(C.byref(self.ptr), C.c_size_t(nbytes)) == 0
+        assert self.hip.hipMemset(self.ptr, fill, C.c_size_t(nbytes)) == 0
+        assert self.hip.hipDeviceSynchronize() == 0
+
+    def read(self, dtype=np.float32) -> np.ndarray:
+        out = np.empty(self.nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        assert self.hip.hipMemcpy(self._C.c_void_p(out.ctypes.data), self.ptr, self._C.c_size_t(self.nbytes), 2) == 0   # hipMemcpyDeviceToHost
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.hip.hipFree(self.ptr)
+            self.ptr = None

@@ -336,3 +336,64 @@ def test_sah_tree_gives_the_same_closest_hits(tmp_path):
     assert rp.counters() == cnt.as_dict()
     same = (got == ref_frame).all(axis=-1)
     assert same.mean() > 0.995, same.mean()
+
+
+def _frames_for_batch():
+    """Three frames with different uniforms (camera, disk rotation time, flags)."""
+    cams = [B.Camera(), B.Camera(position=(2.0, 1.5, -24.0), forward=(-0.0830455, -0.0622841, 0.9945987)),
+            B.Camera(position=(0.0, 3.0, -45.0), forward=(0.0, -0.0665190, 0.9977851))]
+    return [T.uniforms(camera=cams[0], integration_method=1, time=0.0),
+            T.uniforms(camera=cams[1], integration_method=1, time=1.7),
+            T.uniforms(camera=cams[2], integration_method=1, time=3.1)]
+
+
+@pytest.mark.parametrize("spec", [0, 2])
+def test_frame_batches_give_identical_frames(spec):
+    """bhray_config.frames_per_batch: bhray_render stages, every launch covers the staged frames (different uniforms per
+    frame).  Each frame must equal the frame a batch-less ctx renders from the same uniforms, bit for bit."""
+    tex = T.textures()
+    frames = _frames_for_batch()
+    cfg = B.ladder_from_base((24, 14), 3, 3)
+    want = [run_gpu(cfg, *u, tex, speculative_levels=spec).read_hdr() for u in frames]
+    assert not np.array_equal(want[0], want[1]) and not np.array_equal(want[1], want[2])
+    rp = B.RayPass(cfg, device=0, frames_per_batch=3, frames_in_flight=2, speculative_levels=spec, counters=True)
+    rp.set_textures(*tex)
+    h, w = want[0].shape[:2]
+    fb = h * w * 16
+    out = T.DeviceBuffer(7 * fb)                               # NaN-filled
+    order = [0, 1, 2, 2, 0, 1, 1]                              # 2 full batches + a partial one; slots are reused
+    for i, f in enumerate(order):
+        rp.set_uniforms(*frames[f])
+        rp.bind_output(out.ptr.value + i * fb, fb)
+        rp.render()
+    rp.sync()                                                  # flushes the partial batch
+    got = out.read().reshape(7, h, w, 4)
+    for i, f in enumerate(order):
+        assert np.array_equal(got[i], want[f]), f"frame {i} (uniform set {f})"
+    assert np.array_equal(rp.read_hdr(), want[order[-1]])      # the most recent frame, through the bound buffer
+    single = run_gpu(cfg, *frames[order[-1]], tex, speculative_levels=spec, counters=True)
+    assert rp.counters() == single.counters()
+    rp.close(); out.free()
+
+
+def test_frame_batch_switches_kernel_variant_and_partition(tmp_path):
+    """A batch is homogeneous in its kernel variant: a frame that needs another integrator (or the mesh variant) first
+    launches what is staged.  Also: batches on a row partition with a mesh."""
+    tex = T.textures()
+    model = _mesh_model(tmp_path, 12, 16)
+    cam = B.Camera(position=(0.0, 0.0, -40.0), forward=(-0.11914522, 0.0, 0.99287683), fov=1.2)
+    cfg = B.ladder_for_frame((200, 110), 3, 3)
+    us = [T.uniforms(camera=cam, integration_method=1, model_count=1), T.uniforms(camera=cam, integration_method=0, model_count=1),
+          T.uniforms(camera=cam, integration_method=0, model_count=0), T.uniforms(camera=cam, integration_method=1, model_count=1)]
+    want = [run_gpu(cfg, *u, tex, model=model).read_hdr() for u in us]
+    for rank in range(2):
+        rp = B.RayPass(cfg, device=0, frames_per_batch=4, frames_in_flight=2, row_rank=rank, row_world=2, stripe_rows=9, speculative_levels=2)
+        rp.set_textures(*tex); rp.upload_model(model)
+        for i, u in enumerate(us):
+            rp.set_uniforms(*u); rp.render()
+            assert np.array_equal(rp.read_hdr(), want[i][rp.local_rows()]), f"rank {rank} frame {i}"     # read flushes
+        for u in us:                                           # the same four frames staged back to back: three variant switches
+            rp.set_uniforms(*u); rp.render()
+        assert np.array_equal(rp.read_hdr(), want[3][rp.local_rows()])
+    with pytest.raises(B.BhrayError):
+        B.RayPass(cfg, device=0, frames_per_batch=17)
