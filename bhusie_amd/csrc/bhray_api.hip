@@ -924,6 +924,21 @@ int bhray_signal_stream(bhray_ctx* c, void* s) {
     return BHRAY_OK;
 }
 
+int bhray_selftest(bhray_ctx* c, uint64_t mismatches[2]) {
+    if (!c || !mismatches) return BHRAY_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned long long* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, 16));
+    hipError_t e = hipMemset(d, 0, 16);
+    if (e == hipSuccess) e = launch_selftest(d, nullptr);
+    unsigned long long h[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, BHRAY_E_HIP, "selftest: %s", hipGetErrorString(e));
+    mismatches[0] = h[0]; mismatches[1] = h[1];
+    return BHRAY_OK;
+}
+
 int bhray_get_level_counters(bhray_ctx* c, uint32_t level, bhray_counters* out) {
     if (!c || !out) return BHRAY_E_INVALID;
     if (!(c->cfg.flags & BHRAY_F_COUNTERS)) return fail(c, BHRAY_E_STATE, "ctx created without BHRAY_F_COUNTERS");

@@ -121,6 +121,7 @@ SYMBOLS = {
     "bhray_get_counters": (C.c_int, [vp, P(BhrayCounters)]),
     "bhray_get_level_counters": (C.c_int, [vp, u32, P(BhrayCounters)]),
     "bhray_get_timing": (C.c_int, [vp, P(BhrayTiming)]),
+    "bhray_selftest": (C.c_int, [vp, P(C.c_uint64)]),
     "bhray_camera_uniform_update": (None, [P(BhrayCameraUniform), P(C.c_float), P(C.c_float), C.c_float]),
     "bhray_black_hole_default": (None, [P(BhrayBlackHole)]),
     "bhray_black_hole_uniform_update": (None, [P(BhrayBlackHoleUniform), P(BhrayBlackHole)]),

@@ -160,6 +160,12 @@ class RayPass:
         check(lib().bhray_get_level_counters(self._h, level, C.byref(c)), self._h)
         return c.as_dict()
 
+    def selftest(self):
+        """(1/x mismatches, sqrt mismatches) of the step loop's short sequences vs IEEE over all 2^32 inputs; both must be 0."""
+        m = (C.c_uint64 * 2)()
+        check(lib().bhray_selftest(self._h, m), self._h)
+        return int(m[0]), int(m[1])
+
     def timing(self) -> BhrayTiming:
         t = BhrayTiming()
         check(lib().bhray_get_timing(self._h, C.byref(t)), self._h)
