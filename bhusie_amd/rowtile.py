@@ -30,44 +30,58 @@ def max_local_rows(frame_h: int, world: int, stripe_rows: int = 27) -> int:
 
 
 class FrameGather:
-    """Gathers packed per-rank row blocks to `dst` and de-interleaves them into the frame.
+    """Gathers packed per-rank row blocks to `dst` and de-interleaves them into the frame(s).
 
-    Each rank contributes a (max_rows, W, 4) f32 block (ranks with fewer rows pad at the end), so the
-    collective is a plain equal-size gather: torch.distributed.gather (ncclSend/ncclRecv group under
-    the nccl backend).  `assemble` runs on the root only: frame[rows_of_rank] = block[:len(rows)].
+    Each rank contributes a (batch, max_rows, W, 4) f32 block — the frames of one launch batch (bhray_config.frames_per_batch;
+    batch = 1: a single frame), ranks with fewer rows pad at the end — so the collective is ONE plain equal-size gather per
+    batch: torch.distributed.gather (ncclSend/ncclRecv group under the nccl backend).  `assemble` runs on the root only:
+    frames[:, rows_of_rank] = block[:, :len(rows)].  `local[i]` is the buffer frame i of the batch is rendered into.
     """
 
     def __init__(self, frame_w: int, frame_h: int, rank: int, world: int, stripe_rows: int = 27, dst: int = 0,
-                 device="cpu", group=None):
+                 device="cpu", group=None, batch: int = 1):
         import torch
         self.torch = torch
         self.w, self.h, self.rank, self.world, self.dst, self.group = frame_w, frame_h, rank, world, dst, group
+        self.batch = batch
         self.rows = partition_rows(frame_h, world, stripe_rows)
         self.max_rows = max(len(x) for x in self.rows)
         self.device = device
-        self.local = torch.zeros((self.max_rows, frame_w, 4), dtype=torch.float32, device=device)
+        self._local = torch.zeros((batch, self.max_rows, frame_w, 4), dtype=torch.float32, device=device)
         if rank == dst:
-            self.blocks = [torch.zeros_like(self.local) for _ in range(world)]
-            self.frame = torch.zeros((frame_h, frame_w, 4), dtype=torch.float32, device=device)
+            self.blocks = [torch.zeros_like(self._local) for _ in range(world)]
+            self.frames = torch.zeros((batch, frame_h, frame_w, 4), dtype=torch.float32, device=device)
             self.row_index = [torch.as_tensor(x, dtype=torch.long, device=device) for x in self.rows]
         else:
-            self.blocks, self.frame, self.row_index = None, None, None
+            self.blocks, self.frames, self.row_index = None, None, None
+
+    @property
+    def local(self):
+        """The (max_rows, W, 4) buffer of a single-frame gather (batch == 1); `local_frame(i)` in general."""
+        return self._local[0]
+
+    def local_frame(self, i: int):
+        return self._local[i]
+
+    @property
+    def frame(self):
+        return None if self.frames is None else self.frames[0]
 
     def gather(self, async_op: bool = False):
         """Collective over all ranks.  Returns the work handle (or None)."""
         import torch.distributed as dist
         if self.world == 1 and not dist.is_initialized():
-            self.blocks[0] = self.local
+            self.blocks[0] = self._local
             return None
-        return dist.gather(self.local, self.blocks if self.rank == self.dst else None, dst=self.dst,
+        return dist.gather(self._local, self.blocks if self.rank == self.dst else None, dst=self.dst,
                            group=self.group, async_op=async_op)
 
     def assemble(self):
-        """Root only: de-interleave the gathered blocks into the (H, W, 4) frame."""
+        """Root only: de-interleave the gathered blocks into the (batch, H, W, 4) frames; returns frames[0] when batch == 1."""
         if self.rank != self.dst:
             return None
         for k in range(self.world):
             n = len(self.rows[k])
             if n:
-                self.frame.index_copy_(0, self.row_index[k], self.blocks[k][:n])
-        return self.frame
+                self.frames.index_copy_(1, self.row_index[k], self.blocks[k][:, :n])
+        return self.frames[0] if self.batch == 1 else self.frames

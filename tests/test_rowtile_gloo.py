@@ -42,7 +42,17 @@ def _worker(rank, world, port, w, h, stripe, frame_path, out_path):
         if work is not None:
             work.wait()
         frame = g.assemble()
+    # a batch of 3 frames (bhray_config.frames_per_batch): one collective, frames de-interleaved together
+    gb = FrameGather(w, h, rank, world, stripe, 0, device="cpu", batch=3)
+    for i in range(3):
+        gb.local_frame(i).zero_()
+        gb.local_frame(i)[:len(mine)] = torch.from_numpy(full[mine]) * float(i + 1)
+    gb.gather()
+    frames = gb.assemble()
     if rank == 0:
+        assert frames.shape == (3, h, w, 4)
+        for i in range(3):
+            assert np.array_equal(frames[i].numpy(), full * np.float32(i + 1), equal_nan=True)
         np.save(out_path, frame.numpy())
     dist.barrier()
     dist.destroy_process_group()
