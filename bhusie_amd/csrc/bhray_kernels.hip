@@ -335,17 +335,17 @@ __device__ __forceinline__ float sqrt_corrected(float x) {
 __device__ __forceinline__ bool rcp_in_range(float x) { return fabsf(x) >= 0x1p-125f && fabsf(x) < 0x1p126f; }
 __device__ __forceinline__ bool sqrt_in_range(float x) { return x >= 0x1p-95f && x <= 0x1p95f; }
 __device__ __forceinline__ float rcp_rn(float x) {                 // == 1.0f / x
-    if (__ballot(!rcp_in_range(x)) == 0ull) return rcp_newton(x);
+    if (__builtin_expect(__ballot(!rcp_in_range(x)) == 0ull, 1)) return rcp_newton(x);
     return 1.0f / x;
 }
 __device__ __forceinline__ float sqrt_rn(float x) {                // == sqrtf(x)
-    if (__ballot(!sqrt_in_range(x)) == 0ull) return sqrt_corrected(x);
+    if (__builtin_expect(__ballot(!sqrt_in_range(x)) == 0ull, 1)) return sqrt_corrected(x);
     return sqrtf(x);
 }
 // == fnormalize(a) (bhray_math.h): a * (1 / sqrt(fdot(a, a))); one guard covers both (sqrt of an in-range x is in rcp's range)
 __device__ __forceinline__ F3 fnormalize_rn(F3 a) {
     const float d = fdot(a, a);
-    if (__ballot(!sqrt_in_range(d)) == 0ull) return a * rcp_newton(sqrt_corrected(d));
+    if (__builtin_expect(__ballot(!sqrt_in_range(d)) == 0ull, 1)) return a * rcp_newton(sqrt_corrected(d));
     return a * (1.0f / sqrtf(d));
 }
 __device__ __forceinline__ float fdistance_rn(F3 a, F3 b) { const F3 v = a - b; return sqrt_rn(fdot(v, v)); }   // == fdistance(a, b)
