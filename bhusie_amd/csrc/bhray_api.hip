@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <new>
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -75,6 +76,7 @@ struct ModelStore {
     float4* points = nullptr; float4* normals = nullptr; int32_t* triangles = nullptr;
     float4* nodes = nullptr; int32_t* lookup = nullptr; float4* leaf = nullptr;
     int point_count = 0, normal_count = 0, triangle_count = 0, node_count = 0;
+    int root_cull = 0; float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};   // union of the root's child boxes (ModelDev)
     bool loaded = false;
 };
 
@@ -185,6 +187,7 @@ void derive_frame(const bhray_ctx* c, FrameParams& P) {
         md.visible = (m.loaded && m.triangle_count > 0) ? m.visible : 0;
         md.points = m.points; md.normals = m.normals; md.triangles = m.triangles; md.nodes = m.nodes; md.lookup = m.lookup; md.leaf = m.leaf;
         md.node_count = m.node_count;
+        md.root_cull = m.root_cull; memcpy(md.root_lo, m.root_lo, 12); memcpy(md.root_hi, m.root_hi, 12);
         usable = i + 1;
     }
     P.model_count = usable;
@@ -535,6 +538,17 @@ int bhray_upload_model(bhray_ctx* c, uint32_t mi, const bhray_model_desc* d) {
                 }
             }
             m.node_count = (int)order.size();
+            // what the traversal's first visit tests: the two children of the (untested) root.  A ray that misses the union
+            // of their boxes misses both (the slab test is monotone in the box), so the kernel can skip that visit.
+            if (bfs[0].obj_count == 0 && order.size() >= 3) {
+                for (int a = 0; a < 3; a++) {
+                    m.root_lo[a] = bfs[1].min_corner[a] < bfs[2].min_corner[a] ? bfs[1].min_corner[a] : bfs[2].min_corner[a];
+                    m.root_hi[a] = bfs[1].max_corner[a] > bfs[2].max_corner[a] ? bfs[1].max_corner[a] : bfs[2].max_corner[a];
+                }
+                bool finite = true;
+                for (int a = 0; a < 3; a++) finite = finite && std::isfinite(m.root_lo[a]) && std::isfinite(m.root_hi[a]);
+                m.root_cull = finite ? 1 : 0;
+            }
             HIPCHK(c, hipMemcpy(m.nodes, bfs.data(), order.size() * 32, hipMemcpyHostToDevice));
         }
         HIPCHK(c, hipMemcpy(m.lookup, d->bvh_lookup, (size_t)d->triangle_count * 4, hipMemcpyHostToDevice));

@@ -23,6 +23,8 @@ struct ModelDev {
     const int32_t* lookup;
     const float4* leaf;         // pre-gathered leaf geometry: 6 float4 (p1,p2,p3,n1,n2,n3) per bvh_lookup slot
     int node_count;
+    int root_cull;              // 1: root_lo/root_hi hold the union of the root's two child boxes (root is an inner node)
+    float root_lo[3], root_hi[3];
 };
 
 // Everything that is uniform over a frame.  Lives in HBM (one entry per frame of a batch); the address is wave-uniform,

@@ -505,10 +505,10 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3 };
 #define BHRAY_REL_BATCH 16       // integrator steps between refill / flat / epilogue phases
 #endif
 #ifndef BHRAY_FLAT_MIN_LANES
-#define BHRAY_FLAT_MIN_LANES 12    // mesh variant: run the flat/BVH phase when this many lanes wait for it ...
+#define BHRAY_FLAT_MIN_LANES 48    // mesh variant: run the flat/BVH phase when this many lanes wait for it ...
 #endif
 #ifndef BHRAY_FLAT_DEFER
-#define BHRAY_FLAT_DEFER 4         // ... or after this many rounds at the latest
+#define BHRAY_FLAT_DEFER 64        // ... or after this many rounds at the latest (measured 12/4: 2735, 48/64: 2890 Mrays/s)
 #endif
 #ifndef BHRAY_TRACE_WAVES_MESH
 #define BHRAY_TRACE_WAVES_MESH 4 // measured on the mesh workload: 3 -> 2190, 4 -> 2487, 2 -> 1746 Mrays/s
@@ -623,7 +623,23 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
                         for (int mi = 0; mi < P.model_count; mi++) {
                             if (P.models[mi].visible != 0) {
                                 Hit r; F3 nrm;
-                                trace_ray_model<COUNT>(P.models[mi], cpos, cdir, t_min, t_max, r, nrm, cnt, &err);
+                                r.hit = false;
+                                // The traversal's first visit tests the two children of the root.  A ray that misses the union of
+                                // their boxes misses both (the slab test is monotone in the box when 1/dir is finite), so that visit
+                                // - a function call and a dependent 64-byte load for the whole wave - is skipped; most rays that
+                                // leave the sphere point away from the mesh.  Counted as the visit it replaces.
+                                bool skip = false;
+                                if (P.models[mi].root_cull != 0) {
+                                    const F3 inv = f3(1.0f / cdir.x, 1.0f / cdir.y, 1.0f / cdir.z);
+                                    if (fabsf(inv.x) < INFINITY && fabsf(inv.y) < INFINITY && fabsf(inv.z) < INFINITY) {
+                                        const ModelDev& Md = P.models[mi];
+                                        const float d0 = hit_aabb(cpos, inv, make_float4(Md.root_lo[0], Md.root_lo[1], Md.root_lo[2], 0.0f),
+                                                                  make_float4(Md.root_hi[0], Md.root_hi[1], Md.root_hi[2], 0.0f), ld3(Md.pos));
+                                        skip = d0 > t_max;
+                                        if (COUNT && skip) cnt[6]++;
+                                    }
+                                }
+                                if (!skip) trace_ray_model<COUNT>(P.models[mi], cpos, cdir, t_min, t_max, r, nrm, cnt, &err);
                                 if (r.hit && r.t < rs.t) {
                                     rs = r;
                                     const F3 light = normalize(f3(0.2f, 0.2f, -1.0f));
