@@ -352,9 +352,8 @@ __device__ __forceinline__ float fdistance_rn(F3 a, F3 b) { const F3 v = a - b; 
 
 __device__ __forceinline__ float pow5(float d) { return ((d * d) * (d * d)) * d; }
 
-// f, ray.wgsl:401-403, with the per-step invariants factored: c = -1.5*h2, r = 1/dist^5.
-__device__ __forceinline__ F3 f_acc(F3 p, F3 bpos, float c, float r) { return ((p - bpos) * c) * r; }
-
+// f, ray.wgsl:401-403, under N9: f(p) = (p - bh) * s with the per-step scalar s = (-1.5*h2) * (1/dist^5); positions are kept
+// relative to the hole (q = p - bh), so a stage is fma(sum, h, q0) * s.
 // Cash–Karp tableau, ray.wgsl:133-165: untyped consts are evaluated in binary64 and rounded once.
 #define KF(x) ((float)(x))
 __device__ constexpr float A21 = KF(1.0 / 5.0);
@@ -373,17 +372,17 @@ __device__ constexpr float DB1 = KF(37.0 / 378.0 - 2825.0 / 27648.0), DB2 = KF(0
 // `dist` = flength(pos - bpos), carried from the previous step's exit test (same operands, same value).
 __device__ __forceinline__ void next_ray_rk(F3 bpos, F3& pos, F3& dir, float& h_io, float dist) {
     const F3 p0 = pos, d0 = dir;
+    const F3 q0 = p0 - bpos;                         // N9: position relative to the hole, once per step
     const F3 cr = fcross(p0, d0);
     const float h2 = fdot(cr, cr);                   // N3: pow(length(v), 2.0) = dot(v, v)
-    const float c = -1.5f * h2;
-    const float r = rcp_rn(pow5(dist));
+    const float s = (-1.5f * h2) * rcp_rn(pow5(dist));   // N9
     const float h = h_io;
-    const F3 k1 = f_acc(p0, bpos, c, r);
-    const F3 k2 = f_acc(fmadd3(k1 * A21, h, p0), bpos, c, r);
-    const F3 k3 = f_acc(fmadd3(lin2(k1, A31, k2, A32), h, p0), bpos, c, r);
-    const F3 k4 = f_acc(fmadd3(fmadd3(k2, A43, lin2(k1, A41, k2, A42)), h, p0), bpos, c, r);
-    const F3 k5 = f_acc(fmadd3(fmadd3(k4, A54, fmadd3(k3, A53, lin2(k1, A51, k2, A52))), h, p0), bpos, c, r);
-    const F3 k6 = f_acc(fmadd3(fmadd3(k5, A65, fmadd3(k4, A64, fmadd3(k3, A63, lin2(k1, A61, k2, A62)))), h, p0), bpos, c, r);
+    const F3 k1 = q0 * s;
+    const F3 k2 = fmadd3(k1 * A21, h, q0) * s;
+    const F3 k3 = fmadd3(lin2(k1, A31, k2, A32), h, q0) * s;
+    const F3 k4 = fmadd3(fmadd3(k2, A43, lin2(k1, A41, k2, A42)), h, q0) * s;
+    const F3 k5 = fmadd3(fmadd3(k4, A54, fmadd3(k3, A53, lin2(k1, A51, k2, A52))), h, q0) * s;
+    const F3 k6 = fmadd3(fmadd3(k5, A65, fmadd3(k4, A64, fmadd3(k3, A63, lin2(k1, A61, k2, A62)))), h, q0) * s;
     const F3 es = fmadd3(k6, DB6, fmadd3(k5, DB5, fmadd3(k4, DB4, fmadd3(k3, DB3, lin2(k1, DB1, k2, DB2)))));
     const F3 e = es * h;
     const float e_max = max_(max_(fabsf(e.x), fabsf(e.y)), fabsf(e.z));
@@ -394,13 +393,12 @@ __device__ __forceinline__ void next_ray_rk(F3 bpos, F3& pos, F3& dir, float& h_
     else h_io = h * 1.0001f;
 }
 
-// next_ray_euler, ray.wgsl:467-480 (N7).
+// next_ray_euler, ray.wgsl:467-480 (N7, N9).
 __device__ __forceinline__ void next_ray_euler(F3 bpos, F3& pos, F3& dir, float step, float dist) {
     const F3 cr = fcross(pos, dir);
     const float h2 = fdot(cr, cr);                   // N3: pow(length(v), 2.0) = dot(v, v)
-    const float c = -1.5f * h2;
-    const float r = rcp_rn(pow5(dist));
-    dir = fnormalize_rn(fmadd3(f_acc(pos, bpos, c, r), step, dir));
+    const float s = (-1.5f * h2) * rcp_rn(pow5(dist));
+    dir = fnormalize_rn(fmadd3((pos - bpos) * s, step, dir));
     pos = fmadd3(dir, step, pos);
 }
 

@@ -507,17 +507,18 @@ DB = [_K(b - ba) for b, ba in ((B1, BA1), (B2, BA2), (B3, BA3), (B4, BA4), (B5, 
 BA = [_K(v) for v in (BA1, BA2, BA3, BA4, BA5, BA6)]
 
 
-def f_acc(S, p, h2, dist):
-    num = (p - S.bh_pos) * (f32(-1.5) * h2)[:, None]
+def f_scale(h2, dist):
+    """N9: the scalar of f (ray.wgsl:401-403) for one step, s = (-1.5*h2) * (1/dist^5)"""
     d2 = dist * dist
     d5 = (d2 * d2) * dist
-    return vdivs(num, d5)
+    return ((f32(-1.5) * h2) * (f32(1.0) / d5)).astype(np.float32)
 
 
 def next_ray_euler(S, pos, dirn, step):
     cr = fcross(pos, dirn); h2 = fdot(cr, cr)               # N3: pow(length(v), 2.0) = dot(v, v)
-    dist = flen(pos - S.bh_pos)
-    nd = fnorm(fmadd3(f_acc(S, pos, h2, dist), step, dirn))
+    q0 = (pos - S.bh_pos).astype(np.float32)                # N9: position relative to the hole
+    dist = flen(q0)
+    nd = fnorm(fmadd3(q0 * f_scale(h2, dist)[:, None], step, dirn))
     npos = fmadd3(nd, step, pos)
     return npos, nd
 
@@ -532,14 +533,20 @@ def _lin(terms):
 
 
 def next_ray_rk(S, pos, dirn, h):
-    dist = flen(pos - S.bh_pos)
+    q0 = (pos - S.bh_pos).astype(np.float32)                # N9: position relative to the hole, once per step
+    dist = flen(q0)
     cr = fcross(pos, dirn); h2 = fdot(cr, cr)               # N3: pow(length(v), 2.0) = dot(v, v)
-    k1 = f_acc(S, pos, h2, dist)
-    k2 = f_acc(S, fmadd3(k1 * A21, h, pos), h2, dist)
-    k3 = f_acc(S, fmadd3(_lin([(k1, A31), (k2, A32)]), h, pos), h2, dist)
-    k4 = f_acc(S, fmadd3(_lin([(k1, A41), (k2, A42), (k2, A43)]), h, pos), h2, dist)          # a_43*k_2 (sic, ray.wgsl:431)
-    k5 = f_acc(S, fmadd3(_lin([(k1, A51), (k2, A52), (k3, A53), (k4, A54)]), h, pos), h2, dist)
-    k6 = f_acc(S, fmadd3(_lin([(k1, A61), (k2, A62), (k3, A63), (k4, A64), (k5, A65)]), h, pos), h2, dist)
+    s = f_scale(h2, dist)[:, None]                          # N9: f(p) = (p - bh) * s
+
+    def stage(terms):
+        return (fmadd3(_lin(terms), h, q0) * s).astype(np.float32)
+
+    k1 = (q0 * s).astype(np.float32)
+    k2 = (fmadd3(k1 * A21, h, q0) * s).astype(np.float32)
+    k3 = stage([(k1, A31), (k2, A32)])
+    k4 = stage([(k1, A41), (k2, A42), (k2, A43)])                                            # a_43*k_2 (sic, ray.wgsl:431)
+    k5 = stage([(k1, A51), (k2, A52), (k3, A53), (k4, A54)])
+    k6 = stage([(k1, A61), (k2, A62), (k3, A63), (k4, A64), (k5, A65)])
     ks = (k1, k2, k3, k4, k5, k6)
     es = _lin(list(zip(ks, DB)))
     e = es * h[:, None]

@@ -81,6 +81,8 @@ def lib():
         L.oracle_sky_resolve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.oracle_f32_to_f16.restype = C.c_uint16
         L.oracle_f32_to_f16.argtypes = [C.c_float]
+        L.oracle_set_literal.argtypes = [C.c_int]
+        L.oracle_get_literal.restype = C.c_int
         L.oracle_num_threads.restype = C.c_int
         L.oracle_set_threads.argtypes = [C.c_int]
         _lib = L
@@ -239,3 +241,9 @@ def sky_resolve(prev: np.ndarray, t_sky: np.ndarray) -> np.ndarray:
     rc = lib().oracle_sky_resolve(prev.ctypes.data, w, h, t_sky.ctypes.data, t_sky.shape[1], t_sky.shape[0], out.ctypes.data)
     assert rc == 0
     return out.view(np.float16)
+
+
+def set_literal(on: bool) -> None:
+    """Integrator evaluation: False = the numerics contract (N3, N7, N9; what the HIP kernel computes), True = the shader text
+    operator by operator (N0-N2).  Process-wide switch of the C oracle; tests restore it."""
+    lib().oracle_set_literal(1 if on else 0)

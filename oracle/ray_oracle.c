@@ -40,6 +40,11 @@
  *         sum k_i*c_i  = fma(k_n,c_n, ... fma(k_2,c_2, k_1*c_1))  (left to right; first product rounded)
  *       length / normalize / distance inside the integrator are built on fdot.  Everything else (intersections,
  *       shading, grid classification, create_ray) keeps N0: no contraction.
+ *   N9  reassociation in the integrator (WGSL: "an implementation may reassociate operations"): the scalar factors of f are
+ *       combined once per step, s = (-1.5*h2) * (1/dist^5), positions are taken relative to the hole once per step,
+ *       q0 = p0 - bh, and a stage evaluates f(p0 + h*sum) as fma(sum, h, q0) * s  (6 instead of 12 operations per stage).
+ *   oracle_set_literal(1) switches the integrator to the operator-by-operator reading (N0-N2 only) so that the distance
+ *   between the contract and the literal evaluation can be measured (tests/test_oracle_kat.py).
  * Deviations from the reference, both unobservable in it:
  *   D1  the RK retry loop (ray.wgsl:425-451) cannot change h, so it never terminates when
  *       e_max > 1 (or NaN); it is executed exactly once here.
@@ -531,30 +536,73 @@ static RenderState hit_ray(const scene* S, Ray ray, float t_min, float t_max, fl
 }
 
 /* ---- ray.wgsl:401-403 f ---------------------------------------------------------------------- */
+/* Two evaluations of the integrator.  The CONTRACT one (default; what the HIP kernel computes, bit for bit) uses the
+ * evaluation freedoms WGSL grants - fused multiply-add (N7), pow of small integers by multiplication (N3), and
+ * reassociation (N9): f(p) = (p - bh) * s with the per-step scalar s = (-1.5*h2) * (1/dist^5), and stage positions kept
+ * relative to the hole, q_i = fma(sum_i, h, p0 - bh).  The LITERAL one (oracle_set_literal(1)) evaluates the shader text
+ * operator by operator under N0-N2 (+ d*d*d*d*d for pow(d,5), l*l for pow(l,2)); tests/test_oracle_kat.py measures the
+ * distance between the two, which is what separates any two conforming WGSL implementations. */
+static int g_literal = 0;
+void oracle_set_literal(int on) { g_literal = on != 0; }
+int oracle_get_literal(void) { return g_literal; }
+
 static inline float pow5(float d) { return ((d * d) * (d * d)) * d; }                  /* N3 */
-static inline v3 f_acc(const scene* S, v3 p, float h2, float dist) {
+static inline v3 f_literal(const scene* S, v3 p, float h2, float dist) {
     v3 num = muls(sub(p, fromp(S->bh->position)), -1.5f * h2);
     return divs(num, pow5(dist));
 }
+/* N9: the scalar of f for one step */
+static inline float f_scale(float h2, float dist) { return (-1.5f * h2) * (1.0f / pow5(dist)); }
 
-/* ---- ray.wgsl:405-465 next_ray_rk (D1, N7) ---------------------------------------------------- */
-/* sum of scaled vectors, left to right: first product rounded, the rest fused */
-static inline v3 lin2(v3 a, float ca, v3 b, float cb) { return fmadd3(b, cb, muls(a, ca)); }
-static RKState next_ray_rk(const scene* S, RKState st) {
+/* ---- ray.wgsl:405-465 next_ray_rk (D1) -------------------------------------------------------- */
+static RKState next_ray_rk_literal(const scene* S, RKState st) {
     Ray ray = st.ray;
-    v3 p0 = ray.position;
-    float dist = flength(sub(p0, fromp(S->bh->position)));
-    v3 cr = fcross(p0, ray.direction);
-    float h2 = fdot(cr, cr);                                     /* N3: pow(length(v), 2.0) = dot(v, v) */
-    v3 dydx = f_acc(S, p0, h2, dist);
+    float dist = length(sub(ray.position, fromp(S->bh->position)));
+    float lc = length(cross(ray.position, ray.direction));
+    float h2 = lc * lc;
+    v3 dydx = f_literal(S, ray.position, h2, dist);
 
     float h = st.h;
     v3 k1 = dydx;
-    v3 k2 = f_acc(S, fmadd3(muls(k1, a_21), h, p0), h2, dist);
-    v3 k3 = f_acc(S, fmadd3(lin2(k1, a_31, k2, a_32), h, p0), h2, dist);
-    v3 k4 = f_acc(S, fmadd3(fmadd3(k2, a_43, lin2(k1, a_41, k2, a_42)), h, p0), h2, dist);            /* a_43*k_2 (sic) */
-    v3 k5 = f_acc(S, fmadd3(fmadd3(k4, a_54, fmadd3(k3, a_53, lin2(k1, a_51, k2, a_52))), h, p0), h2, dist);
-    v3 k6 = f_acc(S, fmadd3(fmadd3(k5, a_65, fmadd3(k4, a_64, fmadd3(k3, a_63, lin2(k1, a_61, k2, a_62)))), h, p0), h2, dist);
+    v3 k2 = f_literal(S, add(ray.position, muls(muls(k1, a_21), h)), h2, dist);
+    v3 k3 = f_literal(S, add(ray.position, muls(add(muls(k1, a_31), muls(k2, a_32)), h)), h2, dist);
+    v3 k4 = f_literal(S, add(ray.position, muls(add(add(muls(k1, a_41), muls(k2, a_42)), muls(k2, a_43)), h)), h2, dist);
+    v3 k5 = f_literal(S, add(ray.position, muls(add(add(add(muls(k1, a_51), muls(k2, a_52)), muls(k3, a_53)), muls(k4, a_54)), h)), h2, dist);
+    v3 k6 = f_literal(S, add(ray.position, muls(add(add(add(add(muls(k1, a_61), muls(k2, a_62)), muls(k3, a_63)), muls(k4, a_64)), muls(k5, a_65)), h)), h2, dist);
+
+    v3 es = add(add(add(add(add(muls(k1, db_1), muls(k2, db_2)), muls(k3, db_3)), muls(k4, db_4)), muls(k5, db_5)), muls(k6, db_6));
+    v3 e = muls(es, h);
+    st.e_max = fmax_(fmax_(fabsf(e.x), fabsf(e.y)), fabsf(e.z));
+
+    v3 ds = add(add(add(add(add(muls(k1, b_a_1), muls(k2, b_a_2)), muls(k3, b_a_3)), muls(k4, b_a_4)), muls(k5, b_a_5)), muls(k6, b_a_6));
+    st.ray.direction = normalize(add(st.ray.direction, muls(ds, st.h)));
+    st.ray.position = add(st.ray.position, muls(ray.direction, st.h));   /* old direction */
+
+    if (st.e_max > 0.00002f) st.h = st.h * (0.9f * bh_pow_m001(st.e_max));
+    else st.h = st.h * 1.0001f;
+    return st;
+}
+
+/* contract: N3, N7, N9 */
+/* sum of scaled vectors, left to right: first product rounded, the rest fused */
+static inline v3 lin2(v3 a, float ca, v3 b, float cb) { return fmadd3(b, cb, muls(a, ca)); }
+static RKState next_ray_rk(const scene* S, RKState st) {
+    if (g_literal) return next_ray_rk_literal(S, st);
+    Ray ray = st.ray;
+    v3 p0 = ray.position;
+    v3 q0 = sub(p0, fromp(S->bh->position));                     /* N9: position relative to the hole, once per step */
+    float dist = flength(q0);
+    v3 cr = fcross(p0, ray.direction);
+    float h2 = fdot(cr, cr);                                     /* N3: pow(length(v), 2.0) = dot(v, v) */
+    float s = f_scale(h2, dist);                                 /* N9 */
+
+    float h = st.h;
+    v3 k1 = muls(q0, s);
+    v3 k2 = muls(fmadd3(muls(k1, a_21), h, q0), s);
+    v3 k3 = muls(fmadd3(lin2(k1, a_31, k2, a_32), h, q0), s);
+    v3 k4 = muls(fmadd3(fmadd3(k2, a_43, lin2(k1, a_41, k2, a_42)), h, q0), s);                       /* a_43*k_2 (sic) */
+    v3 k5 = muls(fmadd3(fmadd3(k4, a_54, fmadd3(k3, a_53, lin2(k1, a_51, k2, a_52))), h, q0), s);
+    v3 k6 = muls(fmadd3(fmadd3(k5, a_65, fmadd3(k4, a_64, fmadd3(k3, a_63, lin2(k1, a_61, k2, a_62)))), h, q0), s);
 
     v3 es = fmadd3(k6, db_6, fmadd3(k5, db_5, fmadd3(k4, db_4, fmadd3(k3, db_3, lin2(k1, db_1, k2, db_2)))));
     v3 e = muls(es, h);
@@ -571,12 +619,22 @@ static RKState next_ray_rk(const scene* S, RKState st) {
     return st;
 }
 
-/* ---- ray.wgsl:467-480 next_ray_euler (N7) ------------------------------------------------------- */
+/* ---- ray.wgsl:467-480 next_ray_euler ------------------------------------------------------------ */
+static Ray next_ray_euler_literal(const scene* S, Ray ray, float step) {
+    float lc = length(cross(ray.position, ray.direction));
+    float h2 = lc * lc;
+    float dist = length(sub(ray.position, fromp(S->bh->position)));
+    ray.direction = normalize(add(ray.direction, muls(f_literal(S, ray.position, h2, dist), step)));
+    ray.position = add(ray.position, muls(ray.direction, step));
+    return ray;
+}
 static Ray next_ray_euler(const scene* S, Ray ray, float step) {
+    if (g_literal) return next_ray_euler_literal(S, ray, step);
     v3 cr = fcross(ray.position, ray.direction);
     float h2 = fdot(cr, cr);                                     /* N3: pow(length(v), 2.0) = dot(v, v) */
-    float dist = flength(sub(ray.position, fromp(S->bh->position)));
-    ray.direction = fnormalize(fmadd3(f_acc(S, ray.position, h2, dist), step, ray.direction));
+    v3 q0 = sub(ray.position, fromp(S->bh->position));
+    float dist = flength(q0);
+    ray.direction = fnormalize(fmadd3(muls(q0, f_scale(h2, dist)), step, ray.direction));     /* N9 */
     ray.position = fmadd3(ray.direction, step, ray.position);
     return ray;
 }
@@ -612,7 +670,7 @@ static v4 trace_ray(const scene* S, Ray ray) {
                 curr = rk.ray;
                 step_size = rk.h;
             }
-            float cd = fdistance(curr.position, bpos);                   /* N7: the integrator's distance */
+            float cd = g_literal ? distance(curr.position, bpos) : fdistance(curr.position, bpos);   /* N7: the integrator's distance */
             if (cd < closest_to_bh) closest_to_bh = cd;
             prev.direction = curr.direction;
             crs = hit_ray(S, prev, t_min, step_size, ray_distance, 0, 1);
