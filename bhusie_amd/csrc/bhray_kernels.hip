@@ -362,9 +362,9 @@ __device__ constexpr float A41 = KF(3.0 / 10.0), A42 = KF(-9.0 / 10.0), A43 = KF
 __device__ constexpr float A51 = KF(-11.0 / 54.0), A52 = KF(5.0 / 2.0), A53 = KF(-70.0 / 27.0), A54 = KF(35.0 / 27.0);
 __device__ constexpr float A61 = KF(1631.0 / 55296.0), A62 = KF(175.0 / 512.0), A63 = KF(575.0 / 13824.0),
                            A64 = KF(44275.0 / 110592.0), A65 = KF(253.0 / 4096.0);
-__device__ constexpr float BA1 = KF(2825.0 / 27648.0), BA2 = KF(0.0), BA3 = KF(18575.0 / 48384.0),
+__device__ constexpr float BA1 = KF(2825.0 / 27648.0), BA3 = KF(18575.0 / 48384.0),
                            BA4 = KF(13525.0 / 55296.0), BA5 = KF(277.0 / 14336.0), BA6 = KF(1.0 / 4.0);
-__device__ constexpr float DB1 = KF(37.0 / 378.0 - 2825.0 / 27648.0), DB2 = KF(0.0 - 0.0),
+__device__ constexpr float DB1 = KF(37.0 / 378.0 - 2825.0 / 27648.0),
                            DB3 = KF(250.0 / 621.0 - 18575.0 / 48384.0), DB4 = KF(125.0 / 594.0 - 13525.0 / 55296.0),
                            DB5 = KF(0.0 - 277.0 / 14336.0), DB6 = KF(512.0 / 1771.0 - 1.0 / 4.0);
 
@@ -377,17 +377,19 @@ __device__ __forceinline__ void next_ray_rk(F3 bpos, F3& pos, F3& dir, float& h_
     const float h2 = fdot(cr, cr);                   // N3: pow(length(v), 2.0) = dot(v, v)
     const float s = (-1.5f * h2) * rcp_rn(pow5(dist));   // N9
     const float h = h_io;
-    const F3 k1 = q0 * s;
-    const F3 k2 = fmadd3(k1 * A21, h, q0) * s;
-    const F3 k3 = fmadd3(lin2(k1, A31, k2, A32), h, q0) * s;
-    const F3 k4 = fmadd3(fmadd3(k2, A43, lin2(k1, A41, k2, A42)), h, q0) * s;
-    const F3 k5 = fmadd3(fmadd3(k4, A54, fmadd3(k3, A53, lin2(k1, A51, k2, A52))), h, q0) * s;
-    const F3 k6 = fmadd3(fmadd3(k5, A65, fmadd3(k4, A64, fmadd3(k3, A63, lin2(k1, A61, k2, A62)))), h, q0) * s;
-    const F3 es = fmadd3(k6, DB6, fmadd3(k5, DB5, fmadd3(k4, DB4, fmadd3(k3, DB3, lin2(k1, DB1, k2, DB2)))));
-    const F3 e = es * h;
+    // N10: K_i = h*k_i = (q0 + sum a_ij K_j) * (s*h); zero-coefficient terms (b_2, b*_2) dropped
+    const float sh = s * h;
+    const F3 K1 = q0 * sh;
+    const F3 K2 = fmadd3(K1, A21, q0) * sh;
+    const F3 K3 = fmadd3(K2, A32, fmadd3(K1, A31, q0)) * sh;
+    const F3 K4 = fmadd3(K2, A43, fmadd3(K2, A42, fmadd3(K1, A41, q0))) * sh;
+    const F3 K5 = fmadd3(K4, A54, fmadd3(K3, A53, fmadd3(K2, A52, fmadd3(K1, A51, q0)))) * sh;
+    const F3 K6 = fmadd3(K5, A65, fmadd3(K4, A64, fmadd3(K3, A63, fmadd3(K2, A62, fmadd3(K1, A61, q0))))) * sh;
+    const F3 e = fmadd3(K6, DB6, fmadd3(K5, DB5, fmadd3(K4, DB4, fmadd3(K3, DB3, K1 * DB1))));
     const float e_max = max_(max_(fabsf(e.x), fabsf(e.y)), fabsf(e.z));
-    const F3 ds = fmadd3(k6, BA6, fmadd3(k5, BA5, fmadd3(k4, BA4, fmadd3(k3, BA3, lin2(k1, BA1, k2, BA2)))));
-    dir = fnormalize_rn(fmadd3(ds, h, d0));
+    // the small terms are summed first and added to the unit-length direction once (one rounding at magnitude 1)
+    const F3 ds = fmadd3(K6, BA6, fmadd3(K5, BA5, fmadd3(K4, BA4, fmadd3(K3, BA3, K1 * BA1))));
+    dir = fnormalize_rn(d0 + ds);
     pos = fmadd3(d0, h, p0);
     if (e_max > 0.00002f) h_io = h * (0.9f * bh_pow_m001(e_max));
     else h_io = h * 1.0001f;
@@ -398,7 +400,7 @@ __device__ __forceinline__ void next_ray_euler(F3 bpos, F3& pos, F3& dir, float 
     const F3 cr = fcross(pos, dir);
     const float h2 = fdot(cr, cr);                   // N3: pow(length(v), 2.0) = dot(v, v)
     const float s = (-1.5f * h2) * rcp_rn(pow5(dist));
-    dir = fnormalize_rn(fmadd3((pos - bpos) * s, step, dir));
+    dir = fnormalize_rn(fmadd3(pos - bpos, s * step, dir));   // N9, N10
     pos = fmadd3(dir, step, pos);
 }
 

@@ -518,7 +518,7 @@ def next_ray_euler(S, pos, dirn, step):
     cr = fcross(pos, dirn); h2 = fdot(cr, cr)               # N3: pow(length(v), 2.0) = dot(v, v)
     q0 = (pos - S.bh_pos).astype(np.float32)                # N9: position relative to the hole
     dist = flen(q0)
-    nd = fnorm(fmadd3(q0 * f_scale(h2, dist)[:, None], step, dirn))
+    nd = fnorm(fmadd3(q0, (f_scale(h2, dist) * step).astype(np.float32), dirn))          # N9, N10
     npos = fmadd3(nd, step, pos)
     return npos, nd
 
@@ -538,23 +538,31 @@ def next_ray_rk(S, pos, dirn, h):
     cr = fcross(pos, dirn); h2 = fdot(cr, cr)               # N3: pow(length(v), 2.0) = dot(v, v)
     s = f_scale(h2, dist)[:, None]                          # N9: f(p) = (p - bh) * s
 
-    def stage(terms):
-        return (fmadd3(_lin(terms), h, q0) * s).astype(np.float32)
+    # N10: K_i = h*k_i = (q0 + sum a_ij K_j) * (s*h); zero-coefficient terms (b_2, b*_2) dropped
+    sh = (s * h[:, None]).astype(np.float32)
 
-    k1 = (q0 * s).astype(np.float32)
-    k2 = (fmadd3(k1 * A21, h, q0) * s).astype(np.float32)
-    k3 = stage([(k1, A31), (k2, A32)])
-    k4 = stage([(k1, A41), (k2, A42), (k2, A43)])                                            # a_43*k_2 (sic, ray.wgsl:431)
-    k5 = stage([(k1, A51), (k2, A52), (k3, A53), (k4, A54)])
-    k6 = stage([(k1, A61), (k2, A62), (k3, A63), (k4, A64), (k5, A65)])
-    ks = (k1, k2, k3, k4, k5, k6)
-    es = _lin(list(zip(ks, DB)))
-    e = es * h[:, None]
+    def stage(terms):
+        acc = q0
+        for K, c in terms:
+            acc = fma32(K, c, acc)
+        return (acc * sh).astype(np.float32)
+
+    K1 = (q0 * sh).astype(np.float32)
+    K2 = stage([(K1, A21)])
+    K3 = stage([(K1, A31), (K2, A32)])
+    K4 = stage([(K1, A41), (K2, A42), (K2, A43)])                                            # a_43*k_2 (sic, ray.wgsl:431)
+    K5 = stage([(K1, A51), (K2, A52), (K3, A53), (K4, A54)])
+    K6 = stage([(K1, A61), (K2, A62), (K3, A63), (K4, A64), (K5, A65)])
+    e = (K1 * DB[0]).astype(np.float32)
+    for K, c in ((K3, DB[2]), (K4, DB[3]), (K5, DB[4]), (K6, DB[5])):
+        e = fma32(K, c, e)
     ea = np.abs(e)
     e_max = fmax(fmax(ea[:, 0], ea[:, 1]), ea[:, 2])
     # retry loop (ray.wgsl:425-451) cannot change h: run once
-    ds = _lin(list(zip(ks, BA)))
-    nd = fnorm(fmadd3(ds, h, dirn))
+    ds = (K1 * BA[0]).astype(np.float32)                     # small terms first, then ONE addition to the unit-length direction
+    for K, c in ((K3, BA[2]), (K4, BA[3]), (K5, BA[4]), (K6, BA[5])):
+        ds = fma32(K, c, ds)
+    nd = fnorm((dirn + ds).astype(np.float32))
     npos = fmadd3(dirn, h, pos)                              # old direction (ray.wgsl:456)
     with np.errstate(invalid="ignore"):
         grow = e_max > f32(0.00002)

@@ -43,6 +43,10 @@
  *   N9  reassociation in the integrator (WGSL: "an implementation may reassociate operations"): the scalar factors of f are
  *       combined once per step, s = (-1.5*h2) * (1/dist^5), positions are taken relative to the hole once per step,
  *       q0 = p0 - bh, and a stage evaluates f(p0 + h*sum) as fma(sum, h, q0) * s  (6 instead of 12 operations per stage).
+ *   N10 the step size is distributed into the RK stages: K_i = h*k_i = (q0 + sum_j a_ij K_j) * (s*h), so that
+ *       e = sum (b_i - b*_i) K_i and direction + (sum b*_i K_i) need no further multiplication by h; terms whose tableau
+ *       coefficient is exactly zero (b_2 = b*_2 = 0) are dropped (WGSL lets an implementation assume no NaN/inf, so
+ *       0*k + x = x).  Euler: direction + q0 * (s*step).
  *   oracle_set_literal(1) switches the integrator to the operator-by-operator reading (N0-N2 only) so that the distance
  *   between the contract and the literal evaluation can be measured (tests/test_oracle_kat.py).
  * Deviations from the reference, both unobservable in it:
@@ -596,22 +600,25 @@ static RKState next_ray_rk(const scene* S, RKState st) {
     float h2 = fdot(cr, cr);                                     /* N3: pow(length(v), 2.0) = dot(v, v) */
     float s = f_scale(h2, dist);                                 /* N9 */
 
+    /* N10: the step size is distributed into the stages, K_i = h*k_i = (q0 + sum a_ij K_j) * (s*h); terms whose tableau
+       coefficient is exactly 0 (b_2, b*_2) are dropped */
     float h = st.h;
-    v3 k1 = muls(q0, s);
-    v3 k2 = muls(fmadd3(muls(k1, a_21), h, q0), s);
-    v3 k3 = muls(fmadd3(lin2(k1, a_31, k2, a_32), h, q0), s);
-    v3 k4 = muls(fmadd3(fmadd3(k2, a_43, lin2(k1, a_41, k2, a_42)), h, q0), s);                       /* a_43*k_2 (sic) */
-    v3 k5 = muls(fmadd3(fmadd3(k4, a_54, fmadd3(k3, a_53, lin2(k1, a_51, k2, a_52))), h, q0), s);
-    v3 k6 = muls(fmadd3(fmadd3(k5, a_65, fmadd3(k4, a_64, fmadd3(k3, a_63, lin2(k1, a_61, k2, a_62)))), h, q0), s);
+    float sh = s * h;
+    v3 K1 = muls(q0, sh);
+    v3 K2 = muls(fmadd3(K1, a_21, q0), sh);
+    v3 K3 = muls(fmadd3(K2, a_32, fmadd3(K1, a_31, q0)), sh);
+    v3 K4 = muls(fmadd3(K2, a_43, fmadd3(K2, a_42, fmadd3(K1, a_41, q0))), sh);                        /* a_43*k_2 (sic) */
+    v3 K5 = muls(fmadd3(K4, a_54, fmadd3(K3, a_53, fmadd3(K2, a_52, fmadd3(K1, a_51, q0)))), sh);
+    v3 K6 = muls(fmadd3(K5, a_65, fmadd3(K4, a_64, fmadd3(K3, a_63, fmadd3(K2, a_62, fmadd3(K1, a_61, q0))))), sh);
 
-    v3 es = fmadd3(k6, db_6, fmadd3(k5, db_5, fmadd3(k4, db_4, fmadd3(k3, db_3, lin2(k1, db_1, k2, db_2)))));
-    v3 e = muls(es, h);
+    v3 e = fmadd3(K6, db_6, fmadd3(K5, db_5, fmadd3(K4, db_4, fmadd3(K3, db_3, muls(K1, db_1)))));
     /* yscal = 1, eps = 1: e/yscal and e_max/eps are exact */
     st.e_max = fmax_(fmax_(fabsf(e.x), fabsf(e.y)), fabsf(e.z));
     /* D1: retry loop body cannot change h (h_temp < h for e_max > 1); executed once. */
 
-    v3 ds = fmadd3(k6, b_a_6, fmadd3(k5, b_a_5, fmadd3(k4, b_a_4, fmadd3(k3, b_a_3, lin2(k1, b_a_1, k2, b_a_2)))));
-    st.ray.direction = fnormalize(fmadd3(ds, st.h, st.ray.direction));
+    /* the small terms are summed first and added to the unit-length direction once (one rounding at magnitude 1) */
+    v3 ds = fmadd3(K6, b_a_6, fmadd3(K5, b_a_5, fmadd3(K4, b_a_4, fmadd3(K3, b_a_3, muls(K1, b_a_1)))));
+    st.ray.direction = fnormalize(add(st.ray.direction, ds));
     st.ray.position = fmadd3(ray.direction, st.h, st.ray.position);      /* old direction */
 
     if (st.e_max > 0.00002f) st.h = st.h * (0.9f * bh_pow_m001(st.e_max));
@@ -634,7 +641,7 @@ static Ray next_ray_euler(const scene* S, Ray ray, float step) {
     float h2 = fdot(cr, cr);                                     /* N3: pow(length(v), 2.0) = dot(v, v) */
     v3 q0 = sub(ray.position, fromp(S->bh->position));
     float dist = flength(q0);
-    ray.direction = fnormalize(fmadd3(muls(q0, f_scale(h2, dist)), step, ray.direction));     /* N9 */
+    ray.direction = fnormalize(fmadd3(q0, f_scale(h2, dist) * step, ray.direction));          /* N9, N10 */
     ray.position = fmadd3(ray.direction, step, ray.position);
     return ray;
 }

@@ -160,7 +160,7 @@ def test_portable_functions_track_libm():
 @pytest.mark.parametrize("method", [0, 1])
 def test_contract_vs_literal_evaluation_of_the_integrator(method):
     """The numerics contract evaluates the integrator with the freedoms WGSL grants (N3 integer pow, N7 fused multiply-add,
-    N9 reassociation).  oracle_set_literal(1) evaluates the shader text operator by operator instead.  The two must describe
+    N9/N10 reassociation).  oracle_set_literal(1) evaluates the shader text operator by operator instead.  The two must describe
     the same image: identical pixel classes, a median difference at the rounding level, and only the chaotic rays (photon
     sphere, disk edges - where any two conforming implementations disagree) beyond the 1e-4 parity bar.  Measured at
     649x361, every pixel traced: 0 class differences, median 5e-7, 99.88 % of the pixels within 1e-4 (same statistics for
