@@ -370,9 +370,8 @@ __device__ constexpr float DB1 = KF(37.0 / 378.0 - 2825.0 / 27648.0),
 
 // next_ray_rk, ray.wgsl:405-465.  The retry loop (425-451) cannot change h and is run once.  N7: fused arithmetic.
 // `dist` = flength(pos - bpos), carried from the previous step's exit test (same operands, same value).
-__device__ __forceinline__ void next_ray_rk(F3 bpos, F3& pos, F3& dir, float& h_io, float dist) {
-    const F3 p0 = pos, d0 = dir;
-    const F3 q0 = p0 - bpos;                         // N9: position relative to the hole, once per step
+__device__ __forceinline__ void next_ray_rk(F3 q0, F3& pos, F3& dir, float& h_io, float dist) {
+    const F3 p0 = pos, d0 = dir;           // q0 = p0 - bpos (N9), carried by the caller together with dist = flength(q0)
     const F3 cr = fcross(p0, d0);
     const float h2 = fdot(cr, cr);                   // N3: pow(length(v), 2.0) = dot(v, v)
     const float s = (-1.5f * h2) * rcp_rn(pow5(dist));   // N9
@@ -396,11 +395,11 @@ __device__ __forceinline__ void next_ray_rk(F3 bpos, F3& pos, F3& dir, float& h_
 }
 
 // next_ray_euler, ray.wgsl:467-480 (N7, N9).
-__device__ __forceinline__ void next_ray_euler(F3 bpos, F3& pos, F3& dir, float step, float dist) {
+__device__ __forceinline__ void next_ray_euler(F3 q0, F3& pos, F3& dir, float step, float dist) {
     const F3 cr = fcross(pos, dir);
     const float h2 = fdot(cr, cr);                   // N3: pow(length(v), 2.0) = dot(v, v)
     const float s = (-1.5f * h2) * rcp_rn(pow5(dist));
-    dir = fnormalize_rn(fmadd3(pos - bpos, s * step, dir));   // N9, N10
+    dir = fnormalize_rn(fmadd3(q0, s * step, dir));   // N9, N10
     pos = fmadd3(dir, step, pos);
 }
 
@@ -554,6 +553,7 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
     float amount = 1.0f, step = P.step_size, closest = H.ray_distance;
     float dist_c = P.ray_distance_f;      // flength(integrator position - bpos) (N7), carried between steps
     float cpos_dist = P.ray_distance_f;   // flength(cpos - bpos): equals dist_c except in RK mode after a hit moved cpos
+    F3 qrel = cam - bpos;                 // integrator position - bpos (the operand of dist_c), carried with it: the next step's q0
     int it = 0;
     bool hit = false;
     bool exhausted = false;
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
                     cpos = cam; cdir = rdir; ppos = cam; pdir = rdir;
                     rkpos = cam; rkdir = rdir; rkh = P.step_size;
                     color = f3(0, 0, 0); amount = 1.0f; step = P.step_size; closest = H.ray_distance;
-                    dist_c = P.ray_distance_f; cpos_dist = P.ray_distance_f;
+                    dist_c = P.ray_distance_f; cpos_dist = P.ray_distance_f; qrel = cam - bpos;
                     it = 0; hit = false;
                     mode = P.relativity0 ? M_REL : M_FLAT;
                     if (COUNT) cnt[3]++;
@@ -654,12 +654,12 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
                         mode = M_FINISH;                                   // break (no increment)
                     } else {
                         bool chit = false; Hit crs = rs;
-                        if (hs && ths < rs.t) { cpos = cpos + cdir * ths; mode = M_REL; cpos_dist = fdistance(cpos, bpos); if (METHOD == 0) dist_c = cpos_dist; }
+                        if (hs && ths < rs.t) { cpos = cpos + cdir * ths; mode = M_REL; cpos_dist = fdistance(cpos, bpos); if (METHOD == 0) { dist_c = cpos_dist; qrel = cpos - bpos; } }
                         else { chit = rs.hit; }
                         if (chit) {
                             cpos = cpos + pdir * crs.t;
                             cpos_dist = fdistance(cpos, bpos);
-                            if (METHOD == 0) dist_c = cpos_dist;
+                            if (METHOD == 0) { dist_c = cpos_dist; qrel = cpos - bpos; }
                             const F3 cc = f3(clamp_(crs.color.x, 0.0f, 1.0f), clamp_(crs.color.y, 0.0f, 1.0f), clamp_(crs.color.z, 0.0f, 1.0f));
                             color = color + cc * (amount * crs.opacity);
                             amount *= 1.0f - crs.opacity;
@@ -720,12 +720,13 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
                     ppos = cpos; pdir = cdir;
                     const float ppos_dist = cpos_dist;
                     if (METHOD == 0) {
-                        next_ray_euler(bpos, cpos, cdir, step, dist_c);
+                        next_ray_euler(qrel, cpos, cdir, step, dist_c);
                     } else {
-                        next_ray_rk(bpos, rkpos, rkdir, rkh, dist_c);
+                        next_ray_rk(qrel, rkpos, rkdir, rkh, dist_c);
                         cpos = rkpos; cdir = rkdir; step = rkh;
                     }
-                    const float cd = fdistance_rn(cpos, bpos);     // N7: the integrator's distance (ray.wgsl:533)
+                    qrel = cpos - bpos;
+                    const float cd = sqrt_rn(fdot(qrel, qrel));   // N7: the integrator's distance (ray.wgsl:533) = fdistance(cpos, bpos)
                     dist_c = cd; cpos_dist = cd;                       // Euler: cpos is the integrator position; RK: cpos == rkpos here
                     if (cd < closest) closest = cd;
                     pdir = cdir;
@@ -742,7 +743,7 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
                     if (crs.hit) {
                         cpos = cpos + pdir * crs.t;
                         cpos_dist = fdistance(cpos, bpos);
-                        if (METHOD == 0) dist_c = cpos_dist;
+                        if (METHOD == 0) { dist_c = cpos_dist; qrel = cpos - bpos; }
                         const F3 cc = f3(clamp_(crs.color.x, 0.0f, 1.0f), clamp_(crs.color.y, 0.0f, 1.0f), clamp_(crs.color.z, 0.0f, 1.0f));
                         color = color + cc * (amount * crs.opacity);
                         amount *= 1.0f - crs.opacity;
