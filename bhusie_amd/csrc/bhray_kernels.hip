@@ -188,9 +188,10 @@ __device__ __forceinline__ void shade_disk(const HotParams& P, F3 pos, F3 dir, f
 // shader, so they are the cheapest sufficient ones: |oc| is the distance the integrator already carries for this
 // position (`pos_dist`, within a few ulp of the literal |oc|, far inside the margins), and the plane distance is
 // n.b - n.pos with the constant n.b from the host.
-template <bool COUNT>
-__device__ __forceinline__ void hit_black_hole(const FrameParams& P, const HotParams& H, F3 pos, F3 dir, float pos_dist, float t_min, float t_max,
-                                               float total_distance, Hit& rs, unsigned long long* cnt) {
+// Geometry only.  Returns true when the disk is the nearest hit (its parameter in td_out); the shading of that hit
+// (shade_disk) is run by the caller - the trace kernel defers it to a wave-uniform phase of its own.  rs holds the horizon
+// result (hit, t, colour 0, opacity 1) or "no hit".
+__device__ __forceinline__ bool hit_black_hole_geom(const HotParams& H, F3 pos, F3 dir, float pos_dist, float t_min, float t_max, Hit& rs, float& td_out) {
     const F3 bpos = H.bh;
     const float reach = 1.05f * t_max + 0.05f;
     float ts = t_max, td = t_max;
@@ -202,10 +203,8 @@ __device__ __forceinline__ void hit_black_hole(const FrameParams& P, const HotPa
         if (fabsf(numer) <= (1.01f * t_max) * H.bn_len + 1e-4f * H.bn_len) hd = hit_torus2d(pos, dir, H.inner, H.outer, bpos, bn, t_min, t_max, td);
     }
     rs.hit = hs; rs.t = hs ? ts : t_max; rs.color = f3(0.0f, 0.0f, 0.0f); rs.opacity = hs ? 1.0f : 0.0f;
-    if (hd && td < rs.t) {
-        rs.hit = true; rs.t = td;
-        shade_disk<COUNT>(H, pos, dir, td, total_distance, rs, cnt);
-    }
+    td_out = td;
+    return hd && td < rs.t;
 }
 
 // hit_aabb, ray.wgsl:703-723 (node = two float4 halves).
@@ -499,7 +498,7 @@ __global__ __launch_bounds__(256) void classify_kernel(const FrameParams* __rest
 // ------------------------------------------------------------------------------------------
 // trace: ray.wgsl:269-285 + 482-596
 // ------------------------------------------------------------------------------------------
-enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3 };
+enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, M_SHADE_FLAT = 5 };   // M_SHADE_x: a disk hit waits for its shading, then continues in mode x
 #ifndef BHRAY_REL_BATCH
 #define BHRAY_REL_BATCH 16       // integrator steps between refill / flat / epilogue phases
 #endif
@@ -554,6 +553,7 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
     float dist_c = P.ray_distance_f;      // flength(integrator position - bpos) (N7), carried between steps
     float cpos_dist = P.ray_distance_f;   // flength(cpos - bpos): equals dist_c except in RK mode after a hit moved cpos
     F3 qrel = cam - bpos;                 // integrator position - bpos (the operand of dist_c), carried with it: the next step's q0
+    float pend_t = 0.0f;                  // M_SHADE_*: ray parameter of the disk hit that waits for its shading
     int it = 0;
     bool hit = false;
     bool exhausted = false;
@@ -599,6 +599,23 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
                 }
             }
             if (!__any(mode != M_EMPTY)) break;
+        }
+
+        // ---- deferred disk shading (ray.wgsl:612-663 and the hit bookkeeping of 537-552) for lanes that paused on a disk hit
+        if (__any(mode >= M_SHADE_REL)) {
+            if (mode >= M_SHADE_REL) {
+                Hit crs; crs.hit = true; crs.t = pend_t; crs.color = f3(0.0f, 0.0f, 0.0f); crs.opacity = 0.0f;
+                shade_disk<COUNT>(H, ppos, pdir, pend_t, H.ray_distance, crs, cnt);
+                cpos = cpos + pdir * crs.t;
+                cpos_dist = fdistance(cpos, bpos);
+                if (METHOD == 0) { dist_c = cpos_dist; qrel = cpos - bpos; }
+                const F3 cc = f3(clamp_(crs.color.x, 0.0f, 1.0f), clamp_(crs.color.y, 0.0f, 1.0f), clamp_(crs.color.z, 0.0f, 1.0f));
+                color = color + cc * (amount * crs.opacity);
+                amount *= 1.0f - crs.opacity;
+                hit = true;
+                if (amount < 0.005f) mode = M_FINISH;
+                else { it++; mode = (mode == M_SHADE_FLAT) ? M_FLAT : M_REL; }
+            }
         }
 
         // ---- flat-space iterations (ray.wgsl:554-569), one per lane that is in flat space.
@@ -730,8 +747,8 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
                     dist_c = cd; cpos_dist = cd;                       // Euler: cpos is the integrator position; RK: cpos == rkpos here
                     if (cd < closest) closest = cd;
                     pdir = cdir;
-                    Hit crs;
-                    hit_black_hole<COUNT>(P, H, ppos, pdir, ppos_dist, t_min, step, H.ray_distance, crs, cnt);
+                    Hit crs; float td;
+                    const bool disk = hit_black_hole_geom(H, ppos, pdir, ppos_dist, t_min, step, crs, td);
                     if (cd > H.R) {
                         mode = M_FLAT;
                         const float fw = H.R * H.feather;
@@ -740,7 +757,14 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
                         const float m = lin * lin;
                         cdir = mix3(cdir, rdir, m);
                     }
-                    if (crs.hit) {
+                    if (disk) {
+                        // The shading of a disk hit (~700 instructions, needed by 1-5 lanes of a stepping wave) is deferred to the
+                        // shade phase: the lane pauses with ppos / pdir / td intact and resumes in the mode it has now.
+                        pend_t = td;
+                        mode = (mode == M_FLAT) ? M_SHADE_FLAT : M_SHADE_REL;
+                        continue;
+                    }
+                    if (crs.hit) {                               // horizon: colour 0, opacity 1
                         cpos = cpos + pdir * crs.t;
                         cpos_dist = fdistance(cpos, bpos);
                         if (METHOD == 0) { dist_c = cpos_dist; qrel = cpos - bpos; }
