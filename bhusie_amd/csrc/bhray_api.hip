@@ -653,9 +653,11 @@ int launch_batch(bhray_ctx* c) {
     // half of the block slots: the kernels of the other batches fill the rest, and a wave of a half-size grid pulls
     // more than one load of rays, so the refill keeps its lanes busy (+4 % at 16 slots).
     // Register budget of the no-mesh trace kernel (bhray_kernels.hip): the dense build when the device is saturated with
-    // rays - a whole frame per ctx and several batches in flight - otherwise the latency build (measured on MI355X:
-    // 1920x1080, 16 slots: 3340 vs 3210 Mrays/s; one slot: 2.13 vs 1.95 ms per frame; 1/8 row tile: 0.106 vs 0.101 ms).
-    const bool dense = c->dense_override >= 0 ? c->dense_override != 0 : (c->slots.size() >= 4 && c->cfg.row_world == 1);
+    // rays - at least ~4 whole frames' worth in flight (slots x frames per batch / row partitions) - otherwise the latency
+    // build (measured on MI355X: 1920x1080, 16 slots: 4830 vs 4160 Mrays/s; 1/8 row tile, 16 slots x 8 frames: 0.070 vs
+    // 0.080 ms per frame; one slot: the latency build is 7-15 % faster per launch).
+    const bool dense = c->dense_override >= 0 ? c->dense_override != 0
+                                              : (c->slots.size() * (size_t)c->batch >= 4 * (size_t)c->cfg.row_world);
     int bpc = trace_blocks_per_cu(S.method, S.models, count, dense);
     if (c->slots.size() > 1 && bpc > 1) bpc = bpc > 4 ? 2 : (bpc / 2 > 1 ? bpc / 2 : 1);     // measured: 2 blocks per CU is best at 8-16 slots
     if (c->bpc_override > 0) bpc = c->bpc_override;
