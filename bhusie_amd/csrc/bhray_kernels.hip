@@ -509,7 +509,7 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #define BHRAY_FLAT_DEFER 64        // ... or after this many rounds at the latest (measured 12/4: 2735, 48/64: 2890 Mrays/s)
 #endif
 #ifndef BHRAY_TRACE_WAVES_MESH
-#define BHRAY_TRACE_WAVES_MESH 4 // measured on the mesh workload: 3 -> 2190, 4 -> 2487, 2 -> 1746 Mrays/s
+#define BHRAY_TRACE_WAVES_MESH 8 // mesh variant (BVH traversal + stack): 64 VGPRs, the callee spills around the rare traversal calls; measured on the mesh workload 4 -> 3340, 6 -> 3810, 8 -> 4030 Mrays/s (lone-wave latency +5 %)
 #endif
 #ifndef BHRAY_TRACE_WAVES
 #define BHRAY_TRACE_WAVES 4      // waves per SIMD the trace kernel is register-budgeted for (<=128 VGPRs): the latency build
