@@ -64,10 +64,13 @@ private:
 class RayPipeline {
 public:
     // RayPipeline::new x levels: base resolution, multiplier, iterations as in mod.rs:177-205
-    RayPipeline(std::pair<uint32_t, uint32_t> base, uint32_t multiplier, uint32_t levels, int device = 0, uint32_t frames_in_flight = 1) {
+    // frames_in_flight / frames_per_batch > 1: a host that renders ahead (offline sequences); pass() then only stages a frame
+    // until a batch is full, output()/flush() launch what is staged
+    RayPipeline(std::pair<uint32_t, uint32_t> base, uint32_t multiplier, uint32_t levels, int device = 0, uint32_t frames_in_flight = 1,
+                uint32_t frames_per_batch = 1) {
         std::memset(&cfg_, 0, sizeof cfg_);
         check(bhray_ladder_from_base(base.first, base.second, multiplier, levels, &cfg_));
-        cfg_.device = device; cfg_.frames_in_flight = frames_in_flight;
+        cfg_.device = device; cfg_.frames_in_flight = frames_in_flight; cfg_.frames_per_batch = frames_per_batch;
         check(bhray_create(&cfg_, &ctx_));
     }
     RayPipeline(const RayPipeline&) = delete;
@@ -77,6 +80,7 @@ public:
     void upload_model(const Model& m) { bhray_model_desc d = m.desc(); check(bhray_upload_model(ctx_, 0, &d), ctx_); }
     void set_uniforms(const bhray_camera_uniform& c, const bhray_black_hole_uniform& b, const bhray_details& d) { check(bhray_set_uniforms(ctx_, &c, &b, &d), ctx_); }
     void pass() { check(bhray_render(ctx_), ctx_); }                                            // ray_pipeline.rs:301-309
+    void flush() { check(bhray_flush(ctx_), ctx_); }
     void resolve_sky() { check(bhray_resolve_sky(ctx_), ctx_); }                                // sky_pipeline.rs pass
     std::vector<float> output() {                                                               // output_view + read-back
         std::vector<float> out((size_t)cfg_.frame_w * cfg_.frame_h * 4);

@@ -403,3 +403,22 @@ def test_exact_math_selftest():
     """N8: the integrator's short 1/x and sqrt sequences equal the IEEE results on every binary32 input of this device."""
     rp = B.RayPass(B.ladder_from_base((8, 8), 3, 1), device=0)
     assert rp.selftest() == (0, 0)
+
+
+def test_batch_timing_and_flush_accounting():
+    """bhray_timing counts frames and batches separately; bhray_flush launches a partial batch and is a no-op otherwise."""
+    tex = T.textures()
+    u = T.uniforms(integration_method=1)
+    cfg = B.ladder_from_base((24, 14), 3, 2)
+    rp = B.RayPass(cfg, device=0, timing=True, frames_per_batch=3, frames_in_flight=2)
+    rp.set_textures(*tex); rp.set_uniforms(*u)
+    for _ in range(7):
+        rp.render()
+    rp.flush(); rp.flush()
+    t = rp.timing()
+    assert (t.frames, t.batches) == (7, 3)
+    assert t.trace_launches == 3 * 2 and t.classify_launches == 3 * 2
+    want = O.render_ladder(T.oracle_scene(*u, tex), cfg.sizes())[-1]
+    T.assert_parity(rp.read_hdr(), want, "last frame of a partial batch")
+    t = rp.timing()
+    assert (t.frames, t.batches) == (0, 0)
