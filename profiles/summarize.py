@@ -70,6 +70,11 @@ if cands:
         "bytes_per_launch_corrected": (2.0 * fetch_kb + write_kb) * 1024.0,
         "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of the same bench command, averaged over all launches of the kernel",
     }
+    # VALU issue accounting of the same kernel (SQ pass): wave-instructions per launch and the fraction of its lanes that were active
+    if "SQ_INSTS_VALU_avg_per_launch" in summary[k]:
+        traffic["valu_insts_per_launch"] = summary[k]["SQ_INSTS_VALU_avg_per_launch"]
+        if "SQ_THREAD_CYCLES_VALU_avg_per_launch" in summary[k] and "SQ_ACTIVE_INST_VALU_avg_per_launch" in summary[k]:
+            traffic["valu_active_lane_fraction"] = summary[k]["SQ_THREAD_CYCLES_VALU_avg_per_launch"] / (64.0 * summary[k]["SQ_ACTIVE_INST_VALU_avg_per_launch"])
     json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(traffic, indent=1))
 bl = os.path.join(src, "bench_lines.jsonl")
