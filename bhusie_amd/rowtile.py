@@ -48,12 +48,18 @@ class FrameGather:
         self.max_rows = max(len(x) for x in self.rows)
         self.device = device
         self._local = torch.zeros((batch, self.max_rows, frame_w, 4), dtype=torch.float32, device=device)
+        # every rank owns the same number of whole stripes: the de-interleave is then ONE strided copy (a permutation of
+        # [rank][frame][cycle][stripe row] into [frame][cycle][rank][stripe row]) instead of one index_copy per rank
+        self.regular = frame_h % (stripe_rows * world) == 0
+        self.cycles = frame_h // (stripe_rows * world) if self.regular else 0
+        self.stripe_rows = stripe_rows
         if rank == dst:
-            self.blocks = [torch.zeros_like(self._local) for _ in range(world)]
+            self.stacked = torch.zeros((world,) + tuple(self._local.shape), dtype=torch.float32, device=device)
+            self.blocks = list(self.stacked.unbind(0))            # contiguous views: what the gather fills
             self.frames = torch.zeros((batch, frame_h, frame_w, 4), dtype=torch.float32, device=device)
             self.row_index = [torch.as_tensor(x, dtype=torch.long, device=device) for x in self.rows]
         else:
-            self.blocks, self.frames, self.row_index = None, None, None
+            self.stacked, self.blocks, self.frames, self.row_index = None, None, None, None
 
     @property
     def local(self):
@@ -71,7 +77,7 @@ class FrameGather:
         """Collective over all ranks.  Returns the work handle (or None)."""
         import torch.distributed as dist
         if self.world == 1 and not dist.is_initialized():
-            self.blocks[0] = self._local
+            self.blocks[0].copy_(self._local)
             return None
         return dist.gather(self._local, self.blocks if self.rank == self.dst else None, dst=self.dst,
                            group=self.group, async_op=async_op)
@@ -80,8 +86,12 @@ class FrameGather:
         """Root only: de-interleave the gathered blocks into the (batch, H, W, 4) frames; returns frames[0] when batch == 1."""
         if self.rank != self.dst:
             return None
-        for k in range(self.world):
-            n = len(self.rows[k])
-            if n:
-                self.frames.index_copy_(1, self.row_index[k], self.blocks[k][:, :n])
+        if self.regular:
+            B, C, R, sr, W = self.batch, self.cycles, self.world, self.stripe_rows, self.w
+            self.frames.view(B, C, R, sr, W, 4).copy_(self.stacked.view(R, B, C, sr, W, 4).permute(1, 2, 0, 3, 4, 5))
+        else:
+            for k in range(self.world):
+                n = len(self.rows[k])
+                if n:
+                    self.frames.index_copy_(1, self.row_index[k], self.blocks[k][:, :n])
         return self.frames[0] if self.batch == 1 else self.frames

@@ -58,7 +58,7 @@ def _worker(rank, world, port, w, h, stripe, frame_path, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,stripe", [(2, 9), (2, 27)])
+@pytest.mark.parametrize("world,stripe", [(2, 9), (2, 27), (2, 10)])      # 40 rows: (2, 10) is the regular case (one strided copy)
 def test_gather_reassembles_the_frame(tmp_path, world, stripe):
     import torch.multiprocessing as mp
     from bhusie_amd import assets
