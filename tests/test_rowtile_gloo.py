@@ -49,6 +49,14 @@ def _worker(rank, world, port, w, h, stripe, frame_path, out_path):
         gb.local_frame(i)[:len(mine)] = torch.from_numpy(full[mine]) * float(i + 1)
     gb.gather()
     frames = gb.assemble()
+    # another root (bench.py rotates the root over the batch slots)
+    g1 = FrameGather(w, h, rank, world, stripe, world - 1, device="cpu")
+    g1.local.zero_(); g1.local[:len(mine)] = torch.from_numpy(full[mine])
+    g1.gather()
+    f1 = g1.assemble()
+    assert (f1 is not None) == (rank == world - 1)
+    if rank == world - 1:
+        assert np.array_equal(f1.numpy(), full, equal_nan=True)
     if rank == 0:
         assert frames.shape == (3, h, w, 4)
         for i in range(3):
