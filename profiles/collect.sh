@@ -6,7 +6,7 @@
 #   4. PMC pass: SQ instruction/cycle counters
 # Outputs go to gpurun_out/prof_<tag>/ ; profiles/summarize.py turns them into profiles/<tag>_*.{csv,json}.
 TAG=${1:-r01}
-ARGS=${2:-"--steps 64 --warmup 16 --no-cpu-baseline"}
+ARGS=${2:-"--steps 96 --warmup 24 --no-cpu-baseline"}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
