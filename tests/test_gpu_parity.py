@@ -422,3 +422,26 @@ def test_batch_timing_and_flush_accounting():
     T.assert_parity(rp.read_hdr(), want, "last frame of a partial batch")
     t = rp.timing()
     assert (t.frames, t.batches) == (0, 0)
+
+
+@pytest.mark.parametrize("method", [0, 1])
+def test_mirror_symmetry_at_full_size(method):
+    """A size-independent property at the bench size, without the oracle: with the camera and the disk normal in the plane
+    x = 0, a black sky and the (handed) disk texture / Doppler shading off, the scene is mirror-symmetric in x, and so is
+    every IEEE operation of the path (sign symmetry of +, x, fma; squares in the norms).  Every one of the 2 M pixels of a
+    fully traced 1919x1079 level must therefore equal its mirror image bit for bit: escape directions with x negated, the
+    pixel classes and the disk colours unchanged."""
+    tex = list(T.textures())
+    tex[2] = np.zeros((1, 1, 4), dtype=np.uint8)                               # black sky: even a uniform one is not enough, a(1-t) + a t != a
+    bh = B.BlackHole(accretion_disk_rotation=(0.3, 0.0, 0.0), show_disk_texture=0, show_red_shift=0)
+    u = T.uniforms(black_hole=bh, integration_method=method)
+    cfg = B.ladder_from_base((1919, 1079), 3, 1)
+    img = run_gpu(cfg, *u, tex).read_hdr()
+    assert img.shape == (1079, 1919, 4) and np.isfinite(img).all()
+    mir = img[:, ::-1].copy()
+    direction = img[..., 3] == 0
+    assert 0.2 < direction.mean() < 0.98 and (img[..., 3] == 1).any()           # both classes present
+    assert np.array_equal(img[..., 3], mir[..., 3])
+    mir[..., 0] = np.where(direction, -mir[..., 0], mir[..., 0])
+    assert np.array_equal(img.view(np.uint32) & 0x7FFFFFFF, mir.view(np.uint32) & 0x7FFFFFFF)      # up to the sign of zeros
+    assert np.array_equal(img, mir)
