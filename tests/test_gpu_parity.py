@@ -445,3 +445,25 @@ def test_mirror_symmetry_at_full_size(method):
     mir[..., 0] = np.where(direction, -mir[..., 0], mir[..., 0])
     assert np.array_equal(img.view(np.uint32) & 0x7FFFFFFF, mir.view(np.uint32) & 0x7FFFFFFF)      # up to the sign of zeros
     assert np.array_equal(img, mir)
+
+
+def test_production_configuration_is_invariant_at_full_size():
+    """1920x1080 adaptive RK through the configuration bench.py runs on 8 GPUs (row partition 8 x 27-row stripes,
+    speculative levels 2, frame batches, several slots): the eight partitions together must be the whole frame rendered by
+    a plain ctx (one slot, no speculation, no batches), byte for byte."""
+    tex = T.textures()
+    u = T.uniforms(integration_method=1)
+    cfg = B.ladder_for_frame((1920, 1080), 3, 4)
+    whole = run_gpu(cfg, *u, tex, frames_in_flight=1).read_hdr()
+    assert whole.shape == (1080, 1920, 4) and not np.isnan(whole).any()
+    seen = np.zeros(1080, dtype=bool)
+    for rank in range(8):
+        rp = B.RayPass(cfg, device=0, row_rank=rank, row_world=8, stripe_rows=27, speculative_levels=2, frames_per_batch=2, frames_in_flight=3)
+        rp.set_textures(*tex); rp.set_uniforms(*u)
+        for _ in range(5):
+            rp.render()
+        rows = rp.local_rows()
+        assert np.array_equal(rp.read_hdr(), whole[rows]), f"rank {rank}"
+        seen[rows] = True
+        rp.close()
+    assert seen.all()
