@@ -744,9 +744,8 @@ int launch_batch(bhray_ctx* c) {
     }
     if (args_used > S.args_cap) return fail(c, BHRAY_E_STATE, "internal: argument block overflow");
     // enqueue
-    HIPCHK(c, launch_upload(S.h_args, S.d_args, (args_used + 15) / 16, st));
+    HIPCHK(c, launch_upload(S.h_args, S.d_args, (args_used + 15) / 16, S.d_qctl, (size_t)nb * 2 * BHRAY_MAX_LEVELS, st));   // + queue control reset
     HIPCHK(c, hipEventRecord(S.uploaded, st));
-    HIPCHK(c, hipMemsetAsync(S.d_qctl, 0, (size_t)nb * 2 * BHRAY_MAX_LEVELS * sizeof(uint32_t), st));
     if (count) HIPCHK(c, hipMemsetAsync(S.d_counters, 0, (size_t)nb * BHRAY_MAX_LEVELS * sizeof(Counters64), st));
     const size_t ring = (size_t)(c->batch_counter % BHRAY_TIMING_RING);
     hipEvent_t* fev = timing ? &c->events[ring * (nl * 3 + 2)] : nullptr;

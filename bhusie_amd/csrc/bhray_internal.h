@@ -100,7 +100,8 @@ hipError_t launch_trace(const FrameParams* Pb, const FrameLaunch* Fb, int nb, in
 int trace_blocks_per_cu(int method, int has_models, int count, int dense);
 // copies n16 16-byte words from pinned host memory to device memory with a kernel (stays on the compute queue: a DMA copy
 // between the launches of a stream costs a cross-engine handshake each time)
-hipError_t launch_upload(const void* pinned_src, void* dst, size_t n16, hipStream_t s);
+// and zeroes `nzero` 32-bit words at `zero` (the queue control words of the batch) in the same launch
+hipError_t launch_upload(const void* pinned_src, void* dst, size_t n16, uint32_t* zero, size_t nzero, hipStream_t s);
 hipError_t launch_selftest(unsigned long long* bad2, hipStream_t s);   // bad2[0]: 1/x mismatches, bad2[1]: sqrt mismatches
 hipError_t launch_sky(const TexDev& sky, const float4* src, uint2* dst_rgba16f, size_t npix, hipStream_t s);
 

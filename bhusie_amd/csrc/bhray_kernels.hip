@@ -842,15 +842,18 @@ hipError_t launch_selftest(unsigned long long* bad2, hipStream_t s) {
     return hipGetLastError();
 }
 
-// argument-block upload (pinned host memory -> HBM), see launch_upload
-__global__ __launch_bounds__(256) void upload_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+// argument-block upload (pinned host memory -> HBM) + reset of the batch's queue control words, see launch_upload
+__global__ __launch_bounds__(256) void upload_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16,
+                                                     uint32_t* __restrict__ zero, size_t nzero) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n16) dst[i] = src[i];
+    if (i < nzero) zero[i] = 0u;
 }
 
-hipError_t launch_upload(const void* pinned_src, void* dst, size_t n16, hipStream_t s) {
-    if (n16 == 0) return hipSuccess;
-    hipLaunchKernelGGL(upload_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (const uint4*)pinned_src, (uint4*)dst, n16);
+hipError_t launch_upload(const void* pinned_src, void* dst, size_t n16, uint32_t* zero, size_t nzero, hipStream_t s) {
+    const size_t n = n16 > nzero ? n16 : nzero;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(upload_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)pinned_src, (uint4*)dst, n16, zero, nzero);
     return hipGetLastError();
 }
 
