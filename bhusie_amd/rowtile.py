@@ -29,6 +29,13 @@ def max_local_rows(frame_h: int, world: int, stripe_rows: int = 27) -> int:
     return max(len(x) for x in partition_rows(frame_h, world, stripe_rows))
 
 
+class _Done:
+    """Work handle of a collective that has already completed."""
+
+    def wait(self):
+        return True
+
+
 class FrameGather:
     """Gathers packed per-rank row blocks to `dst` and de-interleaves them into the frame(s).
 
@@ -79,6 +86,17 @@ class FrameGather:
         if self.world == 1 and not dist.is_initialized():
             self.blocks[0].copy_(self._local)
             return None
+        if self._local.is_cuda and dist.get_backend(self.group) == "gloo":
+            # functional-test path (several ranks on ONE GPU, bench.py --backend gloo): gloo cannot move device tensors, so
+            # the block is staged through host memory, synchronously.  Same buffers, same de-interleave.
+            self.torch.cuda.current_stream().synchronize()
+            host = self._local.cpu()
+            parts = [self.torch.empty_like(host) for _ in range(self.world)] if self.rank == self.dst else None
+            dist.gather(host, parts, dst=self.dst, group=self.group)
+            if self.rank == self.dst:
+                for k in range(self.world):
+                    self.blocks[k].copy_(parts[k])
+            return _Done() if async_op else None
         return dist.gather(self._local, self.blocks if self.rank == self.dst else None, dst=self.dst,
                            group=self.group, async_op=async_op)
 
