@@ -66,6 +66,11 @@ def main():
     out.append(run("camera outside the sphere (0,3,-45), 960x540, adaptive RK", B.ladder_for_frame((960, 540), 3, 4), cam2, bh, B.RayDetails(integration_method=1)))
     out.append(run("960x540, disk texture + red shift off, step 0.25", B.ladder_for_frame((960, 540), 3, 4), cam,
                    B.BlackHole(show_disk_texture=0, show_red_shift=0), B.RayDetails(integration_method=0, step_size=0.25)))
+    # configs[3] / configs[4] frame sizes on one GPU (the 8-GPU runs render row tiles of exactly these frames)
+    out.append(run("configs[3] frame: 3840x2160, adaptive RK", B.ladder_for_frame((3840, 2160), 3, 4), cam, bh, B.RayDetails(integration_method=1),
+                   speculative_levels=2, frames_per_batch=2))
+    out.append(run("configs[4] frame: 7680x4320, adaptive RK, 2048 max integrator steps", B.ladder_for_frame((7680, 4320), 3, 4), cam, bh,
+                   B.RayDetails(integration_method=1, max_iterations=2048), speculative_levels=2))
     json.dump(out, sys.stdout, indent=1)
 
 
