@@ -148,6 +148,23 @@ std::vector<int32_t> coarse_rows_needed(const std::vector<int32_t>& fine, int h,
     return out;
 }
 
+// bh_acos(c) < thr  <=>  c > acos_threshold(thr)  for c in [-1, 1]: bh_acos is monotone non-increasing over all binary32 values
+// of the interval (exhaustive check: bhray_selftest), so the set where the predicate holds is an upper interval; its lower end is
+// found by bisection over the ordered bit patterns with the same bh_acos the kernels use.
+float acos_threshold(float thr) {
+    if (!(thr == thr)) return INFINITY;                              // NaN threshold: never smaller
+    if (!(bh_acos(1.0f) < thr)) return INFINITY;                     // not even angle 0 is below the threshold
+    if (bh_acos(-1.0f) < thr) return u2f(0xbf800001u);               // every c of [-1, 1] is: c > (largest float below -1)
+    // ordered keys: k < 0 <-> x = -|bits|, k >= 0 <-> x = +bits; x(k) increasing in k
+    auto xk = [](int64_t k) { return k >= 0 ? u2f((uint32_t)k) : u2f(0x80000000u | (uint32_t)(-k)); };
+    int64_t lo = -(int64_t)0x3f800000, hi = (int64_t)0x3f800000;     // predicate false at lo (x = -1), true at hi (x = 1)
+    while (hi - lo > 1) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        if (bh_acos(xk(mid)) < thr) hi = mid; else lo = mid;
+    }
+    return xk(lo);                                                   // the largest c whose angle is not below the threshold
+}
+
 void derive_frame(const bhray_ctx* c, FrameParams& P) {
     memset(&P, 0, sizeof P);
     const bhray_camera_uniform& cam = c->cam;
@@ -178,6 +195,7 @@ void derive_frame(const bhray_ctx* c, FrameParams& P) {
     P.feather = bh.feather_amount;
     P.time = d.time; P.method = d.integration_method != 0 ? 1 : 0; P.step_size = d.step_size;
     P.max_iter = d.max_iterations; P.thr = d.angle_division_threshold;
+    P.acos_cstar = acos_threshold(P.thr);
     int mc = d.model_count; if (mc < 0) mc = 0; if (mc > BHRAY_MAX_MODELS) mc = BHRAY_MAX_MODELS;
     int usable = 0;
     for (int i = 0; i < mc; i++) {
@@ -939,18 +957,18 @@ int bhray_signal_stream(bhray_ctx* c, void* s) {
     return BHRAY_OK;
 }
 
-int bhray_selftest(bhray_ctx* c, uint64_t mismatches[2]) {
+int bhray_selftest(bhray_ctx* c, uint64_t mismatches[3]) {
     if (!c || !mismatches) return BHRAY_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     unsigned long long* d = nullptr;
-    HIPCHK(c, hipMalloc(&d, 16));
-    hipError_t e = hipMemset(d, 0, 16);
+    HIPCHK(c, hipMalloc(&d, 24));
+    hipError_t e = hipMemset(d, 0, 24);
     if (e == hipSuccess) e = launch_selftest(d, nullptr);
-    unsigned long long h[2] = {0, 0};
-    if (e == hipSuccess) e = hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+    unsigned long long h[3] = {0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(c, BHRAY_E_HIP, "selftest: %s", hipGetErrorString(e));
-    mismatches[0] = h[0]; mismatches[1] = h[1];
+    mismatches[0] = h[0]; mismatches[1] = h[1]; mismatches[2] = h[2];
     return BHRAY_OK;
 }
 

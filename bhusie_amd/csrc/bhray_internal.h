@@ -55,6 +55,7 @@ struct FrameParams {
     float step_size;
     int max_iter;
     float thr;
+    float acos_cstar;      // largest c with bh_acos(c) >= thr (host, binary search): bh_acos(c) < thr <=> c > acos_cstar on [-1, 1]
     int model_count;
     TexDev temp, disk, sky;
     ModelDev models[BHRAY_MAX_MODELS];
@@ -102,7 +103,7 @@ int trace_blocks_per_cu(int method, int has_models, int count, int dense);
 // between the launches of a stream costs a cross-engine handshake each time)
 // and zeroes `nzero` 32-bit words at `zero` (the queue control words of the batch) in the same launch
 hipError_t launch_upload(const void* pinned_src, void* dst, size_t n16, uint32_t* zero, size_t nzero, hipStream_t s);
-hipError_t launch_selftest(unsigned long long* bad2, hipStream_t s);   // bad2[0]: 1/x mismatches, bad2[1]: sqrt mismatches
+hipError_t launch_selftest(unsigned long long* bad3, hipStream_t s);   // [0]: 1/x mismatches, [1]: sqrt mismatches, [2]: places where bh_acos increases
 hipError_t launch_sky(const TexDev& sky, const float4* src, uint2* dst_rgba16f, size_t npix, hipStream_t s);
 
 }  // namespace bhray

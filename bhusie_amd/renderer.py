@@ -161,10 +161,11 @@ class RayPass:
         return c.as_dict()
 
     def selftest(self):
-        """(1/x mismatches, sqrt mismatches) of the step loop's short sequences vs IEEE over all 2^32 inputs; both must be 0."""
-        m = (C.c_uint64 * 2)()
+        """(1/x mismatches, sqrt mismatches, places where the portable acos increases): exhaustive device checks of the
+        properties the exact shortcuts rest on; all must be 0."""
+        m = (C.c_uint64 * 3)()
         check(lib().bhray_selftest(self._h, m), self._h)
-        return int(m[0]), int(m[1])
+        return int(m[0]), int(m[1]), int(m[2])
 
     def timing(self) -> BhrayTiming:
         t = BhrayTiming()

@@ -292,10 +292,11 @@ typedef struct bhray_counters {        /* summed over all levels of the last ren
 int bhray_get_counters(bhray_ctx* ctx, bhray_counters* out);   /* needs BHRAY_F_COUNTERS     */
 int bhray_get_level_counters(bhray_ctx* ctx, uint32_t level, bhray_counters* out);
 
-/* Device self-test of the numerics contract's hardware-dependent part: the integrator computes the correctly
- * rounded 1/x and sqrt(x) with short gfx950 sequences; this runs them against the IEEE lowering on all 2^32 binary32 bit
- * patterns and returns the number of differing inputs (both must be 0).  ~10 ms.                                    */
-int bhray_selftest(bhray_ctx* ctx, uint64_t mismatches[2]);    /* [0] = 1/x, [1] = sqrt       */
+/* Device self-test of the properties two exact shortcuts rest on: (i) the integrator computes the correctly
+ * rounded 1/x and sqrt(x) with short gfx950 sequences — run against the IEEE lowering on all 2^32 binary32 bit patterns;
+ * (ii) the grid classification replaces `acos(c) < threshold` by `c > c*` — the portable acos must be monotone over every
+ * binary32 value of [-1, 1].  Returns the number of violating inputs of each (all must be 0).  ~20 ms.              */
+int bhray_selftest(bhray_ctx* ctx, uint64_t mismatches[3]);    /* [0] = 1/x, [1] = sqrt, [2] = acos monotonicity */
 
 /* HIP-event timing of every launch (events recorded on the ctx stream).  bhray_get_timing sums
  * over the batches launched since the previous call (at most BHRAY_TIMING_RING of them).     */

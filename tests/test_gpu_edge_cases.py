@@ -178,3 +178,18 @@ def test_fuzz_mesh_scenes(tmp_path):
         rp.close()
         tested += cnt.triangles; visited += cnt.node_pairs
     assert tested > 1000 and visited > 10000            # the sweep does exercise the traversal
+
+
+@pytest.mark.parametrize("thr", [0.0, -1.0, 1e-9, 0.02, 0.5235988, 1.5707964, 3.1415925, 3.1415927, 4.0, float("nan"), float("inf")])
+def test_angle_threshold_values(thr):
+    """The grid classification compares c = cos(angle) with a host-computed c* instead of acos(c) with the threshold
+    (bh_acos is monotone: bhray_selftest).  Every threshold - none / all pixels interpolated, NaN, the branch points of the
+    portable acos - must classify exactly as the oracle's literal acos(c) < threshold."""
+    tex = T.textures()
+    u = T.uniforms(integration_method=1, angle_division_threshold=thr)
+    cfg = B.ladder_from_base((24, 14), 3, 3)
+    cnt = O.Counters()
+    want = O.render_ladder(T.oracle_scene(*u, tex), cfg.sizes(), cnt)
+    rp = B.RayPass(cfg, device=0, counters=True); rp.set_textures(*tex); rp.set_uniforms(*u); rp.render()
+    check(rp.read_hdr(), want[-1], f"threshold {thr}")
+    assert rp.counters() == cnt.as_dict()
