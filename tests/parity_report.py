@@ -50,6 +50,27 @@ def run(name, cfg, cam, bh, det, model=None, **kw):
             "counters": rp.counters()}
 
 
+def run_vs_literal(name, cfg, cam, bh, det):
+    """HIP path against the oracle's LITERAL evaluation of the integrator (operator by operator, no N3/N7/N9/N10): the
+    distance any two conforming WGSL implementations may show.  Informative; the parity bar applies to the contract oracle."""
+    rp = B.RayPass(cfg, device=0)
+    rp.set_textures(*tex); rp.set_uniforms(cam.uniform(), bh.uniform(), det.uniform()); rp.render()
+    got = rp.read_hdr()
+    try:
+        O.set_literal(True)
+        want = O.render_ladder(O.OracleScene(cam.uniform(), bh.uniform(), det.uniform(), *tex, []), cfg.sizes())[-1]
+    finally:
+        O.set_literal(False)
+    cx, cy = int(cfg.crop_x), int(cfg.crop_y)
+    want = want[cy:cy + int(cfg.frame_h), cx:cx + int(cfg.frame_w)]
+    same = got[..., 3] == want[..., 3]
+    with np.errstate(invalid="ignore"):
+        e = (np.abs(got - want) / np.maximum(np.abs(want), 1e-3))[same].max(axis=-1)
+    return {"config": name + " — vs the LITERAL evaluation (informative)", "pixels": int(same.size), "class_differences": int((~same).sum()),
+            "median_rel_err": float(np.median(e)), "p99_rel_err": float(np.quantile(e, 0.99)), "fraction_within_1e-4": float((e <= 1e-4).mean()),
+            "max_rel_err": float(e.max())}
+
+
 def main():
     out = []
     cam, bh = B.Camera(), B.BlackHole()
@@ -71,6 +92,8 @@ def main():
                    speculative_levels=2, frames_per_batch=2))
     out.append(run("configs[4] frame: 7680x4320, adaptive RK, 2048 max integrator steps", B.ladder_for_frame((7680, 4320), 3, 4), cam, bh,
                    B.RayDetails(integration_method=1, max_iterations=2048), speculative_levels=2))
+    out.append(run_vs_literal("configs[1]: 1920x1080, adaptive RK", B.ladder_for_frame((1920, 1080), 3, 4), cam, bh, B.RayDetails(integration_method=1)))
+    out.append(run_vs_literal("1920x1080, Euler", B.ladder_for_frame((1920, 1080), 3, 4), cam, bh, B.RayDetails(integration_method=0)))
     json.dump(out, sys.stdout, indent=1)
 
 
