@@ -314,22 +314,21 @@ __device__ __noinline__ void trace_ray_model(const ModelDev& M, F3 pos, F3 dir, 
 // Correctly rounded 1/x and sqrt(x) for the step loop.  The compiler's IEEE lowering spends 11 (division) and 16 (sqrt)
 // instructions, mostly on scaling for denormal inputs/results.  On gfx950 the hardware approximations are good enough that
 //   1/x     = v_rcp_f32 + one Newton step in FMA                 for 2^-125 <= |x| < 2^126
-//   sqrt(x) = v_sqrt_f32 + the two-sided one-ulp FMA correction   for 2^-95 <= x <= 2^95
+//   sqrt(x) = v_rsq_f32 + one residual correction in FMA           for 2^-95 <= x <= 2^95
 // equal the IEEE result for EVERY input in those ranges (verified exhaustively, all 2^32 bit patterns: bhray_selftest,
-// tests/test_gpu_parity.py, profiles/ubench/exact_math.hip).  Outside the range - decided per wave, so the branch is uniform -
-// the IEEE lowering runs.  Same bits as `1.0f / x` and `sqrtf(x)`, 5-7 instructions less per use.
+// tests/test_gpu_parity.py, profiles/ubench/exact_math.hip, exact_norm.hip).  Outside the range - decided per wave, so the branch is uniform -
+// the IEEE lowering runs.  Same bits as `1.0f / x` and `sqrtf(x)`, 7-11 instructions less per use.
 __device__ __forceinline__ float rcp_newton(float x) {
     float r = __builtin_amdgcn_rcpf(x);
     const float e = __builtin_fmaf(-x, r, 1.0f);
     return __builtin_fmaf(e, r, r);
 }
 __device__ __forceinline__ float sqrt_corrected(float x) {
-    float s = __builtin_amdgcn_sqrtf(x);
-    const float sm = u2f(f2u(s) - 1u), sp = u2f(f2u(s) + 1u);
-    const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
-    s = rm <= 0.0f ? sm : s;
-    s = rp > 0.0f ? sp : s;
-    return s;
+    // v_rsq_f32 (1 ulp) and one residual correction in FMA (Markstein): s0 = x*y, s = s0 + (x - s0*s0) * y/2
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float s0 = x * y;
+    const float res = __builtin_fmaf(-s0, s0, x);
+    return __builtin_fmaf(res, 0.5f * y, s0);
 }
 __device__ __forceinline__ bool rcp_in_range(float x) { return fabsf(x) >= 0x1p-125f && fabsf(x) < 0x1p126f; }
 __device__ __forceinline__ bool sqrt_in_range(float x) { return x >= 0x1p-95f && x <= 0x1p95f; }
