@@ -6,10 +6,17 @@ the reference host types on the path (RayDetails, CameraUniform, BlackHoleUnifor
 RayPipeline ladder).  Nothing here computes pixels on the CPU; importing the bindings fails loudly
 when the HIP library has not been built.
 """
+import os as _os
+
+# Frame slots run on separate HIP streams and ROCm maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues; aliased
+# streams serialise.  This host layer keeps up to 16 frames in flight (+ the communication streams of a gather), so it raises
+# the limit unless the user set one — it must happen before the first HIP call.  (libbhray itself never touches the environment.)
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+
 from ._lib import lib, LibraryMissing, LIB_PATH  # noqa: F401
 from .layouts import (BhrayConfig, BhrayCounters, BhrayTiming, BhrayDetails, BhrayCameraUniform,  # noqa: F401
                       BhrayBlackHoleUniform, BhrayBlackHole, BhrayModelDesc, BhrayNode, BhrayTriangle,
                       BhrayError, check)
 from .scene import Camera, BlackHole, RayDetails  # noqa: F401
 from .model import Model, load_model  # noqa: F401
-from .renderer import RayPass, Renderer, ladder_from_base, ladder_for_frame  # noqa: F401
+from .renderer import RayPass, Renderer, ladder_from_base, ladder_for_frame, comm_unique_id, partition_rows  # noqa: F401

@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include "bhray_dev.h"
 #include "bhray_internal.h"
 #include "bhray_math.h"
 
@@ -22,10 +23,9 @@ using namespace bhray;
 
 namespace {
 
-// Frame slots run on separate HIP streams; ROCm maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues, so
-// 4+ slots would serialise pairwise.  Raise the default when the library is loaded (no effect if the caller set it or
-// the HIP runtime is already initialised).
-__attribute__((constructor)) void bhray_env_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// Frame slots run on separate HIP streams; ROCm maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues, so 4+ slots
+// serialise pairwise unless the HOST raises the limit before the HIP runtime initialises (include/bhray.h, frames in flight).
+// The library does not touch the process environment.
 
 thread_local std::string g_create_error;
 
@@ -52,7 +52,7 @@ struct FrameRes {
 };
 
 // One batch in flight: a HIP stream, the frames of the batch (frames_per_batch of them) and the argument block of its
-// launches.  bhray_render stages a frame (host work only); the launches of the whole batch are enqueued when the batch is
+// launches.  dev_render stages a frame (host work only); the launches of the whole batch are enqueued when the batch is
 // full or flushed, each launch covering all staged frames.
 struct Slot {
     hipStream_t stream = nullptr;
@@ -82,7 +82,7 @@ struct ModelStore {
 
 }  // namespace
 
-struct bhray_ctx {
+struct bhray_dev {
     bhray_config cfg{};
     int device = 0;
     std::vector<Level> levels;
@@ -90,9 +90,11 @@ struct bhray_ctx {
     uint32_t batch = 1;                    // frames per batch
     int last_slot = 0, last_sub = 0;       // slot / position in its batch of the most recently rendered frame
     uint64_t batch_counter = 0;            // batches launched so far; the staging slot is batch_counter % slots
-    float4* bound_out = nullptr;           // bhray_bind_output: destination of the next frame(s)
-    hipEvent_t wait_ev = nullptr;          // bhray_wait_stream: pending dependency of the next render
-    bool wait_pending = false;
+    bhray::DevOptions opt;
+    float4* bound_out = nullptr;           // dev_bind_output: destination of the next frame (one-shot)
+    std::vector<hipEvent_t> waits;         // dev_wait_event: pending dependencies of the next render (events owned by the caller)
+    int launched_slot = -1;                // dev_take_launched
+    uint32_t launched_frames = 0;
     size_t out_bytes = 0;
     std::vector<uint32_t> local_rows;      // frame rows of this partition, increasing
     // scene
@@ -104,7 +106,7 @@ struct bhray_ctx {
     bhray_details det{};
     bool have_uniforms = false;
     std::vector<hipEvent_t> events;        // ring: [BHRAY_TIMING_RING][levels][3] (before classify, before trace, after trace)
-    uint64_t frame_counter = 0, timing_begin = 0;   // timing_begin: first batch not yet reported by bhray_get_timing
+    uint64_t frame_counter = 0, timing_begin = 0;   // timing_begin: first batch not yet reported by dev_get_timing
     uint8_t sky_recorded[BHRAY_TIMING_RING] = {0};
     uint8_t ring_frames[BHRAY_TIMING_RING] = {0};   // frames of the batch held by each timing-ring entry
     int* d_err = nullptr;
@@ -117,7 +119,7 @@ struct bhray_ctx {
 
 namespace {
 
-int fail(bhray_ctx* ctx, int code, const char* fmt, ...) {
+int fail(bhray_dev* ctx, int code, const char* fmt, ...) {
     char buf[512];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
     if (ctx) ctx->err = buf; else g_create_error = buf;
@@ -149,7 +151,7 @@ std::vector<int32_t> coarse_rows_needed(const std::vector<int32_t>& fine, int h,
 }
 
 // bh_acos(c) < thr  <=>  c > acos_threshold(thr)  for c in [-1, 1]: bh_acos is monotone non-increasing over all binary32 values
-// of the interval (exhaustive check: bhray_selftest), so the set where the predicate holds is an upper interval; its lower end is
+// of the interval (exhaustive check: dev_selftest), so the set where the predicate holds is an upper interval; its lower end is
 // found by bisection over the ordered bit patterns with the same bh_acos the kernels use.
 float acos_threshold(float thr) {
     if (!(thr == thr)) return INFINITY;                              // NaN threshold: never smaller
@@ -165,7 +167,7 @@ float acos_threshold(float thr) {
     return xk(lo);                                                   // the largest c whose angle is not below the threshold
 }
 
-void derive_frame(const bhray_ctx* c, FrameParams& P) {
+void derive_frame(const bhray_dev* c, FrameParams& P) {
     memset(&P, 0, sizeof P);
     const bhray_camera_uniform& cam = c->cam;
     const bhray_black_hole_uniform& bh = c->bh;
@@ -216,9 +218,9 @@ void derive_frame(const bhray_ctx* c, FrameParams& P) {
     for (int i = 0; i < 3; i++) { t[i]->rgba = c->tex[i]; t[i]->w = c->tex_w[i]; t[i]->h = c->tex_h[i]; }
 }
 
-int launch_batch(bhray_ctx* c);
+int launch_batch(bhray_dev* c);
 
-hipError_t sync_all(bhray_ctx* c) {
+hipError_t sync_all(bhray_dev* c) {
     for (Slot& S : c->slots) {
         hipError_t e = hipStreamSynchronize(S.stream);
         if (e != hipSuccess) return e;
@@ -257,7 +259,6 @@ const char* bhray_strerror(int code) {
 
 uint32_t bhray_version(void) { return (BHRAY_VERSION_MAJOR << 16) | BHRAY_VERSION_MINOR; }
 
-const char* bhray_last_error(const bhray_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 int bhray_device_count(void) {
     int n = 0;
@@ -295,7 +296,16 @@ int bhray_ladder_for_frame(uint32_t frame_w, uint32_t frame_h, uint32_t m, uint3
     return BHRAY_OK;
 }
 
-void bhray_destroy(bhray_ctx* c) {
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// per-device engine (bhray_dev.h): one partition of the frame on one GPU.  The public bhray_ctx (bhray_group.hip) owns one
+// of these per local partition.
+// ------------------------------------------------------------------------------------------
+const char* dev_last_error(const bhray_dev* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+void dev_set_create_error(const char* msg) { g_create_error = msg ? msg : ""; }
+
+void dev_destroy(bhray_dev* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (Slot& S : c->slots) if (S.stream) (void)hipStreamSynchronize(S.stream);
@@ -323,12 +333,11 @@ void bhray_destroy(bhray_ctx* c) {
     for (auto& t : c->tex) if (t) (void)hipFree(t);
     for (auto& m : c->models) free_model(m);
     for (auto& e : c->events) if (e) (void)hipEventDestroy(e);
-    if (c->wait_ev) (void)hipEventDestroy(c->wait_ev);
     if (c->d_err) (void)hipFree(c->d_err);
     delete c;
 }
 
-int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
+int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev** out) {
     if (!cfg || !out) return fail(nullptr, BHRAY_E_INVALID, "null argument");
     *out = nullptr;
     if (cfg->struct_size != sizeof(bhray_config)) return fail(nullptr, BHRAY_E_INVALID, "bhray_config.struct_size mismatch");
@@ -350,16 +359,17 @@ int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
         return fail(nullptr, BHRAY_E_NO_DEVICE, "no HIP device visible (libbhray has no CPU path)");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, BHRAY_E_NO_DEVICE, "device %d not present (%d visible)", cfg->device, ndev);
 
-    bhray_ctx* c = new (std::nothrow) bhray_ctx();
+    bhray_dev* c = new (std::nothrow) bhray_dev();
     if (!c) return fail(nullptr, BHRAY_E_NOMEM, "host allocation failed");
     c->cfg = *cfg;
     c->device = cfg->device;
+    c->opt = opt;
 #define CHK(call)                                                                                             \
     do {                                                                                                      \
         hipError_t e_ = (call);                                                                               \
         if (e_ != hipSuccess) {                                                                               \
             int rc_ = fail(nullptr, BHRAY_E_HIP, "%s: %s", #call, hipGetErrorString(e_));                     \
-            bhray_destroy(c);                                                                                 \
+            dev_destroy(c);                                                                                 \
             return rc_;                                                                                       \
         }                                                                                                     \
     } while (0)
@@ -374,7 +384,6 @@ int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
     c->slots.resize(nslots);
     c->batch = cfg->frames_per_batch ? cfg->frames_per_batch : 1;
     c->cfg.frames_per_batch = c->batch;
-    CHK(hipEventCreateWithFlags(&c->wait_ev, hipEventDisableTiming));
 
     // rows of the frame owned by this partition
     for (uint32_t r = 0; r < cfg->frame_h; r++)
@@ -402,12 +411,12 @@ int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
         L.queue_cap = nrows * span;
         if (last) {
             std::vector<int32_t> map((size_t)L.h, -1);
-            for (size_t i = 0; i < c->local_rows.size(); i++) map[(size_t)(cfg->crop_y + c->local_rows[i])] = (int32_t)i;
+            for (size_t i = 0; i < c->local_rows.size(); i++) map[(size_t)(cfg->crop_y + c->local_rows[i])] = opt.frame_rowmap ? (int32_t)c->local_rows[i] : (int32_t)i;
             CHK(hipMalloc(&L.d_rowmap, (size_t)L.h * sizeof(int32_t)));
             CHK(hipMemcpy(L.d_rowmap, map.data(), (size_t)L.h * sizeof(int32_t), hipMemcpyHostToDevice));
         }
     }
-    c->out_bytes = c->local_rows.size() * (size_t)cfg->frame_w * sizeof(float4);
+    c->out_bytes = (opt.frame_rowmap ? (size_t)cfg->frame_h : c->local_rows.size()) * (size_t)cfg->frame_w * sizeof(float4);
     const size_t nlaunch = 3 * (size_t)nl + 2;                            // upper bound of launches per batch
     for (Slot& S : c->slots) {
         CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
@@ -452,7 +461,7 @@ int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
                 }
                 if (cap) CHK(hipMalloc(&R.spec_queue, cap * sizeof(uint32_t)));
             }
-            if (c->out_bytes) {
+            if (c->out_bytes && !opt.external_out) {
                 CHK(hipMalloc(&R.own_out, c->out_bytes));
                 CHK(hipMemset(R.own_out, 0xFF, c->out_bytes));
             }
@@ -477,7 +486,7 @@ int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
     return BHRAY_OK;
 }
 
-int bhray_set_texture(bhray_ctx* c, int slot, const uint8_t* rgba8, uint32_t w, uint32_t h) {
+int dev_set_texture(bhray_dev* c, int slot, const uint8_t* rgba8, uint32_t w, uint32_t h) {
     if (!c) return BHRAY_E_INVALID;
     if (slot < 0 || slot > 2 || !rgba8 || w < 1 || h < 1 || w > 32768 || h > 32768) return fail(c, BHRAY_E_INVALID, "bad texture arguments");
     HIPCHK(c, hipSetDevice(c->device));
@@ -493,7 +502,7 @@ int bhray_set_texture(bhray_ctx* c, int slot, const uint8_t* rgba8, uint32_t w, 
     return BHRAY_OK;
 }
 
-int bhray_upload_model(bhray_ctx* c, uint32_t mi, const bhray_model_desc* d) {
+int dev_upload_model(bhray_dev* c, uint32_t mi, const bhray_model_desc* d) {
     if (!c) return BHRAY_E_INVALID;
     if (mi >= BHRAY_MAX_MODELS || !d) return fail(c, BHRAY_E_INVALID, "bad model arguments");
     if (d->point_count < 0 || d->normal_count < 0 || d->triangle_count < 0 || d->node_count < 0 ||
@@ -589,7 +598,7 @@ int bhray_upload_model(bhray_ctx* c, uint32_t mi, const bhray_model_desc* d) {
     return BHRAY_OK;
 }
 
-int bhray_upload_model_uniform(bhray_ctx* c, uint32_t mi, const void* bytes, size_t size) {
+int dev_upload_model_uniform(bhray_dev* c, uint32_t mi, const void* bytes, size_t size) {
     if (!c) return BHRAY_E_INVALID;
     if (!bytes || size != BHRAY_MODEL_UNIFORM_BYTES) return fail(c, BHRAY_E_INVALID, "ModelUniform must be %u bytes", BHRAY_MODEL_UNIFORM_BYTES);
     const uint8_t* b = (const uint8_t*)bytes;
@@ -625,10 +634,10 @@ int bhray_upload_model_uniform(bhray_ctx* c, uint32_t mi, const void* bytes, siz
         }
     }
     d.node_count = d.triangle_count > 0 ? node_max + 1 : 0;
-    return bhray_upload_model(c, mi, &d);
+    return dev_upload_model(c, mi, &d);
 }
 
-int bhray_set_model_transform(bhray_ctx* c, uint32_t mi, const float position[3], int32_t visible) {
+int dev_set_model_transform(bhray_dev* c, uint32_t mi, const float position[3], int32_t visible) {
     if (!c) return BHRAY_E_INVALID;
     if (mi >= BHRAY_MAX_MODELS || !position) return fail(c, BHRAY_E_INVALID, "bad model arguments");
     memcpy(c->models[mi].pos, position, 12);
@@ -636,7 +645,7 @@ int bhray_set_model_transform(bhray_ctx* c, uint32_t mi, const float position[3]
     return BHRAY_OK;
 }
 
-int bhray_set_uniforms(bhray_ctx* c, const void* cam32, const void* bh132, const void* det32) {
+int dev_set_uniforms(bhray_dev* c, const void* cam32, const void* bh132, const void* det32) {
     if (!c) return BHRAY_E_INVALID;
     if (!cam32 || !bh132 || !det32) return fail(c, BHRAY_E_INVALID, "null uniform block");
     static_assert(sizeof(bhray_camera_uniform) == 32 && sizeof(bhray_black_hole_uniform) == 132 && sizeof(bhray_details) == 32, "layout");
@@ -648,7 +657,7 @@ int bhray_set_uniforms(bhray_ctx* c, const void* cam32, const void* bh132, const
 // Enqueues every launch of the batch staged in the current slot: one argument block (FrameParams + per-launch FrameLaunch
 // arrays) copied to the device, then the same launch sequence a single frame needs, each launch covering all staged frames.
 namespace {
-int launch_batch(bhray_ctx* c) {
+int launch_batch(bhray_dev* c) {
     Slot& S = c->slots[(size_t)(c->batch_counter % c->slots.size())];
     const uint32_t nb = S.pending;
     if (nb == 0) return BHRAY_OK;
@@ -778,19 +787,32 @@ int launch_batch(bhray_ctx* c) {
     S.used = true;
     S.batch_id = c->batch_counter;
     S.pending = 0;
+    c->launched_slot = (int)(c->batch_counter % c->slots.size());
+    c->launched_frames = nb;
     c->batch_counter++;
     return BHRAY_OK;
 }
+
+// kernel variant the current uniforms and scene need (same rule as derive_frame: a mesh only when one is usable and visible)
+void frame_variant(const bhray_dev* c, int& method, bool& models) {
+    method = c->det.integration_method != 0 ? 1 : 0;
+    int mc = c->det.model_count; if (mc < 0) mc = 0; if (mc > BHRAY_MAX_MODELS) mc = BHRAY_MAX_MODELS;
+    models = false;
+    for (int i = 0; i < mc; i++) {
+        const ModelStore& m = c->models[i];
+        if (m.loaded && m.triangle_count > 0 && m.visible != 0) models = true;
+    }
+}
 }  // namespace
 
-int bhray_flush(bhray_ctx* c) {
+int dev_flush(bhray_dev* c) {
     if (!c) return BHRAY_E_INVALID;
     return launch_batch(c);
 }
 
-int bhray_render(bhray_ctx* c) {
+int dev_render(bhray_dev* c) {
     if (!c) return BHRAY_E_INVALID;
-    if (!c->have_uniforms) return fail(c, BHRAY_E_STATE, "bhray_set_uniforms has not been called");
+    if (!c->have_uniforms) return fail(c, BHRAY_E_STATE, "dev_set_uniforms has not been called");
     HIPCHK(c, hipSetDevice(c->device));
     FrameParams P;
     derive_frame(c, P);
@@ -805,11 +827,14 @@ int bhray_render(bhray_ctx* c) {
         if (S.used && hipEventQuery(S.uploaded) != hipSuccess) HIPCHK(c, hipEventSynchronize(S.uploaded));
         S.method = P.method; S.models = P.model_count > 0;
     }
-    if (c->wait_pending) { HIPCHK(c, hipStreamWaitEvent(S.stream, c->wait_ev, 0)); c->wait_pending = false; }
+    for (hipEvent_t ev : c->waits) HIPCHK(c, hipStreamWaitEvent(S.stream, ev, 0));
+    c->waits.clear();
     const uint32_t k = S.pending;
     FrameRes& R = S.fr[k];
     ((FrameParams*)S.h_args)[k] = P;
     R.out = c->bound_out ? c->bound_out : R.own_out;
+    c->bound_out = nullptr;                                   // a binding applies to one frame
+    if (!R.out && c->out_bytes) return fail(c, BHRAY_E_STATE, "internal: no output bound for this frame");
     R.frame_id = c->frame_counter;
     S.pending = k + 1;
     c->last_slot = si; c->last_sub = (int)k;
@@ -819,7 +844,7 @@ int bhray_render(bhray_ctx* c) {
     return BHRAY_OK;
 }
 
-int bhray_sync(bhray_ctx* c) {
+int dev_sync(bhray_dev* c) {
     if (!c) return BHRAY_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     { int rc = launch_batch(c); if (rc) return rc; }
@@ -835,32 +860,32 @@ int bhray_sync(bhray_ctx* c) {
     return BHRAY_OK;
 }
 
-uint32_t bhray_local_rows(const bhray_ctx* c) { return c ? (uint32_t)c->local_rows.size() : 0; }
+uint32_t dev_local_rows(const bhray_dev* c) { return c ? (uint32_t)c->local_rows.size() : 0; }
 
-int bhray_local_row_index(const bhray_ctx* c, uint32_t i, uint32_t* frame_row) {
+int dev_local_row_index(const bhray_dev* c, uint32_t i, uint32_t* frame_row) {
     if (!c || !frame_row || i >= c->local_rows.size()) return BHRAY_E_INVALID;
     *frame_row = c->local_rows[i];
     return BHRAY_OK;
 }
 
-int bhray_read_hdr(bhray_ctx* c, float* dst, size_t pitch) {
+int dev_read_hdr(bhray_dev* c, float* dst, size_t pitch) {
     if (!c) return BHRAY_E_INVALID;
     const size_t rowb = (size_t)c->cfg.frame_w * sizeof(float4);
-    if (c->local_rows.empty()) return bhray_sync(c);              // this partition owns no rows: nothing to copy
+    if (c->local_rows.empty()) return dev_sync(c);              // this partition owns no rows: nothing to copy
     if (!dst || pitch < rowb) return fail(c, BHRAY_E_INVALID, "bad destination / pitch");
-    int rc = bhray_sync(c);
+    int rc = dev_sync(c);
     if (rc) return rc;
     HIPCHK(c, hipMemcpy2D(dst, pitch, c->slots[(size_t)c->last_slot].fr[(size_t)c->last_sub].out, rowb, rowb, c->local_rows.size(), hipMemcpyDeviceToHost));
     return BHRAY_OK;
 }
 
-int bhray_read_level(bhray_ctx* c, uint32_t level, float* dst, size_t pitch) {
+int dev_read_level(bhray_dev* c, uint32_t level, float* dst, size_t pitch) {
     if (!c) return BHRAY_E_INVALID;
     if (level >= c->cfg.levels) return fail(c, BHRAY_E_INVALID, "level out of range");
     const Level& L = c->levels[level];
     const size_t rowb = (size_t)L.w * sizeof(float4);
     if (!dst || pitch < rowb) return fail(c, BHRAY_E_INVALID, "bad destination / pitch");
-    int rc = bhray_sync(c);
+    int rc = dev_sync(c);
     if (rc) return rc;
     if (level + 1 < c->cfg.levels) {
         HIPCHK(c, hipMemcpy2D(dst, pitch, c->slots[(size_t)c->last_slot].fr[(size_t)c->last_sub].level_out[level], rowb, rowb, (size_t)L.h, hipMemcpyDeviceToHost));
@@ -878,13 +903,13 @@ int bhray_read_level(bhray_ctx* c, uint32_t level, float* dst, size_t pitch) {
     return BHRAY_OK;
 }
 
-int bhray_hdr_device_ptr(bhray_ctx* c, void** p, size_t* bytes) {
+int dev_hdr_device_ptr(bhray_dev* c, void** p, size_t* bytes) {
     if (!c || !p) return BHRAY_E_INVALID;
     *p = c->slots[(size_t)c->last_slot].fr[(size_t)c->last_sub].out; if (bytes) *bytes = c->out_bytes;
     return BHRAY_OK;
 }
 
-int bhray_bind_output(bhray_ctx* c, void* p, size_t bytes) {
+int dev_bind_output(bhray_dev* c, void* p, size_t bytes) {
     if (!c) return BHRAY_E_INVALID;
     if (!p) { c->bound_out = nullptr; return BHRAY_OK; }
     if (bytes < c->out_bytes) return fail(c, BHRAY_E_INVALID, "output binding needs %zu bytes", c->out_bytes);
@@ -893,7 +918,7 @@ int bhray_bind_output(bhray_ctx* c, void* p, size_t bytes) {
     return BHRAY_OK;
 }
 
-int bhray_resolve_sky(bhray_ctx* c) {
+int dev_resolve_sky(bhray_dev* c) {
     if (!c) return BHRAY_E_INVALID;
     if (!c->rendered) return fail(c, BHRAY_E_STATE, "nothing rendered yet");
     HIPCHK(c, hipSetDevice(c->device));
@@ -913,42 +938,74 @@ int bhray_resolve_sky(bhray_ctx* c) {
     return BHRAY_OK;
 }
 
-int bhray_read_sky(bhray_ctx* c, uint16_t* dst, size_t pitch) {
+int dev_read_sky(bhray_dev* c, uint16_t* dst, size_t pitch) {
     if (!c) return BHRAY_E_INVALID;
     const size_t rowb = (size_t)c->cfg.frame_w * sizeof(uint2);
-    if (c->local_rows.empty()) return bhray_sync(c);
+    if (c->local_rows.empty()) return dev_sync(c);
     if (!dst || pitch < rowb) return fail(c, BHRAY_E_INVALID, "bad destination / pitch");
     FrameRes& S = c->slots[(size_t)c->last_slot].fr[(size_t)c->last_sub];
-    if (!S.sky_out) return fail(c, BHRAY_E_STATE, "bhray_resolve_sky has not been called for this frame");
-    int rc = bhray_sync(c);
+    if (!S.sky_out) return fail(c, BHRAY_E_STATE, "dev_resolve_sky has not been called for this frame");
+    int rc = dev_sync(c);
     if (rc) return rc;
     if (c->local_rows.empty()) return BHRAY_OK;
     HIPCHK(c, hipMemcpy2D(dst, pitch, S.sky_out, rowb, rowb, c->local_rows.size(), hipMemcpyDeviceToHost));
     return BHRAY_OK;
 }
 
-int bhray_sky_device_ptr(bhray_ctx* c, void** p, size_t* bytes) {
+int dev_sky_device_ptr(bhray_dev* c, void** p, size_t* bytes) {
     if (!c || !p) return BHRAY_E_INVALID;
     *p = c->slots[(size_t)c->last_slot].fr[(size_t)c->last_sub].sky_out;
     if (bytes) *bytes = c->local_rows.size() * (size_t)c->cfg.frame_w * sizeof(uint2);
     return BHRAY_OK;
 }
 
-int bhray_wait_stream(bhray_ctx* c, void* s) {
-    if (!c) return BHRAY_E_INVALID;
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipEventRecord(c->wait_ev, (hipStream_t)s));
-    c->wait_pending = true;
+int dev_wait_event(bhray_dev* c, hipEvent_t ev) {
+    if (!c || !ev) return BHRAY_E_INVALID;
+    c->waits.push_back(ev);
     return BHRAY_OK;
 }
 
-int bhray_next_stream(bhray_ctx* c, void** s) {
+int dev_device(const bhray_dev* c) { return c ? c->device : -1; }
+
+int dev_next_position(bhray_dev* c, int* slot, uint32_t* sub) {
+    if (!c || !slot || !sub) return BHRAY_E_INVALID;
+    Slot& S0 = c->slots[(size_t)(c->batch_counter % c->slots.size())];
+    if (S0.pending > 0) {
+        int method; bool models;
+        frame_variant(c, method, models);
+        if (S0.method != method || S0.models != models) { int rc = launch_batch(c); if (rc) return rc; }
+    }
+    *slot = (int)(c->batch_counter % c->slots.size());
+    *sub = c->slots[(size_t)*slot].pending;
+    return BHRAY_OK;
+}
+
+bool dev_take_launched(bhray_dev* c, int* slot, uint32_t* frames) {
+    if (!c || c->launched_slot < 0) return false;
+    if (slot) *slot = c->launched_slot;
+    if (frames) *frames = c->launched_frames;
+    c->launched_slot = -1; c->launched_frames = 0;
+    return true;
+}
+
+hipStream_t dev_slot_stream(bhray_dev* c, int slot) { return c->slots[(size_t)slot].stream; }
+hipEvent_t dev_slot_done(bhray_dev* c, int slot) { return c->slots[(size_t)slot].done; }
+
+int dev_launch_sky(bhray_dev* c, const void* src, void* dst, size_t npix, hipStream_t stream) {
+    if (!c) return BHRAY_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    TexDev sky; sky.rgba = c->tex[BHRAY_TEX_SKY]; sky.w = c->tex_w[BHRAY_TEX_SKY]; sky.h = c->tex_h[BHRAY_TEX_SKY];
+    HIPCHK(c, launch_sky(sky, (const float4*)src, (uint2*)dst, npix, stream));
+    return BHRAY_OK;
+}
+
+int dev_next_stream(bhray_dev* c, void** s) {
     if (!c || !s) return BHRAY_E_INVALID;
     *s = (void*)c->slots[(size_t)(c->batch_counter % c->slots.size())].stream;
     return BHRAY_OK;
 }
 
-int bhray_signal_stream(bhray_ctx* c, void* s) {
+int dev_signal_stream(bhray_dev* c, void* s) {
     if (!c) return BHRAY_E_INVALID;
     if (!c->rendered) return BHRAY_OK;
     HIPCHK(c, hipSetDevice(c->device));
@@ -957,7 +1014,7 @@ int bhray_signal_stream(bhray_ctx* c, void* s) {
     return BHRAY_OK;
 }
 
-int bhray_selftest(bhray_ctx* c, uint64_t mismatches[3]) {
+int dev_selftest(bhray_dev* c, uint64_t mismatches[3]) {
     if (!c || !mismatches) return BHRAY_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     unsigned long long* d = nullptr;
@@ -972,23 +1029,23 @@ int bhray_selftest(bhray_ctx* c, uint64_t mismatches[3]) {
     return BHRAY_OK;
 }
 
-int bhray_get_level_counters(bhray_ctx* c, uint32_t level, bhray_counters* out) {
+int dev_get_level_counters(bhray_dev* c, uint32_t level, bhray_counters* out) {
     if (!c || !out) return BHRAY_E_INVALID;
     if (!(c->cfg.flags & BHRAY_F_COUNTERS)) return fail(c, BHRAY_E_STATE, "ctx created without BHRAY_F_COUNTERS");
     if (level >= c->cfg.levels) return fail(c, BHRAY_E_INVALID, "level out of range");
-    int rc = bhray_sync(c);
+    int rc = dev_sync(c);
     if (rc) return rc;
     static_assert(sizeof(bhray_counters) == sizeof(Counters64), "counter layout");
     HIPCHK(c, hipMemcpy(out, c->slots[(size_t)c->last_slot].fr[(size_t)c->last_sub].d_counters + level, sizeof(Counters64), hipMemcpyDeviceToHost));
     return BHRAY_OK;
 }
 
-int bhray_get_counters(bhray_ctx* c, bhray_counters* out) {
+int dev_get_counters(bhray_dev* c, bhray_counters* out) {
     if (!c || !out) return BHRAY_E_INVALID;
     memset(out, 0, sizeof *out);
     for (uint32_t l = 0; l < c->cfg.levels; l++) {
         bhray_counters t;
-        int rc = bhray_get_level_counters(c, l, &t);
+        int rc = dev_get_level_counters(c, l, &t);
         if (rc) return rc;
         const uint64_t* a = (const uint64_t*)&t; uint64_t* b = (uint64_t*)out;
         for (size_t k = 0; k < sizeof(bhray_counters) / 8; k++) b[k] += a[k];
@@ -996,10 +1053,10 @@ int bhray_get_counters(bhray_ctx* c, bhray_counters* out) {
     return BHRAY_OK;
 }
 
-int bhray_get_timing(bhray_ctx* c, bhray_timing* out) {
+int dev_get_timing(bhray_dev* c, bhray_timing* out) {
     if (!c || !out) return BHRAY_E_INVALID;
     if (!(c->cfg.flags & BHRAY_F_TIMING)) return fail(c, BHRAY_E_STATE, "ctx created without BHRAY_F_TIMING");
-    int rc = bhray_sync(c);
+    int rc = dev_sync(c);
     if (rc) return rc;
     memset(out, 0, sizeof *out);
     const uint32_t nl = c->cfg.levels;
@@ -1030,5 +1087,3 @@ int bhray_get_timing(bhray_ctx* c, bhray_timing* out) {
     c->timing_begin = c->batch_counter;
     return BHRAY_OK;
 }
-
-}  // extern "C"

@@ -73,11 +73,25 @@ public:
         cfg_.device = device; cfg_.frames_in_flight = frames_in_flight; cfg_.frames_per_batch = frames_per_batch;
         check(bhray_create(&cfg_, &ctx_));
     }
+    // Row-tiled over several GPUs of the node, still ONE pipeline object driven from one thread (mod.rs:415-420): partition i
+    // of the frame is rendered on devices[i]; pass() also enqueues the RCCL gather to devices[0] and the de-interleave, and
+    // output() is the whole frame.
+    RayPipeline(std::pair<uint32_t, uint32_t> base, uint32_t multiplier, uint32_t levels, const std::vector<int>& devices,
+                uint32_t frames_in_flight = 1, uint32_t frames_per_batch = 1) {
+        std::memset(&cfg_, 0, sizeof cfg_);
+        check(bhray_ladder_from_base(base.first, base.second, multiplier, levels, &cfg_));
+        if (devices.empty() || devices.size() > BHRAY_MAX_DEVICES) throw std::runtime_error("bhray: bad device list");
+        cfg_.device_count = (uint32_t)devices.size();
+        for (size_t i = 0; i < devices.size(); i++) cfg_.devices[i] = devices[i];
+        cfg_.frames_in_flight = frames_in_flight; cfg_.frames_per_batch = frames_per_batch;
+        check(bhray_create(&cfg_, &ctx_));
+    }
     RayPipeline(const RayPipeline&) = delete;
     ~RayPipeline() { bhray_destroy(ctx_); }
     std::pair<uint32_t, uint32_t> resolution() const { return {cfg_.frame_w, cfg_.frame_h}; }
     void set_texture(int slot, const uint8_t* rgba8, uint32_t w, uint32_t h) { check(bhray_set_texture(ctx_, slot, rgba8, w, h), ctx_); }
     void upload_model(const Model& m) { bhray_model_desc d = m.desc(); check(bhray_upload_model(ctx_, 0, &d), ctx_); }
+    void set_materials(const void* material_uniforms_128) { check(bhray_set_materials(ctx_, material_uniforms_128, 128), ctx_); }   // mod.rs:389 (ignored by the shader)
     void set_uniforms(const bhray_camera_uniform& c, const bhray_black_hole_uniform& b, const bhray_details& d) { check(bhray_set_uniforms(ctx_, &c, &b, &d), ctx_); }
     void pass() { check(bhray_render(ctx_), ctx_); }                                            // ray_pipeline.rs:301-309
     void flush() { check(bhray_flush(ctx_), ctx_); }
@@ -101,11 +115,14 @@ public:
     RayDetails ray_details;
     explicit Renderer(int device = 0) : ray_pipeline_({72, 41}, 3, 4, device) {}               // mod.rs:177-179
     Renderer(std::pair<uint32_t, uint32_t> base, uint32_t multiplier, uint32_t levels, int device = 0) : ray_pipeline_(base, multiplier, levels, device) {}
+    Renderer(std::pair<uint32_t, uint32_t> base, uint32_t multiplier, uint32_t levels, const std::vector<int>& devices) : ray_pipeline_(base, multiplier, levels, devices) {}
     RayPipeline& ray_pipeline() { return ray_pipeline_; }
     void set_model(const Model& m) { ray_pipeline_.upload_model(m); ray_details.model_count = 1; }   // mod.rs:384
     void render(float dt) {                                                                     // mod.rs:378-420
         ray_details.time += dt;                                                                 // mod.rs:382
-        ray_pipeline_.set_uniforms(camera.uniform(), black_hole.uniform(), ray_details);
+        ray_pipeline_.set_uniforms(camera.uniform(), black_hole.uniform(), ray_details);        // mod.rs:386-388
+        const float materials[32] = {0};
+        ray_pipeline_.set_materials(materials);                                                 // mod.rs:389
         ray_pipeline_.pass();
     }
 private:

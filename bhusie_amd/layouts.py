@@ -4,6 +4,9 @@ from __future__ import annotations
 import ctypes as C
 
 MAX_LEVELS = 8
+MAX_DEVICES = 16
+COMM_ID_BYTES = 128
+GATHER_NONE, GATHER_RCCL = 0, 1
 MAX_MODEL_VERTICES = 524288
 MODEL_UNIFORM_BYTES = 48234572
 F_COUNTERS = 1
@@ -62,7 +65,9 @@ class BhrayConfig(C.Structure):
                 ("level_w", C.c_uint32 * MAX_LEVELS), ("level_h", C.c_uint32 * MAX_LEVELS),
                 ("crop_x", C.c_uint32), ("crop_y", C.c_uint32), ("frame_w", C.c_uint32), ("frame_h", C.c_uint32),
                 ("row_rank", C.c_uint32), ("row_world", C.c_uint32), ("stripe_rows", C.c_uint32), ("flags", C.c_uint32),
-                ("frames_in_flight", C.c_uint32), ("speculative_levels", C.c_uint32), ("frames_per_batch", C.c_uint32)]
+                ("frames_in_flight", C.c_uint32), ("speculative_levels", C.c_uint32), ("frames_per_batch", C.c_uint32),
+                ("device_count", C.c_uint32), ("devices", C.c_int32 * MAX_DEVICES), ("gather", C.c_uint32),
+                ("gather_root", C.c_uint32), ("comm_id", C.c_uint8 * COMM_ID_BYTES)]
 
     def sizes(self):
         return [(int(self.level_w[i]), int(self.level_h[i])) for i in range(self.levels)]
@@ -80,7 +85,17 @@ class BhrayTiming(C.Structure):
     _fields_ = [("frames", C.c_uint32), ("batches", C.c_uint32), ("total_ms", C.c_float), ("trace_ms", C.c_float), ("classify_ms", C.c_float),
                 ("trace_launches", C.c_uint32), ("classify_launches", C.c_uint32),
                 ("level_trace_ms", C.c_float * MAX_LEVELS), ("level_classify_ms", C.c_float * MAX_LEVELS),
-                ("sky_ms", C.c_float), ("sky_launches", C.c_uint32)]
+                ("sky_ms", C.c_float), ("sky_launches", C.c_uint32),
+                ("gather_ms", C.c_float), ("deinterleave_ms", C.c_float), ("gathers", C.c_uint32)]
+
+
+class BhrayGatherInfo(C.Structure):
+    _fields_ = [("partitions", C.c_uint32), ("local_partitions", C.c_uint32), ("root", C.c_uint32), ("root_is_local", C.c_uint32),
+                ("comm_ranks", C.c_uint32), ("rccl_version", C.c_uint32),
+                ("bytes_sent_per_frame", C.c_uint64), ("bytes_received_per_frame", C.c_uint64)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
 assert C.sizeof(BhrayDetails) == 32 and C.sizeof(BhrayCameraUniform) == 32 and C.sizeof(BhrayBlackHoleUniform) == 132
@@ -98,6 +113,11 @@ SYMBOLS = {
     "bhray_strerror": (C.c_char_p, [C.c_int]),
     "bhray_version": (u32, []),
     "bhray_device_count": (C.c_int, []),
+    "bhray_partition_rows": (u32, [u32, u32, u32, u32]),
+    "bhray_partition_row_index": (C.c_int, [u32, u32, u32, u32, u32, P(u32)]),
+    "bhray_comm_unique_id": (C.c_int, [vp]),
+    "bhray_get_gather_info": (C.c_int, [vp, P(BhrayGatherInfo)]),
+    "bhray_set_materials": (C.c_int, [vp, vp, sz]),
     "bhray_set_texture": (C.c_int, [vp, C.c_int, vp, u32, u32]),
     "bhray_upload_model_uniform": (C.c_int, [vp, u32, vp, sz]),
     "bhray_upload_model": (C.c_int, [vp, u32, P(BhrayModelDesc)]),

@@ -13,8 +13,8 @@ import ctypes as C
 import numpy as np
 
 from ._lib import lib
-from .layouts import (F_COUNTERS, F_TIMING, TEX_DISK, TEX_SKY, TEX_TEMP_LUT, BhrayConfig, BhrayCounters, BhrayTiming,
-                      check)
+from .layouts import (F_COUNTERS, F_TIMING, GATHER_RCCL, TEX_DISK, TEX_SKY, TEX_TEMP_LUT, BhrayConfig, BhrayCounters,
+                      BhrayGatherInfo, BhrayTiming, check)
 from .model import Model
 from .scene import BlackHole, Camera, RayDetails
 
@@ -31,12 +31,46 @@ def ladder_for_frame(frame=(1920, 1080), multiplier=3, levels=4) -> BhrayConfig:
     return cfg
 
 
+def comm_unique_id() -> bytes:
+    """A fresh RCCL communicator id (one process per GPU: call on ONE rank, hand the bytes to every rank's RayPass)."""
+    buf = (C.c_uint8 * 128)()
+    check(lib().bhray_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def partition_rows(frame_h: int, world: int, stripe_rows: int = 27):
+    """rows[part] = frame rows of every partition, from the library's own partition arithmetic (host only)."""
+    L = lib()
+    out, r = [], C.c_uint32()
+    for part in range(world):
+        n = int(L.bhray_partition_rows(frame_h, world, stripe_rows, part))
+        rows = np.zeros(n, dtype=np.int64)
+        for i in range(n):
+            check(L.bhray_partition_row_index(frame_h, world, stripe_rows, part, i, C.byref(r)))
+            rows[i] = r.value
+        out.append(rows)
+    return out
+
+
 class RayPass:
+    """devices=[d0, d1, ...]: ONE ctx drives several GPUs (partition i on devices[i]); bhray_render then also gathers the row
+    tiles to `gather_root`'s GPU over RCCL and de-interleaves them, and every output call refers to the whole frame.
+    comm_id + row_rank/row_world: one process per GPU, the same gather enqueued by every rank's library."""
+
     def __init__(self, cfg: BhrayConfig, device=0, counters=False, timing=False, row_rank=0, row_world=1, stripe_rows=27,
-                 frames_in_flight=0, speculative_levels=0, frames_per_batch=0):
+                 frames_in_flight=0, speculative_levels=0, frames_per_batch=0, devices=None, gather_root=0, comm_id=None):
         cfg = BhrayConfig.from_buffer_copy(bytes(cfg))
         cfg.struct_size = C.sizeof(BhrayConfig)
         cfg.device = device
+        if devices is not None:
+            cfg.device_count = len(devices)                      # more than BHRAY_MAX_DEVICES: refused by bhray_create
+            for i, d in enumerate(list(devices)[:len(cfg.devices)]):
+                cfg.devices[i] = int(d)
+        cfg.gather_root = gather_root
+        if comm_id is not None:
+            assert len(comm_id) == 128
+            cfg.gather = GATHER_RCCL
+            C.memmove(cfg.comm_id, bytes(comm_id), 128)
         cfg.flags = (F_COUNTERS if counters else 0) | (F_TIMING if timing else 0)
         cfg.row_rank, cfg.row_world, cfg.stripe_rows = row_rank, row_world, stripe_rows
         cfg.frames_in_flight = frames_in_flight
@@ -73,6 +107,15 @@ class RayPass:
 
     def upload_model_uniform(self, blob: bytes, index=0):
         check(lib().bhray_upload_model_uniform(self._h, index, blob, len(blob)), self._h)
+
+    def set_materials(self, blob: bytes = bytes(128)):
+        """mod.rs:389 — accepted and ignored (the shader never reads the materials)."""
+        check(lib().bhray_set_materials(self._h, blob, len(blob)), self._h)
+
+    def gather_info(self) -> dict:
+        g = BhrayGatherInfo()
+        check(lib().bhray_get_gather_info(self._h, C.byref(g)), self._h)
+        return g.as_dict()
 
     def set_model_transform(self, position, visible=1, index=0):
         check(lib().bhray_set_model_transform(self._h, index, (C.c_float * 3)(*[float(x) for x in position]), int(visible)), self._h)

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define BHRAY_VERSION_MAJOR 0
-#define BHRAY_VERSION_MINOR 1
+#define BHRAY_VERSION_MINOR 2
 
 /* ------------------------------------------------------------------------------------------
  * Error codes
@@ -42,7 +42,8 @@ enum {
     BHRAY_E_STATE       = -5,  /* call order violated (e.g. render before set_uniforms)      */
     BHRAY_E_BVH_DEPTH   = -6,  /* BVH deeper than BHRAY_BVH_STACK                            */
     BHRAY_E_IO          = -7,  /* file could not be read / parsed (OBJ loader)               */
-    BHRAY_E_CAPACITY    = -8   /* model exceeds the reference's fixed capacities             */
+    BHRAY_E_CAPACITY    = -8,  /* model exceeds the reference's fixed capacities             */
+    BHRAY_E_COMM        = -9   /* RCCL could not be loaded / a collective call failed        */
 };
 
 /* ------------------------------------------------------------------------------------------
@@ -99,7 +100,7 @@ typedef struct bhray_triangle {
 } bhray_triangle;                       /* 24 B */
 
 /* ModelUniform — src/renderer/triangle.rs:268-285; the storage buffer bound at ray.wgsl:9.
- * Fixed capacity arrays; byte offsets below are asserted in bhray_layout.cpp.              */
+ * Fixed capacity arrays; every size and offset below is static_assert-ed in bhusie_amd/csrc/bhray_layout.cpp. */
 #define BHRAY_MAX_MODEL_VERTICES 524288  /* triangle.rs:7, ray.wgsl:1 */
 #define BHRAY_MAX_MODELS         1       /* triangle.rs:6, ray.wgsl:2 */
 #define BHRAY_MAX_MATERIALS      8       /* material.rs:3, ray.wgsl:3 */
@@ -141,6 +142,8 @@ typedef struct bhray_model_desc {
 #define BHRAY_MAX_SPEC_LEVELS 4
 #define BHRAY_MAX_FRAMES_PER_BATCH 16
 #define BHRAY_BVH_STACK  64            /* reference: 19 whole nodes, no overflow check (ray.wgsl:292) */
+#define BHRAY_MAX_DEVICES 16           /* GPUs one ctx can drive (one node: 8 MI355X)                 */
+#define BHRAY_COMM_ID_BYTES 128        /* an RCCL ncclUniqueId                                         */
 
 enum {                                  /* bhray_config.flags */
     BHRAY_F_COUNTERS   = 1u << 0,       /* kernels also accumulate bhray_counters (slower)   */
@@ -169,10 +172,29 @@ enum {                                  /* bhray_config.flags */
  *
  * Row partition (multi-GPU row tiling): frame row r belongs to partition
  * (r / stripe_rows) % row_world; this ctx renders only rows of partition row_rank and packs
- * them densely, in increasing r, into its output buffer.  row_world = 1 ⇒ the whole frame. */
+ * them densely, in increasing r, into its output buffer.  row_world = 1 ⇒ the whole frame.
+ *
+ * Multi-GPU.  The reference host is one process on one thread (app.rs:108-114, mod.rs:415-420), so the
+ * row tiling lives behind this ABI:
+ *   device_count = N >= 2 — ONE ctx drives the N GPUs devices[0..N): partition i is rendered on devices[i] (scene and
+ *     uniforms replicated, coarse ladder rows recomputed per partition, nothing exchanged during the levels), and every
+ *     bhray_render also enqueues the gather of the row tiles to the GPU of partition gather_root (RCCL: grouped
+ *     ncclSend/ncclRecv over xGMI, one message per partition per batch) and the de-interleave of the stripes into the
+ *     frame (a HIP kernel on the root GPU).  Output calls (bhray_read_hdr, bhray_hdr_device_ptr, bhray_bind_output,
+ *     bhray_resolve_sky) then refer to the WHOLE frame on the root GPU; bhray_local_rows = frame_h.  row_rank/row_world
+ *     are ignored (row_world is set to N).  A device may appear more than once (functional tests on a one-GPU box): its
+ *     partitions share one RCCL rank and their tiles travel as send/recv-to-self.
+ *   one process per GPU (a launcher such as torchrun/mpirun): every process creates its ctx with device_count <= 1,
+ *     row_rank = its rank, row_world = N, gather = BHRAY_GATHER_RCCL and the SAME comm_id (bhray_comm_unique_id on one
+ *     rank, distributed by the launcher's own means).  The gather is enqueued by bhray_render exactly as above; the frame
+ *     exists on rank gather_root only (the other ranks' output calls succeed and deliver nothing).
+ * RCCL is loaded (dlopen "librccl.so.1") when the first such ctx is created; a single-GPU host never loads it. */
+enum { BHRAY_GATHER_NONE = 0,           /* row_world > 1: this ctx delivers its packed rows, the caller moves them   */
+       BHRAY_GATHER_RCCL = 1 };         /* the library gathers (always on when device_count >= 2)                    */
+
 typedef struct bhray_config {
     uint32_t struct_size;               /* = sizeof(bhray_config)                            */
-    int32_t  device;                    /* HIP device ordinal                                */
+    int32_t  device;                    /* HIP device ordinal (device_count == 0)            */
     uint32_t levels;                    /* 1..BHRAY_MAX_LEVELS                               */
     uint32_t level_w[BHRAY_MAX_LEVELS];
     uint32_t level_h[BHRAY_MAX_LEVELS];
@@ -183,6 +205,11 @@ typedef struct bhray_config {
     uint32_t frames_in_flight;          /* 0 = default (4); 1 = strictly one frame at a time  */
     uint32_t speculative_levels;        /* 0 = off; S>=2: trace EVERY needed pixel of levels 0..S-1 in one launch   */
     uint32_t frames_per_batch;          /* 0/1 = every bhray_render launches; B>1: launches cover B staged frames  */
+    uint32_t device_count;              /* 0: one GPU, `device`; N: devices[0..N) (N >= 2: single-process multi-GPU) */
+    int32_t  devices[BHRAY_MAX_DEVICES];
+    uint32_t gather;                    /* BHRAY_GATHER_*: one process per GPU only (see above)                      */
+    uint32_t gather_root;               /* partition whose GPU receives the frame (default 0)                        */
+    uint8_t  comm_id[BHRAY_COMM_ID_BYTES]; /* one process per GPU: the communicator id shared by all ranks           */
 } bhray_config;
 
 /* Reference ladder rule `r ← r·m − (m−1)` (mod.rs:177-205): fills level_w/h[0..levels).    */
@@ -205,6 +232,26 @@ const char* bhray_strerror(int code);
 uint32_t    bhray_version(void);                      /* major<<16 | minor                   */
 int  bhray_device_count(void);                        /* usable gfx950 devices, ≥0           */
 
+/* Row partition used by the multi-GPU modes (and by bhray_config.row_*): frame row r belongs to partition
+ * (r / stripe_rows) % world.  Pure host arithmetic (no device): the de-interleave kernel uses the same functions.
+ * bhray_partition_rows = rows of `part`; bhray_partition_row_index = frame row of the part's packed row i.        */
+uint32_t bhray_partition_rows(uint32_t frame_h, uint32_t world, uint32_t stripe_rows, uint32_t part);
+int bhray_partition_row_index(uint32_t frame_h, uint32_t world, uint32_t stripe_rows, uint32_t part, uint32_t i, uint32_t* frame_row);
+/* One process per GPU: a fresh communicator id (ncclGetUniqueId); call on ONE rank, hand the bytes to all ranks.  */
+int bhray_comm_unique_id(uint8_t id[BHRAY_COMM_ID_BYTES]);
+/* What a ctx gathers with.                                                                                          */
+typedef struct bhray_gather_info {
+    uint32_t partitions;                /* row partitions of the frame (1 = no tiling)                               */
+    uint32_t local_partitions;          /* partitions rendered by this ctx                                           */
+    uint32_t root;                      /* partition that receives the frame                                         */
+    uint32_t root_is_local;             /* 1: the frame is delivered by this ctx                                     */
+    uint32_t comm_ranks;                /* ranks of the RCCL communicator (0: no gather)                             */
+    uint32_t rccl_version;              /* ncclGetVersion, e.g. 22707 (0: RCCL not loaded)                           */
+    uint64_t bytes_sent_per_frame;      /* by this ctx's non-root partitions                                         */
+    uint64_t bytes_received_per_frame;  /* by the root partition (0 when it is not local)                            */
+} bhray_gather_info;
+int bhray_get_gather_info(const bhray_ctx* ctx, bhray_gather_info* out);
+
 /* Static inputs — replaces the include_bytes! textures (ray_pipeline.rs:63-70) and
  * texture.rs:16-69 semantics: RGBA8 unorm, no sRGB decode, bilinear, clamp-to-edge, 1 mip.  */
 enum { BHRAY_TEX_TEMP_LUT = 0,   /* binding 7  color.png */
@@ -218,6 +265,11 @@ int bhray_upload_model_uniform(bhray_ctx* ctx, uint32_t model_index, const void*
 int bhray_upload_model(bhray_ctx* ctx, uint32_t model_index, const bhray_model_desc* desc);
 /* Per-frame model state without re-uploading 48 MB (the reference re-uploads, mod.rs:391).  */
 int bhray_set_model_transform(bhray_ctx* ctx, uint32_t model_index, const float position[3], int32_t visible);
+
+/* Materials — `queue.write_buffer(&self.material_buffer, ..)` (mod.rs:113,389; material.rs:7-38: MaterialUniform
+ * {color:[f32;4]} x 8 = 128 B, binding 3).  The shader never reads them (no use of `materials` after ray.wgsl:8), so the
+ * bytes are accepted, size-checked and ignored; the call exists so that the Rust call order maps one to one.      */
+int bhray_set_materials(bhray_ctx* ctx, const void* material_uniforms_128, size_t size);
 
 /* Per-frame uniforms — replaces queue.write_buffer ×3 (mod.rs:386-388).                      */
 int bhray_set_uniforms(bhray_ctx* ctx, const void* camera_uniform_32,
@@ -244,9 +296,9 @@ int bhray_local_row_index(const bhray_ctx* ctx, uint32_t i, uint32_t* frame_row)
 
 /* Zero-copy consumers (sky pass, RCCL gather).  An output buffer holds local_rows × frame_w × 4
  * f32.  bhray_hdr_device_ptr returns the buffer of the most recently enqueued frame.
- * bhray_bind_output makes the NEXT bhray_render write into caller-supplied device memory (e.g. a
- * slice of a gather buffer); it applies to that one frame's slot until re-bound, NULL restores the
- * ctx-owned buffer.                                                                           */
+ * bhray_bind_output makes the NEXT bhray_render — that one frame only — write into caller-supplied device
+ * memory (on the GPU that delivers the frame); later frames go to the ctx-owned buffers again unless bound
+ * again.  NULL cancels a pending binding.                                                     */
 int bhray_hdr_device_ptr(bhray_ctx* ctx, void** dev_ptr, size_t* bytes);
 int bhray_bind_output(bhray_ctx* ctx, void* dev_ptr, size_t bytes);
 
@@ -254,7 +306,10 @@ int bhray_bind_output(bhray_ctx* ctx, void* dev_ptr, size_t bytes);
  * are far too small to fill 256 CUs (level 0 is ~3 k rays), so a ctx keeps `frames_in_flight`
  * frame slots, each with its own HIP stream and level/queue buffers; consecutive bhray_render
  * calls go to consecutive slots and overlap on the device (the reference's swap chain runs with
- * desired_maximum_frame_latency = 2, mod.rs:101).  Ordering against the caller's own streams:
+ * desired_maximum_frame_latency = 2, mod.rs:101).  ROCm maps HIP streams onto GPU_MAX_HW_QUEUES (default 4) hardware
+ * queues and aliased streams serialise: a host that keeps more than 4 frames in flight exports
+ * GPU_MAX_HW_QUEUES >= frames_in_flight (+2 with a gather) before its first HIP call; the library never touches the
+ * process environment.  Ordering against the caller's own streams:
  *   bhray_wait_stream(ctx, s)    the NEXT bhray_render starts after everything enqueued on s so far
  *   bhray_signal_stream(ctx, s)  work enqueued on s from now on starts after the LAST bhray_render
  * `s` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the legacy stream.  */
@@ -313,6 +368,9 @@ typedef struct bhray_timing {
     float    level_classify_ms[BHRAY_MAX_LEVELS];
     float    sky_ms;                   /* Σ sky resolve kernels                              */
     uint32_t sky_launches;
+    float    gather_ms;                /* multi-GPU, root: Σ (receive of the row tiles: start → all tiles arrived)   */
+    float    deinterleave_ms;          /* multi-GPU, root: Σ de-interleave kernels                                   */
+    uint32_t gathers;                  /* batches gathered                                                            */
 } bhray_timing;
 int bhray_get_timing(bhray_ctx* ctx, bhray_timing* out);       /* needs BHRAY_F_TIMING       */
 

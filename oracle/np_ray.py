@@ -514,7 +514,70 @@ def f_scale(h2, dist):
     return ((f32(-1.5) * h2) * (f32(1.0) / d5)).astype(np.float32)
 
 
+# ---- the LITERAL reading of the integrator: ray.wgsl:401-480 operator by operator under N0-N2 (one binary32 operation per
+# WGSL operator, no fused multiply-add, no reassociation; pow(d,5) = ((d*d)*(d*d))*d and pow(l,2) = l*l).  It exists to PIN the
+# distance between the numerics contract (N3/N7/N9/N10: what the HIP kernel computes by default) and the shader text:
+# tests/golden/frames_literal.npz is generated from it and is never regenerated when the contract changes.
+LITERAL = False
+
+
+def set_literal(on: bool) -> None:
+    global LITERAL
+    LITERAL = bool(on)
+
+
+def f_literal(S, p, h2, dist):
+    """fn f, ray.wgsl:401-403: -1.5 * h2 * (rayPos - black_hole.position) / pow(dist, 5.0)"""
+    c = (f32(-1.5) * h2).astype(np.float32)
+    num = ((p - S.bh_pos).astype(np.float32) * c[:, None]).astype(np.float32)
+    d2 = dist * dist
+    d5 = (d2 * d2) * dist
+    return vdivs(num, d5).astype(np.float32)
+
+
+def next_ray_euler_literal(S, pos, dirn, step):
+    """ray.wgsl:467-480"""
+    lc = vlen(vcross(pos, dirn)); h2 = lc * lc
+    dist = vlen((pos - S.bh_pos).astype(np.float32))
+    nd = vnorm((dirn + f_literal(S, pos, h2, dist) * step[:, None]).astype(np.float32))
+    npos = (pos + nd * step[:, None]).astype(np.float32)
+    return npos, nd.astype(np.float32)
+
+
+def next_ray_rk_literal(S, pos, dirn, h):
+    """ray.wgsl:405-465; the retry loop (425-451) cannot change h and is run once (D1)"""
+    dist = vlen((pos - S.bh_pos).astype(np.float32))
+    lc = vlen(vcross(pos, dirn)); h2 = lc * lc
+    hh = h[:, None]
+
+    def wsum(terms):                                            # a*k_a + b*k_b + ... left to right
+        k, c = terms[0]
+        acc = k * c
+        for k, c in terms[1:]:
+            acc = acc + k * c
+        return acc.astype(np.float32)
+
+    k1 = f_literal(S, pos, h2, dist)
+    k2 = f_literal(S, pos + (k1 * A21) * hh, h2, dist)
+    k3 = f_literal(S, pos + wsum([(k1, A31), (k2, A32)]) * hh, h2, dist)
+    k4 = f_literal(S, pos + wsum([(k1, A41), (k2, A42), (k2, A43)]) * hh, h2, dist)                      # a_43*k_2 (sic)
+    k5 = f_literal(S, pos + wsum([(k1, A51), (k2, A52), (k3, A53), (k4, A54)]) * hh, h2, dist)
+    k6 = f_literal(S, pos + wsum([(k1, A61), (k2, A62), (k3, A63), (k4, A64), (k5, A65)]) * hh, h2, dist)
+    ks = (k1, k2, k3, k4, k5, k6)
+    e = wsum(list(zip(ks, DB))) * hh
+    ea = np.abs(e)
+    e_max = fmax(fmax(ea[:, 0], ea[:, 1]), ea[:, 2])
+    nd = vnorm((dirn + wsum(list(zip(ks, BA))) * hh).astype(np.float32))
+    npos = (pos + dirn * hh).astype(np.float32)                                                           # old direction
+    with np.errstate(invalid="ignore"):
+        grow = e_max > f32(0.00002)
+    nh = np.where(grow, h * (f32(0.9) * bh_pow_m001(np.where(grow, e_max, f32(1.0)))), h * f32(1.0001)).astype(np.float32)
+    return npos, nd.astype(np.float32), nh
+
+
 def next_ray_euler(S, pos, dirn, step):
+    if LITERAL:
+        return next_ray_euler_literal(S, pos, dirn, step)
     cr = fcross(pos, dirn); h2 = fdot(cr, cr)               # N3: pow(length(v), 2.0) = dot(v, v)
     q0 = (pos - S.bh_pos).astype(np.float32)                # N9: position relative to the hole
     dist = flen(q0)
@@ -533,6 +596,8 @@ def _lin(terms):
 
 
 def next_ray_rk(S, pos, dirn, h):
+    if LITERAL:
+        return next_ray_rk_literal(S, pos, dirn, h)
     q0 = (pos - S.bh_pos).astype(np.float32)                # N9: position relative to the hole, once per step
     dist = flen(q0)
     cr = fcross(pos, dirn); h2 = fdot(cr, cr)               # N3: pow(length(v), 2.0) = dot(v, v)
@@ -605,7 +670,7 @@ def trace_rays(S: Scene, origin, direction, stats=None):
                 np_, nd_, nh_ = next_ray_rk(S, rkpos[kr], rkdir[kr], rkh[kr])
                 rkpos[kr] = np_; rkdir[kr] = nd_; rkh[kr] = nh_
                 cpos[kr] = np_; cdir[kr] = nd_; step[kr] = nh_
-            cd = flen(cpos[kr] - S.bh_pos)                     # N7: the integrator's distance
+            cd = vlen(cpos[kr] - S.bh_pos) if LITERAL else flen(cpos[kr] - S.bh_pos)     # N7: the integrator's distance
             closest[kr] = np.where(cd < closest[kr], cd, closest[kr])
             pdir[kr] = cdir[kr]
             h_, t_, col_, op_ = hit_black_hole(S, ppos[kr], pdir[kr], t_min, step[kr], ray_distance[kr])

@@ -1,9 +1,8 @@
-"""-m gpu: the N>1 path of bench.py end to end on ONE GPU — several ranks (processes) render their row tiles on device 0,
-the tiles travel through torch.distributed (gloo, staged through host memory, because RCCL refuses two ranks on one device)
-and every receiving rank compares the frames it assembled with a frame it renders whole (bench.py --verify).  What this
-covers that the CPU gloo test cannot: the real kernels on a row partition, frame batches, the per-slot buffers, the rotating
-root, partial batches at the end of a phase.  What it cannot cover: RCCL itself and stream ordering against it (exercised at
-world size 1 by `bench.py --force-distributed`)."""
+"""-m gpu: bench.py's N>1 paths end to end on ONE GPU.  The gather lives in libbhray (RCCL send/recv enqueued by bhray_render),
+so `python bench.py --gpus N` needs no launcher; on a one-GPU box the device list repeats device 0 and the tiles travel as RCCL
+send/recv-to-self.  --verify compares the gathered frame with a frame rendered whole, byte for byte.  Also covered: the same
+command under torchrun with --process-model single (rank 0 drives the GPUs, the other ranks only keep the launcher's barriers
+company).  Not coverable here: one process per GPU over RCCL (RCCL refuses two ranks on one device) and the xGMI hop."""
 import json
 import os
 import socket
@@ -14,6 +13,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ["--verify", "--steps", "13", "--warmup", "5", "--min-seconds", "0.05", "--no-cpu-baseline", "--width", "960", "--height", "540", "--frames-in-flight", "4"]
 
 
 def _port():
@@ -21,15 +21,25 @@ def _port():
     return p
 
 
-@pytest.mark.parametrize("world,extra", [(2, []), (4, ["--gather-root", "0", "--frames-per-batch", "3"])])
-def test_row_tiled_bench_assembles_the_whole_frame(world, extra):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--single-device",
-           "--verify", "--steps", "29", "--warmup", "5", "--no-cpu-baseline", "--width", "960", "--height", "540", "--frames-in-flight", "4"] + extra
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+def _line(r):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == world and d["scaling"] == "strong"
-    assert d["config"]["verified_frames"] >= 12, d["config"]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("n,extra", [(2, []), (4, ["--gather-root", "3", "--frames-per-batch", "3"]), (8, [])])
+def test_bench_gpus_n_without_a_launcher(n, extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--devices", ",".join(["0"] * n)] + COMMON + extra
+    d = _line(subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT))
+    assert d["n_gpus"] == n and d["scaling"] == "strong"
+    assert d["config"]["verified_frames"] == 1
+    g = d["gather"]
+    assert g["batches_gathered"] >= 1 and g["bytes_received_per_frame"] > 0 and "RCCL" in g["transport"]
+
+
+def test_bench_under_torchrun_single_process_model():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--process-model", "single", "--devices", "0,0"] + COMMON
+    d = _line(subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT))
+    assert d["n_gpus"] == 2 and d["config"]["verified_frames"] == 1

@@ -1,0 +1,72 @@
+"""CPU: the host-side pieces of the multi-GPU mode that need no device — the row-partition arithmetic the library uses for its
+staging tables and de-interleave kernel (bhray_partition_*), and the launcher plumbing of bench.py's one-process-per-GPU mode
+(world size 2 over gloo: barrier, reductions, broadcast of the 128-byte communicator id)."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+import bhusie_amd as B
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("frame_h,world,stripe", [(1080, 8, 27), (1081, 3, 27), (2160, 8, 27), (4320, 8, 27), (7, 4, 3), (100, 16, 1),
+                                                  (5, 8, 27), (110, 5, 27), (1080, 1, 27), (1, 2, 1)])
+def test_partition_arithmetic_is_a_bijection_onto_the_frame_rows(frame_h, world, stripe):
+    rows = B.partition_rows(frame_h, world, stripe)                  # closed forms inside libbhray
+    r = np.arange(frame_h)
+    owner = (r // stripe) % world                                    # the rule stated in include/bhray.h
+    for k in range(world):
+        assert np.array_equal(rows[k], r[owner == k]), (frame_h, world, stripe, k)
+    allrows = np.concatenate(rows) if rows else np.zeros(0)
+    assert sorted(allrows.tolist()) == list(range(frame_h))          # every frame row exactly once: the de-interleave is a permutation
+    L = B.lib()
+    import ctypes as C
+    out = C.c_uint32()
+    for k in range(world):                                           # one past the end, bad partition: errors, not wrap-around
+        assert L.bhray_partition_row_index(frame_h, world, stripe, k, len(rows[k]), C.byref(out)) != 0
+    assert L.bhray_partition_rows(frame_h, world, stripe, world) == 0
+    assert L.bhray_partition_row_index(frame_h, world, stripe, world, 0, C.byref(out)) != 0
+
+
+def test_partition_matches_the_per_device_engine_rule():
+    """bhray_config.row_* (one ctx = one partition) and the multi-device ctx use the same rule; the 27-row default stripe is one
+    level-0 lattice cell of the 4-level x3 ladder (3^3 final rows)."""
+    rows = B.partition_rows(1080, 8, 27)
+    assert [len(x) for x in rows] == [135] * 8
+    assert rows[3][:3].tolist() == [81, 82, 83] and rows[3][27] == 81 + 8 * 27
+
+
+def _port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def test_launcher_plumbing_world2_gloo(tmp_path):
+    """bench.py's Launcher under a real 2-process gloo group on CPU: what the one-process-per-GPU mode needs from the launcher."""
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {ROOT!r})
+        import bench
+        w, r, l = bench.launcher_env()
+        L = bench.Launcher(w, r)
+        L.barrier()
+        assert L.reduce([1.0 + r, 10.0], op="max") == [2.0, 10.0]
+        assert L.reduce([1 + r, 5], op="sum", dtype="int64") == [3, 10]
+        blob = bytes(range(128)) if r == 0 else None
+        got = L.broadcast_bytes(blob, 128)
+        assert got == bytes(range(128)), got
+        L.close()
+        open(os.path.join({str(tmp_path)!r}, "ok%d" % r), "w").write("ok")
+    """))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
