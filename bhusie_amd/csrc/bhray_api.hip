@@ -189,7 +189,6 @@ void derive_frame(const bhray_dev* c, FrameParams& P) {
     P.bh[0] = bpos.x; P.bh[1] = bpos.y; P.bh[2] = bpos.z;
     memcpy(P.bn, bh.normal, 12);
     P.bn_len = length(ld3(bh.normal));
-    P.bn_dot_bh = dot(ld3(bh.normal), bpos);
     P.inner = bh.accretion_disk_inner; P.outer = bh.accretion_disk_outer;
     P.rot_speed = bh.rotation_speed; P.R = bh.relativity_sphere_radius;
     P.show_tex = bh.show_disk_texture; P.show_shift = bh.show_red_shift;
@@ -685,7 +684,8 @@ int launch_batch(bhray_dev* c) {
     // 0.080 ms per frame; one slot: the latency build is 7-15 % faster per launch).
     const bool dense = c->dense_override >= 0 ? c->dense_override != 0
                                               : (c->slots.size() * (size_t)c->batch >= 4 * (size_t)c->cfg.row_world);
-    int bpc = trace_blocks_per_cu(S.method, S.models, count, dense);
+    const bool literal = (c->cfg.flags & BHRAY_F_LITERAL) != 0;
+    int bpc = trace_blocks_per_cu(S.method, S.models, count, dense, literal);
     if (c->slots.size() > 1 && bpc > 1) bpc = bpc > 4 ? 2 : (bpc / 2 > 1 ? bpc / 2 : 1);     // measured: 2 blocks per CU is best at 8-16 slots
     if (c->bpc_override > 0) bpc = c->bpc_override;
     const int grid = c->num_cus * bpc;
@@ -780,7 +780,7 @@ int launch_batch(bhray_dev* c) {
     for (const Launch& Ln : seq) {
         if (timing) for (int e : Ln.ev_before) HIPCHK(c, hipEventRecord(fev[e], st));
         if (Ln.kind == 0) HIPCHK(c, launch_classify(dP, Ln.d, (int)nb, Ln.blocks, Ln.count, st));
-        else HIPCHK(c, launch_trace(dP, Ln.d, (int)nb, S.method, S.models, Ln.count, dense, c->d_err, Ln.blocks, st));
+        else HIPCHK(c, launch_trace(dP, Ln.d, (int)nb, S.method, S.models, Ln.count, dense, literal, c->d_err, Ln.blocks, st));
         if (timing) for (int e : Ln.ev_after) HIPCHK(c, hipEventRecord(fev[e], st));
     }
     HIPCHK(c, hipEventRecord(S.done, st));

@@ -44,7 +44,6 @@ struct FrameParams {
     float bh[3];
     float bn[3];
     float bn_len;          // length(normal) (host), for the conservative disk cull
-    float bn_dot_bh;       // dot(normal, position) (host), plane offset for the same cull
     float inner, outer, rot_speed, R;
     int show_tex, show_shift;
     float M[9];            // rotation matrix columns c0,c1,c2
@@ -96,9 +95,9 @@ struct FrameLaunch {
 
 // launchers (bhray_kernels.hip); Pb / Fb are device arrays of nb entries
 hipError_t launch_classify(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int blocks, bool count, hipStream_t s);
-hipError_t launch_trace(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int method, bool models, bool count, bool dense, int* err_flag,
+hipError_t launch_trace(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int method, bool models, bool count, bool dense, bool literal, int* err_flag,
                         int grid_blocks, hipStream_t s);
-int trace_blocks_per_cu(int method, int has_models, int count, int dense);
+int trace_blocks_per_cu(int method, int has_models, int count, int dense, int literal);
 // copies n16 16-byte words from pinned host memory to device memory with a kernel (stays on the compute queue: a DMA copy
 // between the launches of a stream costs a cross-engine handshake each time)
 // and zeroes `nzero` 32-bit words at `zero` (the queue control words of the batch) in the same launch

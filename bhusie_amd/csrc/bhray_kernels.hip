@@ -106,7 +106,7 @@ __device__ __forceinline__ bool hit_torus2d(F3 pos, F3 dir, float inner, float o
 // per coarse-level launch).  The loop's operands are therefore loaded once per frame and pinned in SGPRs.
 struct HotParams {
     F3 bh, bn;
-    float bn_dot_bh, bn_len, inner, outer, R, ray_distance, feather, rot_speed, time;
+    float bn_len, inner, outer, R, ray_distance, feather, rot_speed, time;
     int max_iter, show_tex, show_shift;
     float M[9];
     TexDev disk, temp;
@@ -119,7 +119,7 @@ __device__ __forceinline__ HotParams load_hot(const FrameParams& P) {
     HotParams H;
     H.bh = f3(pin_sgpr(P.bh[0]), pin_sgpr(P.bh[1]), pin_sgpr(P.bh[2]));
     H.bn = f3(pin_sgpr(P.bn[0]), pin_sgpr(P.bn[1]), pin_sgpr(P.bn[2]));
-    H.bn_dot_bh = pin_sgpr(P.bn_dot_bh); H.bn_len = pin_sgpr(P.bn_len);
+    H.bn_len = pin_sgpr(P.bn_len);
     H.inner = pin_sgpr(P.inner); H.outer = pin_sgpr(P.outer); H.R = pin_sgpr(P.R);
     H.ray_distance = pin_sgpr(P.ray_distance); H.feather = pin_sgpr(P.feather);
     H.rot_speed = pin_sgpr(P.rot_speed); H.time = pin_sgpr(P.time);
@@ -187,7 +187,7 @@ __device__ __forceinline__ void shade_disk(const HotParams& P, F3 pos, F3 dir, f
 // (checked against the oracle, which always evaluates the literal tests).  The cull quantities are not part of the
 // shader, so they are the cheapest sufficient ones: |oc| is the distance the integrator already carries for this
 // position (`pos_dist`, within a few ulp of the literal |oc|, far inside the margins), and the plane distance is
-// n.b - n.pos with the constant n.b from the host.
+// n.(b - pos), from the hole-relative vector.
 // Geometry only.  Returns true when the disk is the nearest hit (its parameter in td_out); the shading of that hit
 // (shade_disk) is run by the caller - the trace kernel defers it to a wave-uniform phase of its own.  rs holds the horizon
 // result (hit, t, colour 0, opacity 1) or "no hit".
@@ -199,7 +199,9 @@ __device__ __forceinline__ bool hit_black_hole_geom(const HotParams& H, F3 pos, 
     if (pos_dist <= 1.0f + reach) hs = hit_sphere(pos, dir, 1.0f, bpos, t_min, t_max, ts);
     if (pos_dist <= H.outer + reach) {
         const F3 bn = H.bn;
-        const float numer = H.bn_dot_bh - fdot(pos, bn);
+        // signed plane distance from the hole-RELATIVE position: its rounding error (a few ulp of |pos - bh| <= outer + reach)
+        // does not grow with |bh|, unlike n.bh - n.pos for a hole far from the origin
+        const float numer = fdot(bpos - pos, bn);
         if (fabsf(numer) <= (1.01f * t_max) * H.bn_len + 1e-4f * H.bn_len) hd = hit_torus2d(pos, dir, H.inner, H.outer, bpos, bn, t_min, t_max, td);
     }
     rs.hit = hs; rs.t = hs ? ts : t_max; rs.color = f3(0.0f, 0.0f, 0.0f); rs.opacity = hs ? 1.0f : 0.0f;
@@ -401,6 +403,46 @@ __device__ __forceinline__ void next_ray_euler(F3 q0, F3& pos, F3& dir, float st
     pos = fmadd3(dir, step, pos);
 }
 
+// The LITERAL reading of the integrator (BHRAY_F_LITERAL): ray.wgsl:401-480 operator by operator under N0-N2 — one binary32
+// operation per WGSL operator in source order, no fused multiply-add, no reassociation, IEEE division and square root as the
+// compiler lowers them; pow(d, 5) = ((d*d)*(d*d))*d, pow(l, 2) = l*l, pow(e, -0.001) the portable form.  Bit-identical to
+// oracle_set_literal(1) and to tests/golden/frames_literal.npz: the variant exists so that "the contract (N3/N7/N9/N10) is a
+// permitted evaluation of the shader text" is a measured distance between two kernels, not prose.  Not tuned.
+__device__ __forceinline__ F3 f_literal(F3 p, F3 bpos, float h2, float dist) {          // fn f, ray.wgsl:401-403
+    const F3 num = (p - bpos) * (-1.5f * h2);
+    return div_s(num, pow5(dist));
+}
+__device__ __forceinline__ F3 wsum2(F3 a, float ca, F3 b, float cb) { return a * ca + b * cb; }
+__device__ constexpr float DB2 = KF(0.0 - 0.0), BA2 = KF(0.0);
+__device__ __noinline__ void next_ray_rk_literal(F3 bpos, F3& pos, F3& dir, float& h_io) {   // ray.wgsl:405-465 (D1: loop once)
+    const F3 p0 = pos, d0 = dir;
+    const float dist = length(p0 - bpos);
+    const float lc = length(cross(p0, d0));
+    const float h2 = lc * lc;
+    const float h = h_io;
+    const F3 k1 = f_literal(p0, bpos, h2, dist);
+    const F3 k2 = f_literal(p0 + (k1 * A21) * h, bpos, h2, dist);
+    const F3 k3 = f_literal(p0 + (k1 * A31 + k2 * A32) * h, bpos, h2, dist);
+    const F3 k4 = f_literal(p0 + ((k1 * A41 + k2 * A42) + k2 * A43) * h, bpos, h2, dist);                         // a_43*k_2 (sic)
+    const F3 k5 = f_literal(p0 + (((k1 * A51 + k2 * A52) + k3 * A53) + k4 * A54) * h, bpos, h2, dist);
+    const F3 k6 = f_literal(p0 + ((((k1 * A61 + k2 * A62) + k3 * A63) + k4 * A64) + k5 * A65) * h, bpos, h2, dist);
+    const F3 es = ((((k1 * DB1 + k2 * DB2) + k3 * DB3) + k4 * DB4) + k5 * DB5) + k6 * DB6;
+    const F3 e = es * h;
+    const float e_max = max_(max_(fabsf(e.x), fabsf(e.y)), fabsf(e.z));
+    const F3 ds = ((((k1 * BA1 + k2 * BA2) + k3 * BA3) + k4 * BA4) + k5 * BA5) + k6 * BA6;
+    dir = normalize(d0 + ds * h);
+    pos = p0 + d0 * h;                                                                                           // old direction
+    if (e_max > 0.00002f) h_io = h * (0.9f * bh_pow_m001(e_max));
+    else h_io = h * 1.0001f;
+}
+__device__ __noinline__ void next_ray_euler_literal(F3 bpos, F3& pos, F3& dir, float step) {   // ray.wgsl:467-480
+    const float lc = length(cross(pos, dir));
+    const float h2 = lc * lc;
+    const float dist = length(pos - bpos);
+    dir = normalize(dir + f_literal(pos, bpos, h2, dist) * step);
+    pos = pos + dir * step;
+}
+
 // ------------------------------------------------------------------------------------------
 // classify: ray.wgsl:167-243
 // ------------------------------------------------------------------------------------------
@@ -525,7 +567,7 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #define BHRAY_TRACE_WAVES_DENSE 6
 #endif
 
-template <int METHOD, bool MODELS, bool COUNT, bool DENSE>
+template <int METHOD, bool MODELS, bool COUNT, bool DENSE, bool LIT = false>
 __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHRAY_TRACE_WAVES_DENSE : BHRAY_TRACE_WAVES)) void trace_kernel(const FrameParams* __restrict__ Pb, const FrameLaunch* __restrict__ Fb, const int nb, int* __restrict__ err_flag) {
     const int lane = threadIdx.x & 63;
     int err = 0;
@@ -739,6 +781,16 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
                     if (COUNT) cnt[4]++;
                     ppos = cpos; pdir = cdir;
                     const float ppos_dist = cpos_dist;
+                    float cd;
+                    if (LIT) {
+                        if (METHOD == 0) {
+                            next_ray_euler_literal(bpos, cpos, cdir, step);
+                        } else {
+                            next_ray_rk_literal(bpos, rkpos, rkdir, rkh);
+                            cpos = rkpos; cdir = rkdir; step = rkh;
+                        }
+                        cd = distance(cpos, bpos);                        // ray.wgsl:533, operator by operator
+                    } else {
                     if (METHOD == 0) {
                         next_ray_euler(qrel, cpos, cdir, step, dist_c);
                     } else {
@@ -746,7 +798,8 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
                         cpos = rkpos; cdir = rkdir; step = rkh;
                     }
                     qrel = cpos - bpos;
-                    const float cd = sqrt_rn(fdot(qrel, qrel));   // N7: the integrator's distance (ray.wgsl:533) = fdistance(cpos, bpos)
+                    cd = sqrt_rn(fdot(qrel, qrel));               // N7: the integrator's distance (ray.wgsl:533) = fdistance(cpos, bpos)
+                    }
                     dist_c = cd; cpos_dist = cd;                       // Euler: cpos is the integrator position; RK: cpos == rkpos here
                     if (cd < closest) closest = cd;
                     pdir = cdir;
@@ -880,16 +933,22 @@ hipError_t launch_classify(const FrameParams* Pb, const FrameLaunch* Fb, int nb,
     return hipGetLastError();
 }
 
-template <int METHOD, bool MODELS, bool DENSE>
+template <int METHOD, bool MODELS, bool DENSE, bool LIT = false>
 static hipError_t launch_trace_t(const FrameParams* Pb, const FrameLaunch* Fb, int nb, bool count, int* err_flag, int grid_blocks, hipStream_t s) {
-    if (count) hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, true, DENSE>), dim3(grid_blocks), dim3(256), 0, s, Pb, Fb, nb, err_flag);
-    else hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, false, DENSE>), dim3(grid_blocks), dim3(256), 0, s, Pb, Fb, nb, err_flag);
+    if (count) hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, true, DENSE, LIT>), dim3(grid_blocks), dim3(256), 0, s, Pb, Fb, nb, err_flag);
+    else hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, false, DENSE, LIT>), dim3(grid_blocks), dim3(256), 0, s, Pb, Fb, nb, err_flag);
     return hipGetLastError();
 }
 
-hipError_t launch_trace(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int method, bool models, bool count, bool dense, int* err_flag,
+hipError_t launch_trace(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int method, bool models, bool count, bool dense, bool literal, int* err_flag,
                         int grid_blocks, hipStream_t s) {
     if (nb <= 0) return hipSuccess;
+    if (literal) {      // BHRAY_F_LITERAL: the operator-by-operator integrator; one register budget per mesh / no-mesh
+        if (models) return method == 0 ? launch_trace_t<0, true, false, true>(Pb, Fb, nb, count, err_flag, grid_blocks, s)
+                                       : launch_trace_t<1, true, false, true>(Pb, Fb, nb, count, err_flag, grid_blocks, s);
+        return method == 0 ? launch_trace_t<0, false, false, true>(Pb, Fb, nb, count, err_flag, grid_blocks, s)
+                           : launch_trace_t<1, false, false, true>(Pb, Fb, nb, count, err_flag, grid_blocks, s);
+    }
     if (models) {       // the mesh variant has one register budget
         return method == 0 ? launch_trace_t<0, true, false>(Pb, Fb, nb, count, err_flag, grid_blocks, s)
                            : launch_trace_t<1, true, false>(Pb, Fb, nb, count, err_flag, grid_blocks, s);
@@ -902,14 +961,18 @@ hipError_t launch_trace(const FrameParams* Pb, const FrameLaunch* Fb, int nb, in
                  : launch_trace_t<1, false, false>(Pb, Fb, nb, count, err_flag, grid_blocks, s);
 }
 
-int trace_blocks_per_cu(int method, int has_models, int count, int dense) {
+int trace_blocks_per_cu(int method, int has_models, int count, int dense, int literal) {
     int n = 0;
     const void* f;
 #define PICK(M, MD, C, D) (const void*)trace_kernel<M, MD, C, D>
-    if (has_models) f = method == 0 ? (count ? PICK(0, true, true, false) : PICK(0, true, false, false)) : (count ? PICK(1, true, true, false) : PICK(1, true, false, false));
+#define PICKL(M, MD, C) (const void*)trace_kernel<M, MD, C, false, true>
+    if (literal) f = has_models ? (method == 0 ? (count ? PICKL(0, true, true) : PICKL(0, true, false)) : (count ? PICKL(1, true, true) : PICKL(1, true, false)))
+                                : (method == 0 ? (count ? PICKL(0, false, true) : PICKL(0, false, false)) : (count ? PICKL(1, false, true) : PICKL(1, false, false)));
+    else if (has_models) f = method == 0 ? (count ? PICK(0, true, true, false) : PICK(0, true, false, false)) : (count ? PICK(1, true, true, false) : PICK(1, true, false, false));
     else if (dense) f = method == 0 ? (count ? PICK(0, false, true, true) : PICK(0, false, false, true)) : (count ? PICK(1, false, true, true) : PICK(1, false, false, true));
     else f = method == 0 ? (count ? PICK(0, false, true, false) : PICK(0, false, false, false)) : (count ? PICK(1, false, true, false) : PICK(1, false, false, false));
 #undef PICK
+#undef PICKL
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 256, 0) != hipSuccess || n < 1) n = 2;
     return n;
 }

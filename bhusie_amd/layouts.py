@@ -11,6 +11,7 @@ MAX_MODEL_VERTICES = 524288
 MODEL_UNIFORM_BYTES = 48234572
 F_COUNTERS = 1
 F_TIMING = 2
+F_LITERAL = 4
 TEX_TEMP_LUT, TEX_DISK, TEX_SKY = 0, 1, 2
 
 

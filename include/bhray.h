@@ -147,7 +147,11 @@ typedef struct bhray_model_desc {
 
 enum {                                  /* bhray_config.flags */
     BHRAY_F_COUNTERS   = 1u << 0,       /* kernels also accumulate bhray_counters (slower)   */
-    BHRAY_F_TIMING     = 1u << 1        /* record HIP events around every launch             */
+    BHRAY_F_TIMING     = 1u << 1,       /* record HIP events around every launch             */
+    BHRAY_F_LITERAL    = 1u << 2        /* the integrator (ray.wgsl:401-480, 533) operator by operator: one binary32 operation per
+                                           WGSL operator in source order, no fused multiply-add, no reassociation.  Slower; exists
+                                           to MEASURE how far the default evaluation (DESIGN.md §2, N3/N7/N9/N10 — permitted by
+                                           WGSL, cheaper on CDNA4) is from the shader text: tests/test_gpu_literal.py       */
 };
 
 /* The ladder is the reference's chain of RayPipelines (mod.rs:170-207): level 0 traces every

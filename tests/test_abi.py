@@ -104,3 +104,70 @@ def test_cpp_host_program_is_built_and_fails_loudly_without_a_gpu(tmp_path):
         pytest.skip("a GPU is present")
     r = subprocess.run([exe, str(tmp_path / "o.f32")], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+def _header_struct_fields(name):
+    """[(field, ctype, array_len or None)] of `typedef struct name { ... } name;` in include/bhray.h"""
+    text = open(os.path.join(ROOT, "include", "bhray.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), text, flags=re.S).group(1)
+    macros = dict(re.findall(r"#define (BHRAY_[A-Z_]+)\s+(\d+)", text))
+    out = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        m = re.match(r"([a-z0-9_]+)\s+(.*)$", decl)
+        ctype, rest = m.group(1), m.group(2)
+        for item in rest.split(","):
+            item = item.strip()
+            a = re.match(r"([a-zA-Z0-9_]+)\[([A-Z0-9_]+)\]$", item)
+            if a:
+                n = a.group(2)
+                out.append((a.group(1), ctype, int(macros.get(n, n))))
+            else:
+                out.append((item, ctype, None))
+    return out
+
+
+def test_integration_md_rust_binding_matches_the_header():
+    """INTEGRATION.md holds the Rust side a maintainer adds (it cannot be compiled here: no Rust toolchain).  Keep it in lock step:
+    bhray_config field for field (name, type, array length, order), and every extern fn it declares exists in the header with the
+    same number of parameters."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    rust = re.search(r"pub struct bhray_config \{(.*?)\n\}", md, flags=re.S).group(1)
+    rfields = []
+    for name, ty in re.findall(r"pub ([a-z0-9_]+): (\[[a-z0-9]+; \d+\]|[a-z0-9]+)", rust):
+        a = re.match(r"\[([a-z0-9]+); (\d+)\]", ty)
+        rfields.append((name, a.group(1), int(a.group(2))) if a else (name, ty, None))
+    cmap = {"uint32_t": "u32", "int32_t": "i32", "uint8_t": "u8", "float": "f32", "uint64_t": "u64"}
+    hfields = [(n, cmap[t], k) for n, t, k in _header_struct_fields("bhray_config")]
+    assert rfields == hfields, "INTEGRATION.md bhray_config differs from include/bhray.h"
+    def py_field(t):
+        n = getattr(t, "_length_", None)
+        base = t._type_ if n is not None else t
+        return {C.c_uint32: "u32", C.c_int32: "i32", C.c_uint8: "u8"}[base], n
+    assert hfields == [(n,) + py_field(t) for n, t in layouts.BhrayConfig._fields_], "bhusie_amd/layouts.py BhrayConfig differs from include/bhray.h"
+    hdr = open(os.path.join(ROOT, "include", "bhray.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    ext = re.search(r'extern "C" \{(.*?)\n\}', md, flags=re.S).group(1)
+    fns = re.findall(r"pub fn (bhray_[a-z0-9_]+)\((.*?)\)", ext)
+    assert len(fns) >= 10
+    for name, params in fns:
+        m = re.search(r"\b%s\s*\((.*?)\)\s*;" % name, hdr, flags=re.S)
+        assert m, f"{name} is declared in INTEGRATION.md but not in include/bhray.h"
+        nh = 0 if m.group(1).strip() in ("", "void") else m.group(1).count(",") + 1
+        nr = 0 if not params.strip() else params.count(",") + 1
+        assert nh == nr, f"{name}: {nr} parameters in the Rust declaration, {nh} in the header"
+
+
+def test_header_layout_asserts_are_compiled_into_the_library():
+    """include/bhray.h's offsets are static_assert-ed in bhusie_amd/csrc/bhray_layout.cpp, which the Makefile builds into libbhray.so."""
+    src = open(os.path.join(ROOT, "bhusie_amd", "csrc", "bhray_layout.cpp")).read()
+    mk = open(os.path.join(ROOT, "bhusie_amd", "csrc", "Makefile")).read()
+    assert "bhray_layout.cpp" in mk and "bhray_layout.o" in mk
+    for sym in ("BHRAY_MODEL_OFF_POINTS", "BHRAY_MODEL_OFF_NORMALS", "BHRAY_MODEL_OFF_TRIANGLES", "BHRAY_MODEL_OFF_NODES",
+                "BHRAY_MODEL_OFF_LOOKUP", "BHRAY_MODEL_UNIFORM_BYTES", "bhray_node", "bhray_triangle", "bhray_model_header",
+                "bhray_black_hole_uniform", "bhray_camera_uniform", "bhray_details"):
+        assert sym in src, sym
+    assert src.count("static_assert") + src.count("OFF(") + src.count("SZ(") >= 60

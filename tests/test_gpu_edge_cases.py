@@ -106,6 +106,23 @@ def test_degenerate_uniforms_propagate_nan_identically():
             check(gpu_frame(cfg, u, tex).read_hdr(), want[-1], f"{name} / method {method}")
 
 
+@pytest.mark.parametrize("offset", [(1000.0, -700.0, 2500.0), (-9000.0, 4000.0, 7000.0)])
+def test_hole_and_camera_far_from_the_origin(offset):
+    """Hole (and camera) 1e3..1e4 units from the origin: the conservative culls of the horizon / disk tests must stay
+    conservative when |bh.position| is large (their quantities come from hole-relative vectors), so classes, NaN positions
+    (negative density -> pow NaN, ray.wgsl:619-623) and direction bits still equal the oracle's, which evaluates every test."""
+    tex = T.textures()
+    cfg = B.ladder_from_base((40, 24), 3, 2)
+    off = np.array(offset, dtype=np.float32)
+    for method in (0, 1):
+        for rel in ((0.0, 0.0, -19.0), (0.0, 3.0, -45.0)):
+            cam = B.Camera(position=tuple(float(v) for v in (off + np.array(rel, dtype=np.float32))),
+                           forward=tuple(float(v) for v in (-np.array(rel) / np.linalg.norm(rel))))
+            u = T.uniforms(camera=cam, black_hole=B.BlackHole(position=tuple(float(v) for v in off)), integration_method=method)
+            want = O.render_ladder(T.oracle_scene(*u, tex), cfg.sizes())
+            check(gpu_frame(cfg, u, tex, counters=True).read_hdr(), want[-1], f"offset {offset} camera {rel} method {method}")
+
+
 def test_one_texel_textures_and_empty_model():
     tex = tuple(np.full((1, 1, 4), v, dtype=np.uint8) for v in (200, 128, 64))
     u = T.uniforms(integration_method=1, model_count=1)
