@@ -112,6 +112,7 @@ struct bhray_dev {
     int* d_err = nullptr;
     int num_cus = 256;
     int bpc_override = 0;                  // BHRAY_TRACE_BLOCKS_PER_CU (tuning experiments only)
+    int grid_override = 0;                 // BHRAY_TRACE_GRID: absolute number of persistent trace blocks (tuning experiments only)
     int dense_override = -1;               // BHRAY_TRACE_DENSE=0/1 (tuning experiments only)
     bool rendered = false;
     std::string err;
@@ -194,7 +195,7 @@ void derive_frame(const bhray_dev* c, FrameParams& P) {
     P.show_tex = bh.show_disk_texture; P.show_shift = bh.show_red_shift;
     for (int col = 0; col < 3; col++) for (int r = 0; r < 3; r++) P.M[3 * col + r] = bh.rotation_matrix[4 * col + r];
     P.feather = bh.feather_amount;
-    P.time = d.time; P.method = d.integration_method != 0 ? 1 : 0; P.step_size = d.step_size;
+    P.time = d.time; P.time_rot = d.time * bh.rotation_speed; P.method = d.integration_method != 0 ? 1 : 0; P.step_size = d.step_size;
     P.max_iter = d.max_iterations; P.thr = d.angle_division_threshold;
     P.acos_cstar = acos_threshold(P.thr);
     int mc = d.model_count; if (mc < 0) mc = 0; if (mc > BHRAY_MAX_MODELS) mc = BHRAY_MAX_MODELS;
@@ -377,6 +378,7 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
     CHK(hipGetDeviceProperties(&prop, c->device));
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = getenv("BHRAY_TRACE_BLOCKS_PER_CU")) c->bpc_override = atoi(e);
+    if (const char* e = getenv("BHRAY_TRACE_GRID")) c->grid_override = atoi(e);
     if (const char* e = getenv("BHRAY_TRACE_DENSE")) c->dense_override = atoi(e) != 0;
     const uint32_t nslots = cfg->frames_in_flight ? cfg->frames_in_flight : 4;
     c->cfg.frames_in_flight = nslots;
@@ -688,7 +690,7 @@ int launch_batch(bhray_dev* c) {
     int bpc = trace_blocks_per_cu(S.method, S.models, count, dense, literal);
     if (c->slots.size() > 1 && bpc > 1) bpc = bpc > 4 ? 2 : (bpc / 2 > 1 ? bpc / 2 : 1);     // measured: 2 blocks per CU is best at 8-16 slots
     if (c->bpc_override > 0) bpc = c->bpc_override;
-    const int grid = c->num_cus * bpc;
+    const int grid = c->grid_override > 0 ? c->grid_override : c->num_cus * bpc;
     auto level_params = [&](const FrameRes& R, uint32_t l, LevelParams& L) {
         const Level& Lv = c->levels[l];
         const bool last = (l == nl - 1);

@@ -50,6 +50,7 @@ struct FrameParams {
     float feather;
     // details (ray.wgsl:25-34)
     float time;
+    float time_rot;        // time * rotation_speed (ray.wgsl:633): the same single binary32 product, formed once on the host
     int method;
     float step_size;
     int max_iter;

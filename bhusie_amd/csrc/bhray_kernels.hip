@@ -106,7 +106,7 @@ __device__ __forceinline__ bool hit_torus2d(F3 pos, F3 dir, float inner, float o
 // per coarse-level launch).  The loop's operands are therefore loaded once per frame and pinned in SGPRs.
 struct HotParams {
     F3 bh, bn;
-    float bn_len, inner, outer, R, ray_distance, feather, rot_speed, time;
+    float bn_len, inner, outer, R, ray_distance, feather, time_rot, step_size;
     int max_iter, show_tex, show_shift;
     float M[9];
     TexDev disk, temp;
@@ -122,7 +122,7 @@ __device__ __forceinline__ HotParams load_hot(const FrameParams& P) {
     H.bn_len = pin_sgpr(P.bn_len);
     H.inner = pin_sgpr(P.inner); H.outer = pin_sgpr(P.outer); H.R = pin_sgpr(P.R);
     H.ray_distance = pin_sgpr(P.ray_distance); H.feather = pin_sgpr(P.feather);
-    H.rot_speed = pin_sgpr(P.rot_speed); H.time = pin_sgpr(P.time);
+    H.time_rot = pin_sgpr(P.time_rot); H.step_size = pin_sgpr(P.step_size);
     H.max_iter = pin_sgpr(P.max_iter); H.show_tex = pin_sgpr(P.show_tex); H.show_shift = pin_sgpr(P.show_shift);
 #pragma unroll
     for (int k = 0; k < 9; k++) H.M[k] = pin_sgpr(P.M[k]);
@@ -154,7 +154,7 @@ __device__ __forceinline__ void shade_disk(const HotParams& P, F3 pos, F3 dir, f
         F3 c0 = f3(P.M[0], P.M[1], P.M[2]), c1 = f3(P.M[3], P.M[4], P.M[5]), c2 = f3(P.M[6], P.M[7], P.M[8]);
         F3 rot = (c0 * rel.x + c1 * rel.y) + c2 * rel.z;
         float angle = -bh_atan2(rot.z, rot.x);
-        float ph = angle + P.time * P.rot_speed;
+        float ph = angle + P.time_rot;        // time * rotation_speed (ray.wgsl:633), one binary32 product, formed on the host
         float u = bh_sincos<0>(ph) * r, v = bh_sincos<1>(ph) * r;
         u = (u + 1.0f) * 0.5f; v = (v + 1.0f) * 0.5f;
         float4 dc = sample_bilinear(P.disk, u, v);
@@ -443,6 +443,11 @@ __device__ __noinline__ void next_ray_euler_literal(F3 bpos, F3& pos, F3& dir, f
     pos = pos + dir * step;
 }
 
+// number of set bits of a wave mask below this lane (prefix popcount): v_mbcnt_lo + v_mbcnt_hi, no per-lane mask registers
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 // ------------------------------------------------------------------------------------------
 // classify: ray.wgsl:167-243
 // ------------------------------------------------------------------------------------------
@@ -528,7 +533,7 @@ __global__ __launch_bounds__(256) void classify_kernel(const FrameParams* __rest
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(qcount, (uint32_t)__popcll(m));
         base = __builtin_amdgcn_readfirstlane(base);
-        if (need_trace) queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)L.tag << 30) | ((uint32_t)y << 15) | (uint32_t)x;
+        if (need_trace) queue[base + lanes_below(m)] = ((uint32_t)L.tag << 30) | ((uint32_t)y << 15) | (uint32_t)x;
     }
     if (COUNT) {
         const unsigned long long mv = __ballot(valid), m0 = __ballot(kind == 0), m1 = __ballot(kind == 1);
@@ -567,10 +572,43 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #define BHRAY_TRACE_WAVES_DENSE 6
 #endif
 
+// Cold per-lane ray state: values the integrator step loop reads or writes only on its rare paths (sphere exit, an actual hit)
+// or not at all (the pixel id) — 8 words per lane.  The dense build (6 waves per SIMD = 80 VGPRs) keeps them in LDS, one word
+// per lane per plane (lane-consecutive addresses: conflict-free ds_read/ds_write_b32), which takes them out of the register
+// budget of the hot loop: the compiler otherwise spills around the phases between the step batches (scratch traffic through
+// HBM: 7.5 MB written per 1080p launch against 2.9 MB for the 4-wave build).  The latency build keeps them in registers.
+template <bool IN_LDS> struct ColdState;
+template <> struct ColdState<false> {
+    uint32_t pix_ = 0; F3 color_ = {0, 0, 0}, rdir_ = {0, 0, 1}; float pend_t_ = 0.0f;
+    __device__ __forceinline__ explicit ColdState(float*) {}
+    __device__ __forceinline__ uint32_t pix() const { return pix_; }
+    __device__ __forceinline__ void set_pix(uint32_t v) { pix_ = v; }
+    __device__ __forceinline__ F3 color() const { return color_; }
+    __device__ __forceinline__ void set_color(F3 v) { color_ = v; }
+    __device__ __forceinline__ F3 rdir() const { return rdir_; }
+    __device__ __forceinline__ void set_rdir(F3 v) { rdir_ = v; }
+    __device__ __forceinline__ float pend_t() const { return pend_t_; }
+    __device__ __forceinline__ void set_pend_t(float v) { pend_t_ = v; }
+};
+template <> struct ColdState<true> {
+    float* b;                                                                     // this lane's column: plane k at b[256 * k]
+    __device__ __forceinline__ explicit ColdState(float* lds) : b(lds + threadIdx.x) {}
+    __device__ __forceinline__ uint32_t pix() const { return __float_as_uint(b[0]); }
+    __device__ __forceinline__ void set_pix(uint32_t v) { b[0] = __uint_as_float(v); }
+    __device__ __forceinline__ F3 color() const { return f3(b[256], b[512], b[768]); }
+    __device__ __forceinline__ void set_color(F3 v) { b[256] = v.x; b[512] = v.y; b[768] = v.z; }
+    __device__ __forceinline__ F3 rdir() const { return f3(b[1024], b[1280], b[1536]); }
+    __device__ __forceinline__ void set_rdir(F3 v) { b[1024] = v.x; b[1280] = v.y; b[1536] = v.z; }
+    __device__ __forceinline__ float pend_t() const { return b[1792]; }
+    __device__ __forceinline__ void set_pend_t(float v) { b[1792] = v; }
+};
+
 template <int METHOD, bool MODELS, bool COUNT, bool DENSE, bool LIT = false>
 __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHRAY_TRACE_WAVES_DENSE : BHRAY_TRACE_WAVES)) void trace_kernel(const FrameParams* __restrict__ Pb, const FrameLaunch* __restrict__ Fb, const int nb, int* __restrict__ err_flag) {
     const int lane = threadIdx.x & 63;
     int err = 0;
+    constexpr bool COLD_LDS = DENSE && !MODELS;
+    __shared__ float cold_lds[COLD_LDS ? 8 * 256 : 1];
     // the frames of the batch, starting with this block's own: a block whose frame has run dry helps with the others
     for (int fi = 0; fi < nb; fi++) {
     const int fb = (int)((blockIdx.x + (unsigned)fi) % (unsigned)nb);
@@ -584,21 +622,19 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
     const uint32_t qcount = F.qctl[0];
     const HotParams H = load_hot(P);
     const F3 bpos = H.bh;
-    const F3 cam = ld3(P.cam);
     const float t_max = 1e5f, t_min = 1e-8f;
 
     // per-lane ray state (trace_ray locals, ray.wgsl:486-516)
     int mode = M_EMPTY;
-    uint32_t pix = 0;
-    F3 cpos = cam, cdir = f3(0, 0, 1), ppos = cam, pdir = f3(0, 0, 1), rdir = f3(0, 0, 1);
-    F3 rkpos = cam, rkdir = f3(0, 0, 1);
+    ColdState<COLD_LDS> cold(cold_lds);   // pix, color, rdir (the ray's original direction), pend_t
+    F3 cpos = f3(0, 0, 0), cdir = f3(0, 0, 1), ppos = f3(0, 0, 0), pdir = f3(0, 0, 1);      // set when a lane takes a ray
+    F3 rkpos = f3(0, 0, 0), rkdir = f3(0, 0, 1);
     float rkh = 0.0f;
-    F3 color = f3(0, 0, 0);
-    float amount = 1.0f, step = P.step_size, closest = H.ray_distance;
+    float amount = 1.0f, closest = H.ray_distance;
+    // the segment length of a step's hit test (ray.wgsl:530,541): Euler - the uniform step size; RK - the post-step h, i.e. rkh
     float dist_c = P.ray_distance_f;      // flength(integrator position - bpos) (N7), carried between steps
     float cpos_dist = P.ray_distance_f;   // flength(cpos - bpos): equals dist_c except in RK mode after a hit moved cpos
-    F3 qrel = cam - bpos;                 // integrator position - bpos (the operand of dist_c), carried with it: the next step's q0
-    float pend_t = 0.0f;                  // M_SHADE_*: ray parameter of the disk hit that waits for its shading
+    F3 qrel = f3(0, 0, 0);                // integrator position - bpos (the operand of dist_c), carried with it: the next step's q0
     int it = 0;
     bool hit = false;
     bool exhausted = false;
@@ -616,9 +652,10 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
                 if (lane == (int)__builtin_ctzll(need)) base = atomicAdd(qhead, n);
                 base = (uint32_t)__shfl((int)base, (int)__builtin_ctzll(need));
                 if (base + n >= qcount) exhausted = true;
-                const uint32_t idx = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                const uint32_t idx = base + lanes_below(need);
                 if (mode == M_EMPTY && idx < qcount) {
-                    pix = queue[idx];
+                    const uint32_t pix = queue[idx];
+                    cold.set_pix(pix);
                     const int px = (int)(pix & 0x7fffu), py = (int)((pix >> 15) & 0x7fffu);
                     // level geometry: the launch's level, or (speculative multi-level launch) the entry's tagged level
                     int lw = L.w, lh = L.h;
@@ -633,10 +670,12 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
                     const float increment = 1.0f / (float)sm;
                     const float posx = (2.0f * ((float)px - (float)(lw - 1) * 0.5f)) * increment;
                     const float posy = (2.0f * ((float)py - (float)(lh - 1) * 0.5f)) * increment;
-                    rdir = normalize((ld3(P.right) * posx + ld3(P.up) * posy) + ld3(P.fwd_ff));
+                    const F3 cam = ld3(P.cam);               // uniform: scalar loads here, not three VGPRs held across the step loop
+                    const F3 rdir = normalize((ld3(P.right) * posx + ld3(P.up) * posy) + ld3(P.fwd_ff));
+                    cold.set_rdir(rdir);
                     cpos = cam; cdir = rdir; ppos = cam; pdir = rdir;
                     rkpos = cam; rkdir = rdir; rkh = P.step_size;
-                    color = f3(0, 0, 0); amount = 1.0f; step = P.step_size; closest = H.ray_distance;
+                    cold.set_color(f3(0, 0, 0)); amount = 1.0f; closest = H.ray_distance;
                     dist_c = P.ray_distance_f; cpos_dist = P.ray_distance_f; qrel = cam - bpos;
                     it = 0; hit = false;
                     mode = P.relativity0 ? M_REL : M_FLAT;
@@ -649,13 +688,14 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
         // ---- deferred disk shading (ray.wgsl:612-663 and the hit bookkeeping of 537-552) for lanes that paused on a disk hit
         if (__any(mode >= M_SHADE_REL)) {
             if (mode >= M_SHADE_REL) {
+                const float pend_t = cold.pend_t();
                 Hit crs; crs.hit = true; crs.t = pend_t; crs.color = f3(0.0f, 0.0f, 0.0f); crs.opacity = 0.0f;
                 shade_disk<COUNT>(H, ppos, pdir, pend_t, H.ray_distance, crs, cnt);
                 cpos = cpos + pdir * crs.t;
                 cpos_dist = fdistance(cpos, bpos);
                 if (METHOD == 0) { dist_c = cpos_dist; qrel = cpos - bpos; }
                 const F3 cc = f3(clamp_(crs.color.x, 0.0f, 1.0f), clamp_(crs.color.y, 0.0f, 1.0f), clamp_(crs.color.z, 0.0f, 1.0f));
-                color = color + cc * (amount * crs.opacity);
+                cold.set_color(cold.color() + cc * (amount * crs.opacity));
                 amount *= 1.0f - crs.opacity;
                 hit = true;
                 if (amount < 0.005f) mode = M_FINISH;
@@ -723,7 +763,7 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
                             cpos_dist = fdistance(cpos, bpos);
                             if (METHOD == 0) { dist_c = cpos_dist; qrel = cpos - bpos; }
                             const F3 cc = f3(clamp_(crs.color.x, 0.0f, 1.0f), clamp_(crs.color.y, 0.0f, 1.0f), clamp_(crs.color.z, 0.0f, 1.0f));
-                            color = color + cc * (amount * crs.opacity);
+                            cold.set_color(cold.color() + cc * (amount * crs.opacity));
                             amount *= 1.0f - crs.opacity;
                             hit = true;
                         }
@@ -737,6 +777,8 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
         if (__any(mode == M_FINISH)) {
             if (mode == M_FINISH) {
                 float4 o;
+                F3 color = cold.color();
+                const uint32_t pix = cold.pix();
                 if (hit || it <= 5) {
                     if (amount > 0.001f) {
                         if (COUNT) cnt[9]++;
@@ -784,18 +826,18 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
                     float cd;
                     if (LIT) {
                         if (METHOD == 0) {
-                            next_ray_euler_literal(bpos, cpos, cdir, step);
+                            next_ray_euler_literal(bpos, cpos, cdir, H.step_size);
                         } else {
                             next_ray_rk_literal(bpos, rkpos, rkdir, rkh);
-                            cpos = rkpos; cdir = rkdir; step = rkh;
+                            cpos = rkpos; cdir = rkdir;
                         }
                         cd = distance(cpos, bpos);                        // ray.wgsl:533, operator by operator
                     } else {
                     if (METHOD == 0) {
-                        next_ray_euler(qrel, cpos, cdir, step, dist_c);
+                        next_ray_euler(qrel, cpos, cdir, H.step_size, dist_c);
                     } else {
                         next_ray_rk(qrel, rkpos, rkdir, rkh, dist_c);
-                        cpos = rkpos; cdir = rkdir; step = rkh;
+                        cpos = rkpos; cdir = rkdir;
                     }
                     qrel = cpos - bpos;
                     cd = sqrt_rn(fdot(qrel, qrel));               // N7: the integrator's distance (ray.wgsl:533) = fdistance(cpos, bpos)
@@ -804,19 +846,20 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
                     if (cd < closest) closest = cd;
                     pdir = cdir;
                     Hit crs; float td;
-                    const bool disk = hit_black_hole_geom(H, ppos, pdir, ppos_dist, t_min, step, crs, td);
+                    const float seg = METHOD == 0 ? H.step_size : rkh;
+                    const bool disk = hit_black_hole_geom(H, ppos, pdir, ppos_dist, t_min, seg, crs, td);
                     if (cd > H.R) {
                         mode = M_FLAT;
                         const float fw = H.R * H.feather;
                         const float fs = H.R - fw;
                         const float lin = clamp_((closest - fs) / fw, 0.0f, 1.0f);
                         const float m = lin * lin;
-                        cdir = mix3(cdir, rdir, m);
+                        cdir = mix3(cdir, cold.rdir(), m);
                     }
                     if (disk) {
                         // The shading of a disk hit (~700 instructions, needed by 1-5 lanes of a stepping wave) is deferred to the
                         // shade phase: the lane pauses with ppos / pdir / td intact and resumes in the mode it has now.
-                        pend_t = td;
+                        cold.set_pend_t(td);
                         mode = (mode == M_FLAT) ? M_SHADE_FLAT : M_SHADE_REL;
                         continue;
                     }
@@ -825,7 +868,7 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
                         cpos_dist = fdistance(cpos, bpos);
                         if (METHOD == 0) { dist_c = cpos_dist; qrel = cpos - bpos; }
                         const F3 cc = f3(clamp_(crs.color.x, 0.0f, 1.0f), clamp_(crs.color.y, 0.0f, 1.0f), clamp_(crs.color.z, 0.0f, 1.0f));
-                        color = color + cc * (amount * crs.opacity);
+                        cold.set_color(cold.color() + cc * (amount * crs.opacity));
                         amount *= 1.0f - crs.opacity;
                         hit = true;
                     }

@@ -8,18 +8,19 @@ using namespace bhray;
 template <int R>
 __global__ void k(float* out, int steps, float x0) {
     const F3 bpos = f3(0.0f, 0.0f, 0.0f);
-    F3 pos[R], dir[R]; float h[R], dist[R], closest[R]; int hits[R];
+    F3 pos[R], dir[R], q[R]; float h[R], dist[R], closest[R]; int hits[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
         pos[r] = f3(x0 + threadIdx.x * 0.01f + r * 0.37f, 2.5f + r, -19.0f); dir[r] = normalize(f3(0.01f * threadIdx.x, 0.02f + 0.01f * r, 1.0f));
-        h[r] = 0.15f; dist[r] = length(pos[r] - bpos); closest[r] = dist[r]; hits[r] = 0;
+        h[r] = 0.15f; q[r] = pos[r] - bpos; dist[r] = length(q[r]); closest[r] = dist[r]; hits[r] = 0;
     }
     for (int i = 0; i < steps; i++) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const F3 ppos = pos[r];
-            next_ray_rk(bpos, pos[r], dir[r], h[r], dist[r]);
-            const float cd = distance(pos[r], bpos);
+            next_ray_rk(q[r], pos[r], dir[r], h[r], dist[r]);
+            q[r] = pos[r] - bpos;
+            const float cd = sqrt_rn(fdot(q[r], q[r]));
             dist[r] = cd;
             if (cd < closest[r]) closest[r] = cd;
             const F3 oc = ppos - bpos;
@@ -52,8 +53,8 @@ void run(int waves_per_simd) {
 }
 
 int main() {
-    for (int w : {1, 2, 4, 8}) run<1>(w);
-    for (int w : {1, 2, 4}) run<2>(w);
+    for (int w : {1, 2, 4, 6, 8}) run<1>(w);
+    for (int w : {1, 2, 3, 4}) run<2>(w);
     for (int w : {1, 2}) run<3>(w);
     return 0;
 }
