@@ -43,6 +43,7 @@ struct FrameRes {
     std::vector<uint32_t*> queue;       // [levels]
     std::vector<float4*> spec_out;      // speculative mode: traced images of levels 1..S-1 (level 0 traces straight into level_out[0])
     uint32_t* spec_queue = nullptr;     // speculative mode: merged, level-tagged queue of levels 0..S-1
+    uint32_t* super_queue = nullptr;    // superset speculation: merged, level-tagged queue of the last U levels
     uint32_t* d_qctl = nullptr;         // [2*BHRAY_MAX_LEVELS]: qcount[l], qhead[l]   (a slice of Slot::d_qctl)
     Counters64* d_counters = nullptr;   // [BHRAY_MAX_LEVELS]                         (a slice of Slot::d_counters)
     float4* own_out = nullptr;
@@ -315,6 +316,7 @@ void dev_destroy(bhray_dev* c) {
             for (auto p : R.queue) if (p) (void)hipFree(p);
             for (auto p : R.spec_out) if (p) (void)hipFree(p);
             if (R.spec_queue) (void)hipFree(R.spec_queue);
+            if (R.super_queue) (void)hipFree(R.super_queue);
             if (R.own_out) (void)hipFree(R.own_out);
             if (R.sky_out) (void)hipFree(R.sky_out);
         }
@@ -354,6 +356,9 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
     if (cfg->frames_per_batch > BHRAY_MAX_FRAMES_PER_BATCH) return fail(nullptr, BHRAY_E_INVALID, "frames_per_batch > %d", BHRAY_MAX_FRAMES_PER_BATCH);
     if (cfg->speculative_levels == 1 || cfg->speculative_levels > BHRAY_MAX_SPEC_LEVELS || (cfg->speculative_levels && cfg->speculative_levels >= cfg->levels))
         return fail(nullptr, BHRAY_E_INVALID, "speculative_levels must be 0 or 2..min(%d, levels-1)", BHRAY_MAX_SPEC_LEVELS);
+    if (cfg->superset_levels == 1 || cfg->superset_levels > BHRAY_MAX_SPEC_LEVELS ||
+        (cfg->superset_levels && cfg->superset_levels + (cfg->speculative_levels ? cfg->speculative_levels : 1) > cfg->levels))
+        return fail(nullptr, BHRAY_E_INVALID, "superset_levels must be 0 or 2..%d and leave at least one coarser level (beyond the speculative ones)", BHRAY_MAX_SPEC_LEVELS);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(nullptr, BHRAY_E_NO_DEVICE, "no HIP device visible (libbhray has no CPU path)");
@@ -418,7 +423,7 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
         }
     }
     c->out_bytes = (opt.frame_rowmap ? (size_t)cfg->frame_h : c->local_rows.size()) * (size_t)cfg->frame_w * sizeof(float4);
-    const size_t nlaunch = 3 * (size_t)nl + 2;                            // upper bound of launches per batch
+    const size_t nlaunch = 4 * (size_t)nl + 2;                            // upper bound of launches per batch
     for (Slot& S : c->slots) {
         CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
         CHK(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
@@ -461,6 +466,11 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
                     }
                 }
                 if (cap) CHK(hipMalloc(&R.spec_queue, cap * sizeof(uint32_t)));
+            }
+            if (cfg->superset_levels) {
+                size_t cap = 0;
+                for (uint32_t l = nl - cfg->superset_levels; l < nl; l++) cap += c->levels[l].queue_cap;
+                if (cap) CHK(hipMalloc(&R.super_queue, cap * sizeof(uint32_t)));
             }
             if (c->out_bytes && !opt.external_out) {
                 CHK(hipMalloc(&R.own_out, c->out_bytes));
@@ -761,7 +771,9 @@ int launch_batch(bhray_dev* c) {
         }
         first_normal = ns;
     }
-    for (uint32_t l = first_normal; l < nl && any_rows; l++) {
+    const uint32_t nu = c->cfg.superset_levels;
+    const uint32_t u0 = nu ? nl - nu : nl;                     // first level of the superset group
+    for (uint32_t l = first_normal; l < u0 && any_rows; l++) {
         FrameLaunch* h; const FrameLaunch* d; next_launch(h, d);
         for (uint32_t k = 0; k < nb; k++) {
             const FrameRes& R = S.fr[k];
@@ -770,6 +782,54 @@ int launch_batch(bhray_dev* c) {
         }
         seq.push_back({0, d, classify_blocks(l), count, {(int)(3 * l)}, {(int)(3 * l + 1)}});
         seq.push_back({1, d, grid, count, {}, {(int)(3 * l + 2)}});
+    }
+    if (nu && any_rows) {
+        // Superset speculation over the last nu levels: ONE trace launch instead of nu dependent ones.
+        //  (1) tentative classification of levels u0..nl-1 in order: a pixel whose coarser inputs are known is classified exactly,
+        //      a pixel with an input that is itself queued (PENDING) is queued conservatively -> one level-tagged queue;
+        //  (2) one trace launch over it, each ray stored at its level's own place;
+        //  (3) the levels are classified again, exactly, now that the coarser level is final: copy / interpolate are stored,
+        //      pixels that need tracing keep what (2) wrote (the queued set is a superset of the needed one).
+        // Same pixels as the plain ladder; the extra rays are the conservatively queued pixels that turn out to interpolate.
+        // Queue control words of level u0 serve the merged queue; the trace is timed as level u0's.
+        for (uint32_t l = u0; l < nl; l++) {
+            FrameLaunch* h; const FrameLaunch* d; next_launch(h, d);
+            for (uint32_t k = 0; k < nb; k++) {
+                const FrameRes& R = S.fr[k];
+                level_params(R, l, h[k].L);
+                h[k].L.pass = CLASSIFY_TENTATIVE; h[k].L.tag = (int)(l - u0); h[k].L.no_store = (l == nl - 1) ? 1 : 0;
+                h[k].queue = R.super_queue; h[k].qctl = R.d_qctl + 2 * u0; h[k].counters = nullptr;
+            }
+            seq.push_back({0, d, classify_blocks(l), false, {}, {}});
+            if (l == u0) seq.back().ev_before = {(int)(3 * u0)};
+            if (l == nl - 1) seq.back().ev_after = {(int)(3 * u0 + 1)};
+        }
+        {
+            FrameLaunch* h; const FrameLaunch* d; next_launch(h, d);
+            for (uint32_t k = 0; k < nb; k++) {
+                const FrameRes& R = S.fr[k];
+                level_params(R, u0, h[k].L);
+                h[k].SL.n = (int)nu;
+                for (uint32_t l = u0; l < nl; l++) {
+                    LevelParams Lp; level_params(R, l, Lp);
+                    SpecLevel& sl = h[k].SL.l[l - u0];
+                    sl.w = Lp.w; sl.h = Lp.h; sl.out = Lp.out; sl.out_pitch = Lp.out_pitch; sl.out_x0 = Lp.out_x0; sl.rowmap = Lp.rowmap;
+                }
+                h[k].queue = R.super_queue; h[k].qctl = R.d_qctl + 2 * u0; h[k].counters = count ? R.d_counters + u0 : nullptr;
+            }
+            seq.push_back({1, d, grid, count, {}, {(int)(3 * u0 + 2)}});
+        }
+        for (uint32_t l = u0; l < nl; l++) {
+            FrameLaunch* h; const FrameLaunch* d; next_launch(h, d);
+            for (uint32_t k = 0; k < nb; k++) {
+                const FrameRes& R = S.fr[k];
+                level_params(R, l, h[k].L);
+                h[k].L.pass = CLASSIFY_KEEP;
+                h[k].queue = nullptr; h[k].qctl = R.d_qctl + 2 * l; h[k].counters = count ? R.d_counters + l : nullptr;
+            }
+            if (l == u0) seq.push_back({0, d, classify_blocks(l), count, {}, {}});      // inside level u0's trace interval
+            else seq.push_back({0, d, classify_blocks(l), count, {(int)(3 * l)}, {(int)(3 * l + 1), (int)(3 * l + 2)}});
+        }
     }
     if (args_used > S.args_cap) return fail(c, BHRAY_E_STATE, "internal: argument block overflow");
     // enqueue
@@ -1050,7 +1110,7 @@ int dev_get_counters(bhray_dev* c, bhray_counters* out) {
         int rc = dev_get_level_counters(c, l, &t);
         if (rc) return rc;
         const uint64_t* a = (const uint64_t*)&t; uint64_t* b = (uint64_t*)out;
-        for (size_t k = 0; k < sizeof(bhray_counters) / 8; k++) b[k] += a[k];
+        for (size_t k = 0; k < sizeof(bhray_counters) / 8; k++) { if (k == 12) b[k] = a[k] > b[k] ? a[k] : b[k]; else b[k] += a[k]; }   // [12] max_ray_iterations
     }
     return BHRAY_OK;
 }
@@ -1076,7 +1136,8 @@ int dev_get_timing(bhray_dev* c, bhray_timing* out) {
             float a = 0, b = 0;
             HIPCHK(c, hipEventElapsedTime(&a, ev[3 * l], ev[3 * l + 1]));
             HIPCHK(c, hipEventElapsedTime(&b, ev[3 * l + 1], ev[3 * l + 2]));
-            const bool spec_classified = c->cfg.speculative_levels && l >= 1 && l < c->cfg.speculative_levels;   // no trace launch of its own
+            const bool spec_classified = (c->cfg.speculative_levels && l >= 1 && l < c->cfg.speculative_levels) ||
+                                         (c->cfg.superset_levels && l > nl - c->cfg.superset_levels);               // no trace launch of its own
             out->classify_ms += a; out->level_classify_ms[l] += a; out->classify_launches++;
             if (!spec_classified) { out->trace_ms += b; out->level_trace_ms[l] += b; out->trace_launches++; }
             if (!first) first = ev[3 * l];

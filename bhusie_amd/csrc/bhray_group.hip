@@ -801,7 +801,7 @@ int bhray_get_level_counters(bhray_ctx* c, uint32_t level, bhray_counters* out) 
         bhray_counters t;
         DEV(c, p.dev, dev_get_level_counters(p.dev, level, &t));
         const uint64_t* a = (const uint64_t*)&t; uint64_t* b = (uint64_t*)out;
-        for (size_t k = 0; k < sizeof(bhray_counters) / 8; k++) b[k] += a[k];
+        for (size_t k = 0; k < sizeof(bhray_counters) / 8; k++) { if (k == 12) b[k] = a[k] > b[k] ? a[k] : b[k]; else b[k] += a[k]; }   // [12] max_ray_iterations
     }
     return BHRAY_OK;
 }
@@ -814,7 +814,7 @@ int bhray_get_counters(bhray_ctx* c, bhray_counters* out) {
         int rc = bhray_get_level_counters(c, l, &t);
         if (rc) return rc;
         const uint64_t* a = (const uint64_t*)&t; uint64_t* b = (uint64_t*)out;
-        for (size_t k = 0; k < sizeof(bhray_counters) / 8; k++) b[k] += a[k];
+        for (size_t k = 0; k < sizeof(bhray_counters) / 8; k++) { if (k == 12) b[k] = a[k] > b[k] ? a[k] : b[k]; else b[k] += a[k]; }   // [12] max_ray_iterations
     }
     return BHRAY_OK;
 }

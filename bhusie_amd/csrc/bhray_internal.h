@@ -76,13 +76,24 @@ struct LevelParams {
     int x0, x1;            // columns to compute
     int tag;               // speculative mode: level id stored in bits 30-31 of the queue entries
     const float4* spec;    // speculative mode: already traced pixels of this level; a pixel that needs tracing copies from here
+    int pass;              // CLASSIFY_NORMAL / CLASSIFY_TENTATIVE / CLASSIFY_KEEP (superset speculation, bhray_config.superset_levels)
+    int no_store;          // tentative pass of the last level: nobody reads its image, only the queue entries are produced
 };
+enum : int { CLASSIFY_NORMAL = 0,
+             // the coarser level may hold PENDING pixels (alpha = 2: queued for tracing, value not known yet).  A pixel whose inputs are all
+             // known is classified exactly (copy / interpolate -> stored; trace -> queued, PENDING stored); a pixel with a PENDING
+             // input is queued conservatively (a copy pixel: just marked PENDING).  The queued set is a superset of the exact one.
+             CLASSIFY_TENTATIVE = 1,
+             // after the trace of the superset: the coarser level is final.  Copy / interpolate are stored (overwriting speculative
+             // traces the exact classification does not want); a pixel that needs tracing is left as the trace launch wrote it.
+             CLASSIFY_KEEP = 2 };
+#define BHRAY_PENDING_ALPHA 2.0f   // alpha of a final pixel is exactly 0 or 1
 
 // Speculative tracing of several levels in one launch: per-level geometry and destination, selected by the entry's tag.
-struct SpecLevel { int w, h; float4* out; int out_pitch; };
+struct SpecLevel { int w, h; float4* out; int out_pitch; int out_x0; const int32_t* rowmap; };   // rowmap/out_x0 as in LevelParams
 struct SpecLevels { int n; SpecLevel l[BHRAY_MAX_SPEC_LEVELS]; };   // n == 0: one level, described by LevelParams
 
-struct Counters64 { unsigned long long v[10]; };   // order = bhray_counters
+struct Counters64 { unsigned long long v[13]; };   // order = bhray_counters
 
 // One frame's share of one launch.  A launch covers the `nb` frames of a batch: classify uses blockIdx.y as the frame
 // index, the persistent trace blocks start on frame blockIdx.x % nb and move on to the other frames when theirs runs dry.

@@ -498,15 +498,18 @@ __global__ __launch_bounds__(256) void classify_kernel(const FrameParams* __rest
             const float ppx = (float)x * L.rx, ppy = (float)y * L.ry;
             const float tlx = floorf(ppx), tly = floorf(ppy);
             const float4 c_tl = load_prev(L, (int)tlx, (int)tly);
+            const bool tentative = L.pass == CLASSIFY_TENTATIVE;
+            const float4 pending = make_float4(0.0f, 0.0f, 0.0f, BHRAY_PENDING_ALPHA);
             if (fabsf(tlx - ppx) < 0.001f && fabsf(tly - ppy) < 0.001f) {
-                L.out[out_index(L, x, y)] = c_tl; kind = 0;
+                if (!L.no_store) L.out[out_index(L, x, y)] = c_tl;       // tentative: a PENDING source stays PENDING; the KEEP pass copies the final value
+                kind = 0;
             } else {
                 const float4 c_bl = load_prev(L, (int)tlx, (int)(tly + 1.0f));
                 const float4 c_tr = load_prev(L, (int)(tlx + 1.0f), (int)tly);
                 const float4 c_br = load_prev(L, (int)(tlx + 1.0f), (int)(tly + 1.0f));
                 const bool alphas0 = c_tl.w == 0.0f && c_tr.w == 0.0f && c_bl.w == 0.0f && c_br.w == 0.0f;
                 bool interp = false;
-                if (alphas0) {
+                if (alphas0) {                       // a PENDING neighbour (alpha 2) fails this test: the pixel is queued, conservatively
                     const float cs = P.acos_cstar;
                     interp = angle_below_threshold(c_bl, c_tl, cs) && angle_below_threshold(c_br, c_tr, cs) &&
                              angle_below_threshold(c_tl, c_tr, cs) && angle_below_threshold(c_bl, c_br, cs);
@@ -516,12 +519,15 @@ __global__ __launch_bounds__(256) void classify_kernel(const FrameParams* __rest
                     F3 top = mix3(f3(c_tl.x, c_tl.y, c_tl.z), f3(c_tr.x, c_tr.y, c_tr.z), tx_);
                     F3 bot = mix3(f3(c_bl.x, c_bl.y, c_bl.z), f3(c_br.x, c_br.y, c_br.z), tx_);
                     F3 p = mix3(top, bot, ty_);
-                    L.out[out_index(L, x, y)] = make_float4(p.x, p.y, p.z, 0.0f); kind = 1;
+                    if (!L.no_store) L.out[out_index(L, x, y)] = make_float4(p.x, p.y, p.z, 0.0f);
+                    kind = 1;
                 } else {
                     need_trace = true; kind = 2;
+                    if (tentative && !L.no_store) L.out[out_index(L, x, y)] = pending;
                 }
             }
         }
+        if (need_trace && L.pass == CLASSIFY_KEEP) need_trace = false;      // traced by the superset launch: leave the pixel as it is
         if (need_trace && L.spec) {                  // speculative mode: the traced value already exists
             L.out[out_index(L, x, y)] = L.spec[(size_t)y * (size_t)L.w + (size_t)x];
             need_trace = false;
@@ -571,6 +577,12 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #ifndef BHRAY_TRACE_WAVES_DENSE
 #define BHRAY_TRACE_WAVES_DENSE 6
 #endif
+#ifndef BHRAY_TRACE_THREADS
+#define BHRAY_TRACE_THREADS 256  // threads per persistent trace block (a multiple of 64)
+#endif
+#ifndef BHRAY_MAILBOX_T
+#define BHRAY_MAILBOX_T 0        // drain merging (measured, off: DESIGN.md §4): a wave with this many live rays or fewer parks them; 0 disables
+#endif
 
 // Cold per-lane ray state: values the integrator step loop reads or writes only on its rare paths (sphere exit, an actual hit)
 // or not at all (the pixel id) — 8 words per lane.  The dense build (6 waves per SIMD = 80 VGPRs) keeps them in LDS, one word
@@ -591,27 +603,48 @@ template <> struct ColdState<false> {
     __device__ __forceinline__ void set_pend_t(float v) { pend_t_ = v; }
 };
 template <> struct ColdState<true> {
-    float* b;                                                                     // this lane's column: plane k at b[256 * k]
+    float* b;                                                                     // this lane's column: plane k at b[S * k]
     __device__ __forceinline__ explicit ColdState(float* lds) : b(lds + threadIdx.x) {}
     __device__ __forceinline__ uint32_t pix() const { return __float_as_uint(b[0]); }
     __device__ __forceinline__ void set_pix(uint32_t v) { b[0] = __uint_as_float(v); }
-    __device__ __forceinline__ F3 color() const { return f3(b[256], b[512], b[768]); }
-    __device__ __forceinline__ void set_color(F3 v) { b[256] = v.x; b[512] = v.y; b[768] = v.z; }
-    __device__ __forceinline__ F3 rdir() const { return f3(b[1024], b[1280], b[1536]); }
-    __device__ __forceinline__ void set_rdir(F3 v) { b[1024] = v.x; b[1280] = v.y; b[1536] = v.z; }
-    __device__ __forceinline__ float pend_t() const { return b[1792]; }
-    __device__ __forceinline__ void set_pend_t(float v) { b[1792] = v; }
+    static constexpr int S = BHRAY_TRACE_THREADS;                                 // plane stride
+    __device__ __forceinline__ F3 color() const { return f3(b[S], b[2 * S], b[3 * S]); }
+    __device__ __forceinline__ void set_color(F3 v) { b[S] = v.x; b[2 * S] = v.y; b[3 * S] = v.z; }
+    __device__ __forceinline__ F3 rdir() const { return f3(b[4 * S], b[5 * S], b[6 * S]); }
+    __device__ __forceinline__ void set_rdir(F3 v) { b[4 * S] = v.x; b[5 * S] = v.y; b[6 * S] = v.z; }
+    __device__ __forceinline__ float pend_t() const { return b[7 * S]; }
+    __device__ __forceinline__ void set_pend_t(float v) { b[7 * S] = v; }
 };
 
 template <int METHOD, bool MODELS, bool COUNT, bool DENSE, bool LIT = false>
-__global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHRAY_TRACE_WAVES_DENSE : BHRAY_TRACE_WAVES)) void trace_kernel(const FrameParams* __restrict__ Pb, const FrameLaunch* __restrict__ Fb, const int nb, int* __restrict__ err_flag) {
+__global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHRAY_TRACE_WAVES_DENSE : BHRAY_TRACE_WAVES)) void trace_kernel(const FrameParams* __restrict__ Pb, const FrameLaunch* __restrict__ Fb, const int nb, int* __restrict__ err_flag) {
     const int lane = threadIdx.x & 63;
     int err = 0;
     constexpr bool COLD_LDS = DENSE && !MODELS;
-    __shared__ float cold_lds[COLD_LDS ? 8 * 256 : 1];
+    __shared__ float cold_lds[COLD_LDS ? 8 * BHRAY_TRACE_THREADS : 1];
+    // Drain merging (dense build).  Once a launch's queue has run dry its waves finish their rays at ever lower lane occupancy
+    // (16 % of the lane-steps of a 1080p frame).  A wave left with <= MB_T live rays parks them - the whole per-ray state, 36 words -
+    // in the block's LDS mailbox and exits; waves of the same block with empty lanes adopt parked rays at their next refill.  A ray is
+    // the same sequence of operations whichever lane runs it, so pixels do not change.  Protocol (LDS atomics by lane 0):
+    //   alive    waves of the block that have not left; a donor leaves only if somebody stays (it decrements alive and reverts if
+    //            it was the last), the last wave never parks and adopts whatever is still parked before it leaves;
+    //   pending  donors between their reservation and their publication - raised BEFORE alive is decremented, so the last wave,
+    //            which got there after the donor, sees it and waits;
+    //   reserved / ready / taken  slots handed to donors / published / claimed by adopters (each wave parks at most once: <= 3 x MB_T).
+    // Only in the last frame of a batch (waves of a block walk the frames in the same order, so the parked rays' frame is the frame
+    // every later wave ends on).
+    constexpr int MB_T = BHRAY_MAILBOX_T, MB_CAP = 3 * MB_T, MB_WORDS = 36;
+    constexpr bool MAILBOX = COLD_LDS && MB_T > 0 && BHRAY_TRACE_THREADS > 64;
+    __shared__ int mb_ctl[8];                                   // [0] alive [1] pending [2] reserved [3] ready [4] taken
+    __shared__ float mb_state[MAILBOX ? MB_WORDS * MB_CAP : 1]; // word w of slot k at [w * MB_CAP + k]
+    if (MAILBOX) {
+        if (threadIdx.x < 8) mb_ctl[threadIdx.x] = threadIdx.x == 0 ? (int)(blockDim.x >> 6) : 0;
+        __syncthreads();
+    }
     // the frames of the batch, starting with this block's own: a block whose frame has run dry helps with the others
     for (int fi = 0; fi < nb; fi++) {
     const int fb = (int)((blockIdx.x + (unsigned)fi) % (unsigned)nb);
+    const bool last_frame = fi == nb - 1;
     const FrameParams& P = Pb[fb];
     const FrameLaunch& F = Fb[fb];
     const LevelParams& L = F.L;
@@ -639,8 +672,8 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
     bool hit = false;
     bool exhausted = false;
     int flat_round = 0;
-    unsigned long long cnt[10];
-    if (COUNT) { for (int k = 0; k < 10; k++) cnt[k] = 0; }
+    unsigned long long cnt[13];           // [0..9] = bhray_counters' frame counters, [10] wave steps (lane 0), [11] rays adopted, [12] longest ray
+    if (COUNT) { for (int k = 0; k < 13; k++) cnt[k] = 0; }
 
     for (;;) {
         // ---- refill finished lanes from the queue (wave ballot + prefix popcount)
@@ -682,7 +715,108 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
                     if (COUNT) cnt[3]++;
                 }
             }
-            if (!__any(mode != M_EMPTY)) break;
+            if (!(MAILBOX && MB_T > 0 && last_frame)) { if (!__any(mode != M_EMPTY)) break; }
+        }
+        // ---- drain merging through the block's LDS mailbox (see the declaration of mb_ctl)
+        if (MAILBOX && MB_T > 0 && last_frame) {
+            if (!exhausted) {
+                if (!__any(mode != M_EMPTY)) exhausted = true;      // cannot happen (an empty wave has just been refused by the queue)
+            }
+            if (exhausted) {
+#define BHRAY_RAY_FLOATS(X)                                                                                              \
+    X(0, cpos.x) X(1, cpos.y) X(2, cpos.z) X(3, cdir.x) X(4, cdir.y) X(5, cdir.z) X(6, ppos.x) X(7, ppos.y) X(8, ppos.z)     \
+    X(9, pdir.x) X(10, pdir.y) X(11, pdir.z) X(12, rkpos.x) X(13, rkpos.y) X(14, rkpos.z) X(15, rkdir.x) X(16, rkdir.y)     \
+    X(17, rkdir.z) X(18, qrel.x) X(19, qrel.y) X(20, qrel.z) X(21, rkh) X(22, amount) X(23, closest) X(24, dist_c) X(25, cpos_dist)
+                // (1) adopt parked rays into the empty lanes
+                const unsigned long long emptym = __ballot(mode == M_EMPTY);
+                if (emptym != 0ull) {
+                    int t0 = 0, n = 0;
+                    if (lane == 0) {
+                        const int want = __popcll(emptym);
+                        int old = __hip_atomic_load(&mb_ctl[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        for (;;) {
+                            const int av = __hip_atomic_load(&mb_ctl[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - old;
+                            if (av <= 0) { n = 0; break; }
+                            n = want < av ? want : av;
+                            const int seen = atomicCAS(&mb_ctl[4], old, old + n);
+                            if (seen == old) { t0 = old; break; }
+                            old = seen;
+                        }
+                    }
+                    t0 = __builtin_amdgcn_readfirstlane(t0); n = __builtin_amdgcn_readfirstlane(n);
+                    if (n > 0) {
+                        const int e = (int)lanes_below(emptym);
+                        if (mode == M_EMPTY && e < n) {
+                            const float* sp = mb_state + (t0 + e);
+#define X(w, v) v = sp[(w) * MB_CAP];
+                            BHRAY_RAY_FLOATS(X)
+#undef X
+                            cold.set_color(f3(sp[26 * MB_CAP], sp[27 * MB_CAP], sp[28 * MB_CAP]));
+                            cold.set_rdir(f3(sp[29 * MB_CAP], sp[30 * MB_CAP], sp[31 * MB_CAP]));
+                            cold.set_pend_t(sp[32 * MB_CAP]);
+                            cold.set_pix(__float_as_uint(sp[33 * MB_CAP]));
+                            const int mh = __float_as_int(sp[34 * MB_CAP]);
+                            mode = mh & 0xff; hit = (mh >> 8) != 0;
+                            it = __float_as_int(sp[35 * MB_CAP]);
+                            if (COUNT) cnt[11]++;
+                        }
+                    }
+                }
+                // (2) nothing left: leave (the last wave of the block first adopts what is still parked); few left: park them and leave
+                const unsigned long long livem = __ballot(mode != M_EMPTY);
+                const int live = __popcll(livem);
+                if (live == 0) {
+                    int r = 1;
+                    if (lane == 0) {
+                        const int old = atomicSub(&mb_ctl[0], 1);
+                        if (old <= 1) {                               // the last wave standing: parked rays are its responsibility
+                            int spins = 0;
+                            while (__hip_atomic_load(&mb_ctl[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0 && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(2); spins++; }
+                            if (spins >= (1 << 22)) r = 2;
+                            else if (__hip_atomic_load(&mb_ctl[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - __hip_atomic_load(&mb_ctl[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > 0) {
+                                atomicAdd(&mb_ctl[0], 1); r = 0;      // back in: adopt at the top of the loop
+                            }
+                        }
+                    }
+                    r = __builtin_amdgcn_readfirstlane(r);
+                    if (r == 2) err = BHRAY_E_STATE;
+                    if (r != 0) break;
+                    continue;
+                }
+                if (live <= MB_T) {
+                    int base = -1;
+                    if (lane == 0) {
+                        atomicAdd(&mb_ctl[1], 1);
+                        const int old = atomicSub(&mb_ctl[0], 1);
+                        if (old <= 1) { atomicAdd(&mb_ctl[0], 1); atomicSub(&mb_ctl[1], 1); }      // nobody would be left to adopt them: carry on
+                        else base = atomicAdd(&mb_ctl[2], live);
+                    }
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= 0) {
+                        if (mode != M_EMPTY) {
+                            float* sp = mb_state + (base + (int)lanes_below(livem));
+#define X(w, v) sp[(w) * MB_CAP] = v;
+                            BHRAY_RAY_FLOATS(X)
+#undef X
+                            const F3 col = cold.color(), rd = cold.rdir();
+                            sp[26 * MB_CAP] = col.x; sp[27 * MB_CAP] = col.y; sp[28 * MB_CAP] = col.z;
+                            sp[29 * MB_CAP] = rd.x; sp[30 * MB_CAP] = rd.y; sp[31 * MB_CAP] = rd.z;
+                            sp[32 * MB_CAP] = cold.pend_t();
+                            sp[33 * MB_CAP] = __uint_as_float(cold.pix());
+                            sp[34 * MB_CAP] = __int_as_float(mode | (hit ? 0x100 : 0));
+                            sp[35 * MB_CAP] = __int_as_float(it);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) {
+                            __hip_atomic_fetch_add(&mb_ctl[3], live, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            atomicSub(&mb_ctl[1], 1);
+                        }
+                        mode = M_EMPTY;
+                        break;
+                    }
+                }
+#undef BHRAY_RAY_FLOATS
+            }
         }
 
         // ---- deferred disk shading (ray.wgsl:612-663 and the hit bookkeeping of 537-552) for lanes that paused on a disk hit
@@ -779,6 +913,7 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
                 float4 o;
                 F3 color = cold.color();
                 const uint32_t pix = cold.pix();
+                if (COUNT && (unsigned long long)it > cnt[12]) cnt[12] = (unsigned long long)it;
                 if (hit || it <= 5) {
                     if (amount > 0.001f) {
                         if (COUNT) cnt[9]++;
@@ -801,10 +936,11 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
                     const int ox = (int)(pix & 0x7fffu), oy = (int)((pix >> 15) & 0x7fffu);
                     if (SL.n > 0) {
                         const int lv = (int)(pix >> 30);
-                        float4* dst = SL.l[0].out; int pitch = SL.l[0].out_pitch;
+                        float4* dst = SL.l[0].out; int pitch = SL.l[0].out_pitch, x0 = SL.l[0].out_x0; const int32_t* rowmap = SL.l[0].rowmap;
 #pragma unroll
-                        for (int q = 1; q < BHRAY_MAX_SPEC_LEVELS; q++) if (lv == q) { dst = SL.l[q].out; pitch = SL.l[q].out_pitch; }
-                        dst[(size_t)oy * (size_t)pitch + (size_t)ox] = o;
+                        for (int q = 1; q < BHRAY_MAX_SPEC_LEVELS; q++) if (lv == q) { dst = SL.l[q].out; pitch = SL.l[q].out_pitch; x0 = SL.l[q].out_x0; rowmap = SL.l[q].rowmap; }
+                        const int orow = rowmap ? rowmap[oy] : oy;
+                        dst[(size_t)orow * (size_t)pitch + (size_t)(ox - x0)] = o;
                     } else {
                         L.out[out_index(L, ox, oy)] = o;
                     }
@@ -816,6 +952,7 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
         // ---- a batch of integrator steps (ray.wgsl:522-553) for lanes inside the sphere
         for (int k = 0; k < BHRAY_REL_BATCH; k++) {
             if (!__any(mode == M_REL)) break;
+            if (COUNT && lane == 0) cnt[10]++;
             if (mode == M_REL) {
                 if (it >= H.max_iter) {
                     mode = M_FINISH;
@@ -879,10 +1016,15 @@ __global__ __launch_bounds__(256, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHR
     }
 
     if (COUNT) {
-        for (int k = 3; k < 10; k++) {
+        for (int k = 3; k < 12; k++) {
             unsigned long long v = cnt[k];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
             if (lane == 0 && v) atomicAdd(&counters->v[k], v);
+        }
+        {
+            unsigned long long v = cnt[12];
+            for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_down(v, off); v = o > v ? o : v; }
+            if (lane == 0 && v) atomicMax(&counters->v[12], v);
         }
     }
     }   // frames of the batch
@@ -978,8 +1120,8 @@ hipError_t launch_classify(const FrameParams* Pb, const FrameLaunch* Fb, int nb,
 
 template <int METHOD, bool MODELS, bool DENSE, bool LIT = false>
 static hipError_t launch_trace_t(const FrameParams* Pb, const FrameLaunch* Fb, int nb, bool count, int* err_flag, int grid_blocks, hipStream_t s) {
-    if (count) hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, true, DENSE, LIT>), dim3(grid_blocks), dim3(256), 0, s, Pb, Fb, nb, err_flag);
-    else hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, false, DENSE, LIT>), dim3(grid_blocks), dim3(256), 0, s, Pb, Fb, nb, err_flag);
+    if (count) hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, true, DENSE, LIT>), dim3((grid_blocks * 256 + BHRAY_TRACE_THREADS - 1) / BHRAY_TRACE_THREADS), dim3(BHRAY_TRACE_THREADS), 0, s, Pb, Fb, nb, err_flag);
+    else hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, false, DENSE, LIT>), dim3((grid_blocks * 256 + BHRAY_TRACE_THREADS - 1) / BHRAY_TRACE_THREADS), dim3(BHRAY_TRACE_THREADS), 0, s, Pb, Fb, nb, err_flag);
     return hipGetLastError();
 }
 
@@ -1016,8 +1158,9 @@ int trace_blocks_per_cu(int method, int has_models, int count, int dense, int li
     else f = method == 0 ? (count ? PICK(0, false, true, false) : PICK(0, false, false, false)) : (count ? PICK(1, false, true, false) : PICK(1, false, false, false));
 #undef PICK
 #undef PICKL
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 256, 0) != hipSuccess || n < 1) n = 2;
-    return n;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, BHRAY_TRACE_THREADS, 0) != hipSuccess || n < 1) n = 2;
+    n = n * BHRAY_TRACE_THREADS / 256;            // in units of 256 threads (the grid is sized in those)
+    return n < 1 ? 1 : n;
 }
 
 }  // namespace bhray

@@ -53,11 +53,12 @@ static_assert(BHRAY_MODEL_UNIFORM_BYTES == 48234572u, "ModelUniform size (triang
 static_assert(BHRAY_MAX_MODELS == 1 && BHRAY_MAX_MATERIALS == 8, "triangle.rs:6, material.rs:3");
 
 // not reference layouts, but ABI the bindings restate (bhusie_amd/layouts.py)
-static_assert(sizeof(bhray_counters) == 80, "bhray_counters");
+static_assert(sizeof(bhray_counters) == 104, "bhray_counters");
 static_assert(BHRAY_COMM_ID_BYTES == 128, "ncclUniqueId");
 OFF(bhray_config, level_w, 12); OFF(bhray_config, level_h, 12 + 4 * BHRAY_MAX_LEVELS); OFF(bhray_config, crop_x, 12 + 8 * BHRAY_MAX_LEVELS);
-OFF(bhray_config, device_count, 12 + 8 * BHRAY_MAX_LEVELS + 44);
-OFF(bhray_config, devices, 12 + 8 * BHRAY_MAX_LEVELS + 48);
-OFF(bhray_config, gather, 12 + 8 * BHRAY_MAX_LEVELS + 48 + 4 * BHRAY_MAX_DEVICES);
-OFF(bhray_config, comm_id, 12 + 8 * BHRAY_MAX_LEVELS + 48 + 4 * BHRAY_MAX_DEVICES + 8);
-SZ(bhray_config, 12 + 8 * BHRAY_MAX_LEVELS + 48 + 4 * BHRAY_MAX_DEVICES + 8 + BHRAY_COMM_ID_BYTES);
+OFF(bhray_config, superset_levels, 12 + 8 * BHRAY_MAX_LEVELS + 44);
+OFF(bhray_config, device_count, 12 + 8 * BHRAY_MAX_LEVELS + 48);
+OFF(bhray_config, devices, 12 + 8 * BHRAY_MAX_LEVELS + 52);
+OFF(bhray_config, gather, 12 + 8 * BHRAY_MAX_LEVELS + 52 + 4 * BHRAY_MAX_DEVICES);
+OFF(bhray_config, comm_id, 12 + 8 * BHRAY_MAX_LEVELS + 52 + 4 * BHRAY_MAX_DEVICES + 8);
+SZ(bhray_config, 12 + 8 * BHRAY_MAX_LEVELS + 52 + 4 * BHRAY_MAX_DEVICES + 8 + BHRAY_COMM_ID_BYTES);

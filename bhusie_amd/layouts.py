@@ -67,7 +67,7 @@ class BhrayConfig(C.Structure):
                 ("crop_x", C.c_uint32), ("crop_y", C.c_uint32), ("frame_w", C.c_uint32), ("frame_h", C.c_uint32),
                 ("row_rank", C.c_uint32), ("row_world", C.c_uint32), ("stripe_rows", C.c_uint32), ("flags", C.c_uint32),
                 ("frames_in_flight", C.c_uint32), ("speculative_levels", C.c_uint32), ("frames_per_batch", C.c_uint32),
-                ("device_count", C.c_uint32), ("devices", C.c_int32 * MAX_DEVICES), ("gather", C.c_uint32),
+                ("superset_levels", C.c_uint32), ("device_count", C.c_uint32), ("devices", C.c_int32 * MAX_DEVICES), ("gather", C.c_uint32),
                 ("gather_root", C.c_uint32), ("comm_id", C.c_uint8 * COMM_ID_BYTES)]
 
     def sizes(self):
@@ -75,11 +75,19 @@ class BhrayConfig(C.Structure):
 
 
 class BhrayCounters(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("pixels", "copied", "interpolated", "traced", "steps", "flat_iters",
-                                           "node_pairs", "triangles", "disk_hits", "sky_samples")]
+    FRAME = ("pixels", "copied", "interpolated", "traced", "steps", "flat_iters", "node_pairs", "triangles", "disk_hits", "sky_samples")
+    SCHED = ("wave_steps", "rays_adopted", "max_ray_iterations")
+    _fields_ = [(n, C.c_uint64) for n in FRAME + SCHED]
 
     def as_dict(self):
-        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+        """the counters that are a property of the frame (equal to the oracle's)"""
+        return {n: int(getattr(self, n)) for n in self.FRAME}
+
+    def scheduling(self):
+        """how the trace kernel scheduled that work: depends on the build, frames in flight, batches"""
+        d = {n: int(getattr(self, n)) for n in self.SCHED}
+        d["step_lane_occupancy"] = (self.steps / (64.0 * self.wave_steps)) if self.wave_steps else None
+        return d
 
 
 class BhrayTiming(C.Structure):

@@ -59,7 +59,7 @@ class RayPass:
 
     def __init__(self, cfg: BhrayConfig, device=0, counters=False, timing=False, row_rank=0, row_world=1, stripe_rows=27,
                  frames_in_flight=0, speculative_levels=0, frames_per_batch=0, devices=None, gather_root=0, comm_id=None,
-                 literal=False):
+                 literal=False, superset_levels=0):
         cfg = BhrayConfig.from_buffer_copy(bytes(cfg))
         cfg.struct_size = C.sizeof(BhrayConfig)
         cfg.device = device
@@ -77,6 +77,7 @@ class RayPass:
         cfg.frames_in_flight = frames_in_flight
         cfg.speculative_levels = speculative_levels
         cfg.frames_per_batch = frames_per_batch
+        cfg.superset_levels = superset_levels
         self.cfg = cfg
         h = C.c_void_p()
         check(lib().bhray_create(C.byref(cfg), C.byref(h)))
@@ -198,6 +199,12 @@ class RayPass:
         c = BhrayCounters()
         check(lib().bhray_get_counters(self._h, C.byref(c)), self._h)
         return c.as_dict()
+
+    def scheduling_counters(self) -> dict:
+        """wave steps, rays adopted through the drain-merging mailbox, lane occupancy of the step loop (needs counters=True)"""
+        c = BhrayCounters()
+        check(lib().bhray_get_counters(self._h, C.byref(c)), self._h)
+        return c.scheduling()
 
     def level_counters(self, level: int) -> dict:
         c = BhrayCounters()

@@ -167,6 +167,14 @@ enum {                                  /* bhray_config.flags */
  * launches, more rays traced (bhray_counters then count the speculative work).  Meant for small per-GPU frames
  * (row-tiled multi-GPU); off by default.
  *
+ * Superset speculation.  speculative_levels shortens the chain at its coarse end by tracing everything; at the fine end
+ * that would trace 6x too many rays.  With superset_levels = U the last U levels are first classified TENTATIVELY in order - a
+ * pixel whose coarser inputs are known is classified exactly, a pixel with an input that is itself queued is queued
+ * conservatively - then traced in ONE launch, then classified again exactly (copy / interpolate stored, traced pixels kept).
+ * The queued set contains every pixel the shader would trace, so the frame is unchanged; the surplus (conservatively queued
+ * pixels that turn out to interpolate) is a few per cent of the rays.  One dependent trace launch instead of U: meant for one
+ * frame at a time (an interactive host) and small per-GPU frames.  speculative_levels + superset_levels < levels.
+ *
  * Frame batches.  With frames_per_batch = B > 1, bhray_render only STAGES a frame (uniforms, output binding); the
  * launches are enqueued once B frames are staged (or bhray_flush / any call that waits for or reads a frame is made),
  * and every launch then covers the B frames: B times fewer dependent launches per frame and B times more rays per
@@ -209,6 +217,7 @@ typedef struct bhray_config {
     uint32_t frames_in_flight;          /* 0 = default (4); 1 = strictly one frame at a time  */
     uint32_t speculative_levels;        /* 0 = off; S>=2: trace EVERY needed pixel of levels 0..S-1 in one launch   */
     uint32_t frames_per_batch;          /* 0/1 = every bhray_render launches; B>1: launches cover B staged frames  */
+    uint32_t superset_levels;           /* 0 = off; U>=2: the LAST U levels are traced in one launch over a conservative superset    */
     uint32_t device_count;              /* 0: one GPU, `device`; N: devices[0..N) (N >= 2: single-process multi-GPU) */
     int32_t  devices[BHRAY_MAX_DEVICES];
     uint32_t gather;                    /* BHRAY_GATHER_*: one process per GPU only (see above)                      */
@@ -347,6 +356,12 @@ typedef struct bhray_counters {        /* summed over all levels of the last ren
     uint64_t triangles;                /* hit_triangle calls                                 */
     uint64_t disk_hits;                /* accretion-disk shading events                      */
     uint64_t sky_samples;              /* in-kernel sky taps (ray.wgsl:587)                  */
+    /* scheduling of the trace kernel (not a property of the frame: depends on frames in flight, batches, the kernel build)   */
+    uint64_t wave_steps;               /* integrator steps issued by waves: `steps` / (64 * wave_steps) = fraction of the lanes
+                                          of a stepping wave that hold a live ray                                            */
+    uint64_t rays_adopted;             /* rays that changed wave through the drain-merging mailbox (dense build)             */
+    uint64_t max_ray_iterations;       /* iterations of the longest ray (a maximum, also over levels): the latency floor of a level
+                                          is its longest ray                                                                  */
 } bhray_counters;
 int bhray_get_counters(bhray_ctx* ctx, bhray_counters* out);   /* needs BHRAY_F_COUNTERS     */
 int bhray_get_level_counters(bhray_ctx* ctx, uint32_t level, bhray_counters* out);
