@@ -44,6 +44,12 @@ struct FrameRes {
     std::vector<float4*> spec_out;      // speculative mode: traced images of levels 1..S-1 (level 0 traces straight into level_out[0])
     uint32_t* spec_queue = nullptr;     // speculative mode: merged, level-tagged queue of levels 0..S-1
     uint32_t* super_queue = nullptr;    // superset speculation: merged, level-tagged queue of the last U levels
+    // temporal speculation (BHRAY_F_TEMPORAL): the pixels the previous frame held here had to trace, all levels, level-tagged
+    uint32_t* pred[2] = {nullptr, nullptr};   // [pred_cur] is consumed by this frame's predicted launch, the other one is filled for the next
+    uint32_t* pred_ctl = nullptr;       // [2 * buf + 0] entries, [2 * buf + 1] entries taken
+    std::vector<uint32_t*> stamp;       // per level: stamp[y * w + x] == stamp_value <=> the predicted launch traced that pixel this frame
+    uint32_t stamp_value = 0;
+    int pred_cur = 0;
     uint32_t* d_qctl = nullptr;         // [2*BHRAY_MAX_LEVELS]: qcount[l], qhead[l]   (a slice of Slot::d_qctl)
     Counters64* d_counters = nullptr;   // [BHRAY_MAX_LEVELS]                         (a slice of Slot::d_counters)
     float4* own_out = nullptr;
@@ -317,6 +323,9 @@ void dev_destroy(bhray_dev* c) {
             for (auto p : R.spec_out) if (p) (void)hipFree(p);
             if (R.spec_queue) (void)hipFree(R.spec_queue);
             if (R.super_queue) (void)hipFree(R.super_queue);
+            for (auto p : R.pred) if (p) (void)hipFree(p);
+            if (R.pred_ctl) (void)hipFree(R.pred_ctl);
+            for (auto p : R.stamp) if (p) (void)hipFree(p);
             if (R.own_out) (void)hipFree(R.own_out);
             if (R.sky_out) (void)hipFree(R.sky_out);
         }
@@ -359,6 +368,8 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
     if (cfg->superset_levels == 1 || cfg->superset_levels > BHRAY_MAX_SPEC_LEVELS ||
         (cfg->superset_levels && cfg->superset_levels + (cfg->speculative_levels ? cfg->speculative_levels : 1) > cfg->levels))
         return fail(nullptr, BHRAY_E_INVALID, "superset_levels must be 0 or 2..%d and leave at least one coarser level (beyond the speculative ones)", BHRAY_MAX_SPEC_LEVELS);
+    if ((cfg->flags & BHRAY_F_TEMPORAL) && (cfg->levels > BHRAY_MAX_SPEC_LEVELS || cfg->speculative_levels || cfg->superset_levels))
+        return fail(nullptr, BHRAY_E_INVALID, "BHRAY_F_TEMPORAL needs levels <= %d and no speculative / superset levels", BHRAY_MAX_SPEC_LEVELS);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(nullptr, BHRAY_E_NO_DEVICE, "no HIP device visible (libbhray has no CPU path)");
@@ -423,7 +434,7 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
         }
     }
     c->out_bytes = (opt.frame_rowmap ? (size_t)cfg->frame_h : c->local_rows.size()) * (size_t)cfg->frame_w * sizeof(float4);
-    const size_t nlaunch = 4 * (size_t)nl + 2;                            // upper bound of launches per batch
+    const size_t nlaunch = 4 * (size_t)nl + 3;                            // upper bound of launches per batch
     for (Slot& S : c->slots) {
         CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
         CHK(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
@@ -466,6 +477,20 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
                     }
                 }
                 if (cap) CHK(hipMalloc(&R.spec_queue, cap * sizeof(uint32_t)));
+            }
+            if (cfg->flags & BHRAY_F_TEMPORAL) {
+                size_t cap = 0;
+                R.stamp.assign(nl, nullptr);
+                for (uint32_t l = 0; l < nl; l++) {
+                    const Level& L = c->levels[l];
+                    cap += L.queue_cap;
+                    const size_t npix = (size_t)L.w * (size_t)L.h;
+                    CHK(hipMalloc(&R.stamp[l], npix * sizeof(uint32_t)));
+                    CHK(hipMemset(R.stamp[l], 0, npix * sizeof(uint32_t)));
+                }
+                for (int b = 0; b < 2; b++) if (cap) CHK(hipMalloc(&R.pred[b], cap * sizeof(uint32_t)));
+                CHK(hipMalloc(&R.pred_ctl, 4 * sizeof(uint32_t)));
+                CHK(hipMemset(R.pred_ctl, 0, 4 * sizeof(uint32_t)));
             }
             if (cfg->superset_levels) {
                 size_t cap = 0;
@@ -771,7 +796,54 @@ int launch_batch(bhray_dev* c) {
         }
         first_normal = ns;
     }
-    const uint32_t nu = c->cfg.superset_levels;
+    const bool temporal = (c->cfg.flags & BHRAY_F_TEMPORAL) != 0;
+    if (temporal && any_rows) {
+        // Temporal speculation: ONE launch traces, for every level, the pixels the previous frame held in this slot position had
+        // to trace (its exact classification recorded them); then the ladder runs as usual, except that a pixel that needs tracing
+        // and was delivered by the predicted launch (stamp) is not traced again.  With a perfect prediction the per-level trace
+        // launches find empty queues and the chain of dependent long rays collapses into one launch; with no prediction (first
+        // frame, scene cut) this is the plain ladder.  Pixels are identical in every case.
+        for (uint32_t k = 0; k < nb; k++) {
+            FrameRes& R = S.fr[k];
+            R.stamp_value++;
+            if (R.stamp_value == 0) R.stamp_value = 1;
+            const int cur = R.pred_cur, nxt = cur ^ 1;
+            HIPCHK(c, hipMemsetAsync(R.pred_ctl + 2 * cur + 1, 0, sizeof(uint32_t), st));        // entries taken
+            HIPCHK(c, hipMemsetAsync(R.pred_ctl + 2 * nxt, 0, 2 * sizeof(uint32_t), st));
+        }
+        {
+            FrameLaunch* h; const FrameLaunch* d; next_launch(h, d);
+            for (uint32_t k = 0; k < nb; k++) {
+                const FrameRes& R = S.fr[k];
+                level_params(R, 0, h[k].L);
+                h[k].SL.n = (int)nl;
+                for (uint32_t l = 0; l < nl; l++) {
+                    LevelParams Lp; level_params(R, l, Lp);
+                    SpecLevel& sl = h[k].SL.l[l];
+                    sl.w = Lp.w; sl.h = Lp.h; sl.out = Lp.out; sl.out_pitch = Lp.out_pitch; sl.out_x0 = Lp.out_x0; sl.rowmap = Lp.rowmap; sl.stamp = R.stamp[l];
+                }
+                h[k].queue = R.pred[R.pred_cur]; h[k].qctl = R.pred_ctl + 2 * R.pred_cur; h[k].counters = count ? R.d_counters : nullptr;
+                h[k].stamp_value = R.stamp_value; h[k].probe_empty = 1;
+            }
+            seq.push_back({1, d, grid, count, {0}, {}});
+        }
+        for (uint32_t l = 0; l < nl; l++) {
+            FrameLaunch* h; const FrameLaunch* d; next_launch(h, d);
+            for (uint32_t k = 0; k < nb; k++) {
+                const FrameRes& R = S.fr[k];
+                level_params(R, l, h[k].L);
+                h[k].L.pass = CLASSIFY_FIXUP; h[k].L.tag = (int)l;
+                h[k].queue = R.queue[l]; h[k].qctl = R.d_qctl + 2 * l; h[k].counters = count ? R.d_counters + l : nullptr;
+                h[k].pred_queue = R.pred[R.pred_cur ^ 1]; h[k].pred_ctl = R.pred_ctl + 2 * (R.pred_cur ^ 1);
+                h[k].stamp = R.stamp[l]; h[k].stamp_value = R.stamp_value; h[k].probe_empty = 1;
+            }
+            seq.push_back({0, d, classify_blocks(l), count, l == 0 ? std::vector<int>{} : std::vector<int>{(int)(3 * l)}, {(int)(3 * l + 1)}});
+            seq.push_back({1, d, grid, count, {}, {(int)(3 * l + 2)}});
+        }
+        for (uint32_t k = 0; k < nb; k++) S.fr[k].pred_cur ^= 1;
+        first_normal = nl;
+    }
+    const uint32_t nu = temporal ? 0 : c->cfg.superset_levels;
     const uint32_t u0 = nu ? nl - nu : nl;                     // first level of the superset group
     for (uint32_t l = first_normal; l < u0 && any_rows; l++) {
         FrameLaunch* h; const FrameLaunch* d; next_launch(h, d);

@@ -86,11 +86,16 @@ enum : int { CLASSIFY_NORMAL = 0,
              CLASSIFY_TENTATIVE = 1,
              // after the trace of the superset: the coarser level is final.  Copy / interpolate are stored (overwriting speculative
              // traces the exact classification does not want); a pixel that needs tracing is left as the trace launch wrote it.
-             CLASSIFY_KEEP = 2 };
+             CLASSIFY_KEEP = 2,
+             // temporal speculation: exact classification (the coarser level is final).  Copy / interpolate are stored; a pixel that
+             // needs tracing is recorded for the next frame's prediction and, unless this frame's predicted launch already traced it
+             // (stamp), queued for this level's own trace launch.
+             CLASSIFY_FIXUP = 3 };
 #define BHRAY_PENDING_ALPHA 2.0f   // alpha of a final pixel is exactly 0 or 1
 
 // Speculative tracing of several levels in one launch: per-level geometry and destination, selected by the entry's tag.
-struct SpecLevel { int w, h; float4* out; int out_pitch; int out_x0; const int32_t* rowmap; };   // rowmap/out_x0 as in LevelParams
+struct SpecLevel { int w, h; float4* out; int out_pitch; int out_x0; const int32_t* rowmap;    // rowmap/out_x0 as in LevelParams
+                   uint32_t* stamp; };   // temporal speculation: stamp[y*w + x] = FrameLaunch::stamp_value when the pixel is stored
 struct SpecLevels { int n; SpecLevel l[BHRAY_MAX_SPEC_LEVELS]; };   // n == 0: one level, described by LevelParams
 
 struct Counters64 { unsigned long long v[13]; };   // order = bhray_counters
@@ -103,6 +108,13 @@ struct FrameLaunch {
     uint32_t* queue;       // ray queue of this frame and level(s)
     uint32_t* qctl;        // [0] entries appended (classify), [1] entries taken (trace)
     Counters64* counters;  // nullptr unless BHRAY_F_COUNTERS
+    // temporal speculation (BHRAY_F_TEMPORAL): the exact classification records every pixel that needs tracing for the NEXT frame's
+    // predicted launch, and sends to this frame's queue only those the predicted launch has not traced already
+    uint32_t* pred_queue;  // level-tagged entries for the next frame (nullptr: off)
+    uint32_t* pred_ctl;    // [0] entries appended
+    const uint32_t* stamp; // this level's stamp image (classify); nullptr outside temporal mode
+    uint32_t stamp_value;  // stamp of the current frame
+    int probe_empty;       // trace: this launch is expected to find its queue (nearly) used up - look before the first atomic
 };
 
 // launchers (bhray_kernels.hip); Pb / Fb are device arrays of nb entries

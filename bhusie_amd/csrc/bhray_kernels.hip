@@ -533,6 +533,18 @@ __global__ __launch_bounds__(256) void classify_kernel(const FrameParams* __rest
             need_trace = false;
         }
     }
+    if (L.pass == CLASSIFY_FIXUP) {
+        // every pixel the shader traces goes into the prediction of the next frame ...
+        const unsigned long long mp = __ballot(need_trace);
+        if (mp) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(F.pred_ctl, (uint32_t)__popcll(mp));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (need_trace) F.pred_queue[base + lanes_below(mp)] = ((uint32_t)L.tag << 30) | ((uint32_t)y << 15) | (uint32_t)x;
+        }
+        // ... and into this frame's own queue only if the predicted launch has not delivered it
+        if (need_trace && F.stamp[(size_t)y * (size_t)L.w + (size_t)x] == F.stamp_value) need_trace = false;
+    }
     // wave-ballot compaction: one atomic per wave, lanes keep tile order
     const unsigned long long m = __ballot(need_trace);
     if (m) {
@@ -653,6 +665,12 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
     uint32_t* __restrict__ qhead = F.qctl + 1;
     Counters64* __restrict__ counters = F.counters;
     const uint32_t qcount = F.qctl[0];
+    // A queue that is (nearly) used up when this wave arrives is seen with a plain load, before any atomic: 4 096 waves hitting one
+    // word with failing atomics cost ~50 us per launch (11-13 ns each) - what an empty queue (a fix-up launch of the temporal mode)
+    // used to take.  Only here (a load in front of every refill doubles the refill's round trips: -6 % throughput, measured) and only
+    // in the latency build and in launches the host expects to be nearly empty (probe_empty): in the dense build even the untaken
+    // branch costs a saturated device 2 % (measured: 4 930 -> 4 835 Mrays/s).
+    if (!DENSE && F.probe_empty && __hip_atomic_load(qhead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= qcount) continue;
     const HotParams H = load_hot(P);
     const F3 bpos = H.bh;
     const float t_max = 1e5f, t_min = 1e-8f;
@@ -941,6 +959,12 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                         for (int q = 1; q < BHRAY_MAX_SPEC_LEVELS; q++) if (lv == q) { dst = SL.l[q].out; pitch = SL.l[q].out_pitch; x0 = SL.l[q].out_x0; rowmap = SL.l[q].rowmap; }
                         const int orow = rowmap ? rowmap[oy] : oy;
                         dst[(size_t)orow * (size_t)pitch + (size_t)(ox - x0)] = o;
+                        if (F.stamp_value != 0u) {                       // temporal speculation: this pixel of this level is done for this frame
+                            uint32_t* st = SL.l[0].stamp; int sw = SL.l[0].w;
+#pragma unroll
+                            for (int q = 1; q < BHRAY_MAX_SPEC_LEVELS; q++) if (lv == q) { st = SL.l[q].stamp; sw = SL.l[q].w; }
+                            st[(size_t)oy * (size_t)sw + (size_t)ox] = F.stamp_value;
+                        }
                     } else {
                         L.out[out_index(L, ox, oy)] = o;
                     }

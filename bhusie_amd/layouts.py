@@ -12,6 +12,7 @@ MODEL_UNIFORM_BYTES = 48234572
 F_COUNTERS = 1
 F_TIMING = 2
 F_LITERAL = 4
+F_TEMPORAL = 8
 TEX_TEMP_LUT, TEX_DISK, TEX_SKY = 0, 1, 2
 
 
