@@ -263,20 +263,55 @@ __device__ __forceinline__ bool hit_triangle(F3 pos, F3 dir, float t_min, float 
 //    bvh_lookup -> triangle -> point/normal index chain (ray.wgsl:333-343) from the traversal.
 // The reference stacks 19 whole nodes without an overflow check (ray.wgsl:292,327); here the stack holds the two
 // words per node and an overflow raises *err instead of corrupting memory.
+// LDS staging (north_star: "LDS-staged triangle/node tiles"), both optional at compile time and measured on the mesh workload
+// (profiles/r02_bvh_lds.md):
+//   BHRAY_BVH_LDS_TOP    the first N nodes of the breadth-first order - the levels every traversal starts with - are copied into
+//                        LDS once per block; a child pair inside that range is read with 4 ds_read_b128 (~64 cycles) instead of
+//                        a global load (L1/L2 hit: ~200 cycles).
+//   BHRAY_BVH_LDS_STACK  the first D entries of a lane's traversal stack live in LDS (entry k of lane t at [k * threads + t]:
+//                        conflict-free 8-byte accesses) instead of scratch, whose loads - a pop is on the critical path - go
+//                        through the vector memory pipeline; deeper entries fall back to scratch.
+#ifndef BHRAY_TRACE_THREADS
+#define BHRAY_TRACE_THREADS 256  // threads per persistent trace block (a multiple of 64; 64 / 128 / 512 measured slower: DESIGN.md §4)
+#endif
+#ifndef BHRAY_BVH_LDS_TOP
+#define BHRAY_BVH_LDS_TOP 0
+#endif
+#ifndef BHRAY_BVH_LDS_STACK
+#define BHRAY_BVH_LDS_STACK 0
+#endif
+struct BvhLds { const float4* nodes; int node_count; int2* stack; };     // stack: this lane's column (entry k at stack[k * BHRAY_TRACE_THREADS])
+
 template <bool COUNT>
-__device__ __noinline__ void trace_ray_model(const ModelDev& M, F3 pos, F3 dir, float t_min, float t_max,
+__device__ __noinline__ void trace_ray_model(const ModelDev& M, const BvhLds lds, F3 pos, F3 dir, float t_min, float t_max,
                                              Hit& closest, F3& normal_out, unsigned long long* cnt, int* err) {
     F3 mpos = ld3(M.pos);
     F3 inv = f3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
     closest.hit = false; closest.t = t_max; closest.color = f3(0, 0, 0); closest.opacity = 0.0f;
     normal_out = f3(0, 0, 0);
     int contents = __float_as_int(M.nodes[0].w), obj_count = __float_as_int(M.nodes[1].w);     // nodes[0], untested root (ray.wgsl:291)
-    int2 stack[BHRAY_BVH_STACK];
+    constexpr int LSTK = BHRAY_BVH_LDS_STACK;
+    int2 stack[BHRAY_BVH_STACK - LSTK];                          // entries beyond the LDS part
     int sp = 0;
+    auto push = [&](int2 v) {
+        if (LSTK > 0 && sp < LSTK) lds.stack[sp * BHRAY_TRACE_THREADS] = v; else stack[sp - LSTK] = v;
+        sp++;
+    };
+    auto pop = [&]() -> int2 {
+        --sp;
+        if (LSTK > 0 && sp < LSTK) return lds.stack[sp * BHRAY_TRACE_THREADS];
+        return stack[sp - LSTK];
+    };
     for (;;) {
         if (obj_count == 0) {
-            const float4* pair = M.nodes + 2 * (size_t)contents;
-            const float4 a_lo = pair[0], a_hi = pair[1], b_lo = pair[2], b_hi = pair[3];
+            float4 a_lo, a_hi, b_lo, b_hi;
+            if (BHRAY_BVH_LDS_TOP > 0 && contents + 1 < lds.node_count) {
+                const float4* pair = lds.nodes + 2 * contents;
+                a_lo = pair[0]; a_hi = pair[1]; b_lo = pair[2]; b_hi = pair[3];
+            } else {
+                const float4* pair = M.nodes + 2 * (size_t)contents;
+                a_lo = pair[0]; a_hi = pair[1]; b_lo = pair[2]; b_hi = pair[3];
+            }
             if (COUNT) cnt[6]++;
             float d1 = hit_aabb(pos, inv, a_lo, a_hi, mpos);
             float d2 = hit_aabb(pos, inv, b_lo, b_hi, mpos);
@@ -285,11 +320,11 @@ __device__ __noinline__ void trace_ray_model(const ModelDev& M, F3 pos, F3 dir, 
             if (d1 > d2) { float td = d1; d1 = d2; d2 = td; int2 tn = n1; n1 = n2; n2 = tn; }
             if (d1 > closest.t) {
                 if (sp == 0) break;
-                --sp; contents = stack[sp].x; obj_count = stack[sp].y;
+                const int2 e = pop(); contents = e.x; obj_count = e.y;
             } else {
                 contents = n1.x; obj_count = n1.y;
                 if (d2 < closest.t) {
-                    if (sp < BHRAY_BVH_STACK) stack[sp++] = n2; else *err = BHRAY_E_BVH_DEPTH;
+                    if (sp < BHRAY_BVH_STACK) push(n2); else *err = BHRAY_E_BVH_DEPTH;
                 }
             }
         } else {
@@ -305,7 +340,7 @@ __device__ __noinline__ void trace_ray_model(const ModelDev& M, F3 pos, F3 dir, 
                 }
             }
             if (sp == 0) break;
-            --sp; contents = stack[sp].x; obj_count = stack[sp].y;
+            const int2 e = pop(); contents = e.x; obj_count = e.y;
         }
     }
 }
@@ -589,9 +624,6 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #ifndef BHRAY_TRACE_WAVES_DENSE
 #define BHRAY_TRACE_WAVES_DENSE 6
 #endif
-#ifndef BHRAY_TRACE_THREADS
-#define BHRAY_TRACE_THREADS 256  // threads per persistent trace block (a multiple of 64)
-#endif
 #ifndef BHRAY_MAILBOX_T
 #define BHRAY_MAILBOX_T 0        // drain merging (measured, off: DESIGN.md §4): a wave with this many live rays or fewer parks them; 0 disables
 #endif
@@ -634,6 +666,21 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
     int err = 0;
     constexpr bool COLD_LDS = DENSE && !MODELS;
     __shared__ float cold_lds[COLD_LDS ? 8 * BHRAY_TRACE_THREADS : 1];
+    // mesh variant: optional LDS staging of the top of the BVH and of the shallow part of the traversal stacks (trace_ray_model)
+    constexpr int BVH_TOP = MODELS ? BHRAY_BVH_LDS_TOP : 0;
+    // (dynamic LDS: with a static array the compiler assumes 64 KB of LDS per CU - gfx950 has 160 KB -, concludes that occupancy is
+    // LDS-limited and gives up the 64-VGPR budget of 8 waves per SIMD: 142-152 VGPRs, 3 waves)
+    extern __shared__ float4 bvh_dyn_lds[];
+    float4* bvh_top = bvh_dyn_lds;
+    int2* bvh_stack = reinterpret_cast<int2*>(bvh_dyn_lds + 2 * BVH_TOP);
+    BvhLds bvh_lds; bvh_lds.nodes = bvh_top; bvh_lds.node_count = 0; bvh_lds.stack = bvh_stack + threadIdx.x;
+    if (BVH_TOP > 0) {
+        const ModelDev& M0 = Pb[0].models[0];                      // one model per ctx (BHRAY_MAX_MODELS), constant over a batch
+        const int n = (Pb[0].model_count > 0 && M0.node_count > 0) ? (M0.node_count < BVH_TOP ? M0.node_count : BVH_TOP) : 0;
+        for (int i = threadIdx.x; i < 2 * n; i += BHRAY_TRACE_THREADS) bvh_top[i] = M0.nodes[i];
+        bvh_lds.node_count = n;
+        __syncthreads();
+    }
     // Drain merging (dense build).  Once a launch's queue has run dry its waves finish their rays at ever lower lane occupancy
     // (16 % of the lane-steps of a 1080p frame).  A wave left with <= MB_T live rays parks them - the whole per-ray state, 36 words -
     // in the block's LDS mailbox and exits; waves of the same block with empty lanes adopt parked rays at their next refill.  A ray is
@@ -893,7 +940,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                                         if (COUNT && skip) cnt[6]++;
                                     }
                                 }
-                                if (!skip) trace_ray_model<COUNT>(P.models[mi], cpos, cdir, t_min, t_max, r, nrm, cnt, &err);
+                                if (!skip) trace_ray_model<COUNT>(P.models[mi], bvh_lds, cpos, cdir, t_min, t_max, r, nrm, cnt, &err);
                                 if (r.hit && r.t < rs.t) {
                                     rs = r;
                                     const F3 light = normalize(f3(0.2f, 0.2f, -1.0f));
@@ -1144,8 +1191,9 @@ hipError_t launch_classify(const FrameParams* Pb, const FrameLaunch* Fb, int nb,
 
 template <int METHOD, bool MODELS, bool DENSE, bool LIT = false>
 static hipError_t launch_trace_t(const FrameParams* Pb, const FrameLaunch* Fb, int nb, bool count, int* err_flag, int grid_blocks, hipStream_t s) {
-    if (count) hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, true, DENSE, LIT>), dim3((grid_blocks * 256 + BHRAY_TRACE_THREADS - 1) / BHRAY_TRACE_THREADS), dim3(BHRAY_TRACE_THREADS), 0, s, Pb, Fb, nb, err_flag);
-    else hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, false, DENSE, LIT>), dim3((grid_blocks * 256 + BHRAY_TRACE_THREADS - 1) / BHRAY_TRACE_THREADS), dim3(BHRAY_TRACE_THREADS), 0, s, Pb, Fb, nb, err_flag);
+    constexpr size_t dyn_lds = MODELS ? (size_t)BHRAY_BVH_LDS_TOP * 32 + (size_t)BHRAY_BVH_LDS_STACK * BHRAY_TRACE_THREADS * 8 : 0;   // trace_ray_model's LDS
+    if (count) hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, true, DENSE, LIT>), dim3((grid_blocks * 256 + BHRAY_TRACE_THREADS - 1) / BHRAY_TRACE_THREADS), dim3(BHRAY_TRACE_THREADS), dyn_lds, s, Pb, Fb, nb, err_flag);
+    else hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, false, DENSE, LIT>), dim3((grid_blocks * 256 + BHRAY_TRACE_THREADS - 1) / BHRAY_TRACE_THREADS), dim3(BHRAY_TRACE_THREADS), dyn_lds, s, Pb, Fb, nb, err_flag);
     return hipGetLastError();
 }
 
@@ -1182,7 +1230,8 @@ int trace_blocks_per_cu(int method, int has_models, int count, int dense, int li
     else f = method == 0 ? (count ? PICK(0, false, true, false) : PICK(0, false, false, false)) : (count ? PICK(1, false, true, false) : PICK(1, false, false, false));
 #undef PICK
 #undef PICKL
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, BHRAY_TRACE_THREADS, 0) != hipSuccess || n < 1) n = 2;
+    const size_t dyn_lds = has_models ? (size_t)BHRAY_BVH_LDS_TOP * 32 + (size_t)BHRAY_BVH_LDS_STACK * BHRAY_TRACE_THREADS * 8 : 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, BHRAY_TRACE_THREADS, dyn_lds) != hipSuccess || n < 1) n = 2;
     n = n * BHRAY_TRACE_THREADS / 256;            // in units of 256 threads (the grid is sized in those)
     return n < 1 ? 1 : n;
 }
