@@ -244,6 +244,7 @@ int group_gather(bhray_ctx* c, int si, uint32_t nb) {
         if (c->table_rows) {
             FramePtrs fp; memset(&fp, 0, sizeof fp);
             for (uint32_t k = 0; k < nb; k++) fp.p[k] = G.dst[k];
+            (void)hipGetLastError();          // a stale error of an unrelated earlier call must not be blamed on this launch
             hipLaunchKernelGGL(deinterleave_kernel, dim3(c->table_rows, nb), dim3(256), 0, rr->stream, G.staging, fp, c->d_table, (int)W);
             GHIP(c, hipGetLastError());
         }
@@ -428,15 +429,19 @@ int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
         Part& p = c->parts[q];
         p.rows = part_rows(cfg->frame_h, c->world, stripe, q);
         if (multi_dev) {
+            if (cfg->devices[q] < 0 || cfg->devices[q] >= ndev) FAIL(BHRAY_E_NO_DEVICE, "device %d not present (%d visible)", cfg->devices[q], ndev);
             p.device = cfg->devices[q];
-            if (p.device < 0 || p.device >= ndev) FAIL(BHRAY_E_NO_DEVICE, "device %d not present (%d visible)", p.device, ndev);
             int r = -1;
             for (size_t k = 0; k < rank_dev.size(); k++) if (rank_dev[k] == p.device) r = (int)k;
             if (r < 0) { r = (int)rank_dev.size(); rank_dev.push_back(p.device); }
             p.rank = r;
         } else {
             p.rank = (int)q;
-            if (q == cfg->row_rank) { p.device = cfg->device_count == 1 ? cfg->devices[0] : cfg->device; if (p.device < 0 || p.device >= ndev) FAIL(BHRAY_E_NO_DEVICE, "device %d not present (%d visible)", p.device, ndev); }
+            if (q == cfg->row_rank) {
+                const int d = cfg->device_count == 1 ? cfg->devices[0] : cfg->device;
+                if (d < 0 || d >= ndev) FAIL(BHRAY_E_NO_DEVICE, "device %d not present (%d visible)", d, ndev);
+                p.device = d;
+            }
         }
     }
     c->comm_size = multi_dev ? (uint32_t)rank_dev.size() : c->world;

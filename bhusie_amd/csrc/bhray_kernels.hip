@@ -1128,8 +1128,11 @@ __global__ __launch_bounds__(256) void sky_kernel(const TexDev sky, const float4
     dst[i] = make_uint2(lo, hi);
 }
 
+// Launchers report the error of THEIR launch: HIP's last-error state is sticky across unrelated calls of the process (e.g. a
+// refused hipSetDevice of another ctx), so it is cleared first.
 hipError_t launch_sky(const TexDev& sky, const float4* src, uint2* dst, size_t npix, hipStream_t s) {
     if (npix == 0) return hipSuccess;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(sky_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, sky, src, dst, npix);
     return hipGetLastError();
 }
@@ -1160,6 +1163,7 @@ __global__ __launch_bounds__(256) void selftest_kernel(unsigned long long* __res
 }
 
 hipError_t launch_selftest(unsigned long long* bad2, hipStream_t s) {
+    (void)hipGetLastError();
     hipLaunchKernelGGL(selftest_kernel, dim3(8192), dim3(256), 0, s, bad2);
     return hipGetLastError();
 }
@@ -1175,6 +1179,7 @@ __global__ __launch_bounds__(256) void upload_kernel(const uint4* __restrict__ s
 hipError_t launch_upload(const void* pinned_src, void* dst, size_t n16, uint32_t* zero, size_t nzero, hipStream_t s) {
     const size_t n = n16 > nzero ? n16 : nzero;
     if (n == 0) return hipSuccess;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(upload_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)pinned_src, (uint4*)dst, n16, zero, nzero);
     return hipGetLastError();
 }
@@ -1184,6 +1189,7 @@ hipError_t launch_upload(const void* pinned_src, void* dst, size_t n16, uint32_t
 // ------------------------------------------------------------------------------------------
 hipError_t launch_classify(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int blocks, bool count, hipStream_t s) {
     if (blocks <= 0 || nb <= 0) return hipSuccess;
+    (void)hipGetLastError();
     if (count) hipLaunchKernelGGL(classify_kernel<true>, dim3(blocks, nb), dim3(256), 0, s, Pb, Fb);
     else hipLaunchKernelGGL(classify_kernel<false>, dim3(blocks, nb), dim3(256), 0, s, Pb, Fb);
     return hipGetLastError();
@@ -1191,6 +1197,7 @@ hipError_t launch_classify(const FrameParams* Pb, const FrameLaunch* Fb, int nb,
 
 template <int METHOD, bool MODELS, bool DENSE, bool LIT = false>
 static hipError_t launch_trace_t(const FrameParams* Pb, const FrameLaunch* Fb, int nb, bool count, int* err_flag, int grid_blocks, hipStream_t s) {
+    (void)hipGetLastError();
     constexpr size_t dyn_lds = MODELS ? (size_t)BHRAY_BVH_LDS_TOP * 32 + (size_t)BHRAY_BVH_LDS_STACK * BHRAY_TRACE_THREADS * 8 : 0;   // trace_ray_model's LDS
     if (count) hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, true, DENSE, LIT>), dim3((grid_blocks * 256 + BHRAY_TRACE_THREADS - 1) / BHRAY_TRACE_THREADS), dim3(BHRAY_TRACE_THREADS), dyn_lds, s, Pb, Fb, nb, err_flag);
     else hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, false, DENSE, LIT>), dim3((grid_blocks * 256 + BHRAY_TRACE_THREADS - 1) / BHRAY_TRACE_THREADS), dim3(BHRAY_TRACE_THREADS), dyn_lds, s, Pb, Fb, nb, err_flag);
