@@ -140,7 +140,7 @@ typedef struct bhray_model_desc {
 #define BHRAY_MAX_LEVELS 8
 #define BHRAY_MAX_FRAMES_IN_FLIGHT 32
 #define BHRAY_MAX_SPEC_LEVELS 4
-#define BHRAY_MAX_FRAMES_PER_BATCH 16
+#define BHRAY_MAX_FRAMES_PER_BATCH 32
 #define BHRAY_BVH_STACK  64            /* reference: 19 whole nodes, no overflow check (ray.wgsl:292) */
 #define BHRAY_MAX_DEVICES 16           /* GPUs one ctx can drive (one node: 8 MI355X)                 */
 #define BHRAY_COMM_ID_BYTES 128        /* an RCCL ncclUniqueId                                         */
