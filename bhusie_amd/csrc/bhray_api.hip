@@ -45,11 +45,12 @@ struct FrameRes {
     uint32_t* spec_queue = nullptr;     // speculative mode: merged, level-tagged queue of levels 0..S-1
     uint32_t* super_queue = nullptr;    // superset speculation: merged, level-tagged queue of the last U levels
     // temporal speculation (BHRAY_F_TEMPORAL): the pixels the previous frame held here had to trace, all levels, level-tagged
-    uint32_t* pred[2] = {nullptr, nullptr};   // [pred_cur] is consumed by this frame's predicted launch, the other one is filled for the next
-    uint32_t* pred_ctl = nullptr;       // [2 * buf + 0] entries, [2 * buf + 1] entries taken
+    uint32_t* pred_queue = nullptr;     // the predicted launch's queue: built by predict_kernel from the previous frame's marks
+    uint32_t* pred_ctl = nullptr;       // [0] entries [1] entries taken
+    std::vector<uint8_t*> need;         // per level: need[y * w + x] = the last exact classification had to trace that pixel
     std::vector<uint32_t*> stamp;       // per level: stamp[y * w + x] == stamp_value <=> the predicted launch traced that pixel this frame
     uint32_t stamp_value = 0;
-    int pred_cur = 0;
+
     uint32_t* d_qctl = nullptr;         // [2*BHRAY_MAX_LEVELS]: qcount[l], qhead[l]   (a slice of Slot::d_qctl)
     Counters64* d_counters = nullptr;   // [BHRAY_MAX_LEVELS]                         (a slice of Slot::d_counters)
     float4* own_out = nullptr;
@@ -118,6 +119,8 @@ struct bhray_dev {
     uint8_t ring_frames[BHRAY_TIMING_RING] = {0};   // frames of the batch held by each timing-ring entry
     int* d_err = nullptr;
     int num_cus = 256;
+    uint32_t temporal_radius = 0;          // BHRAY_F_TEMPORAL: dilation of the previous frame's traced set in pixels (BHRAY_TEMPORAL_RADIUS; measured: a
+                                           // radius of 1-2 adds 2-4 % rays and does not shorten a moving camera's frames - the misses are scattered interpolate/trace flips)
     int bpc_override = 0;                  // BHRAY_TRACE_BLOCKS_PER_CU (tuning experiments only)
     int grid_override = 0;                 // BHRAY_TRACE_GRID: absolute number of persistent trace blocks (tuning experiments only)
     int dense_override = -1;               // BHRAY_TRACE_DENSE=0/1 (tuning experiments only)
@@ -323,7 +326,8 @@ void dev_destroy(bhray_dev* c) {
             for (auto p : R.spec_out) if (p) (void)hipFree(p);
             if (R.spec_queue) (void)hipFree(R.spec_queue);
             if (R.super_queue) (void)hipFree(R.super_queue);
-            for (auto p : R.pred) if (p) (void)hipFree(p);
+            if (R.pred_queue) (void)hipFree(R.pred_queue);
+            for (auto p : R.need) if (p) (void)hipFree(p);
             if (R.pred_ctl) (void)hipFree(R.pred_ctl);
             for (auto p : R.stamp) if (p) (void)hipFree(p);
             if (R.own_out) (void)hipFree(R.own_out);
@@ -395,6 +399,7 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = getenv("BHRAY_TRACE_BLOCKS_PER_CU")) c->bpc_override = atoi(e);
     if (const char* e = getenv("BHRAY_TRACE_GRID")) c->grid_override = atoi(e);
+    if (const char* e = getenv("BHRAY_TEMPORAL_RADIUS")) { const int r = atoi(e); c->temporal_radius = r < 0 ? 0 : (r > 4 ? 4 : (uint32_t)r); }
     if (const char* e = getenv("BHRAY_TRACE_DENSE")) c->dense_override = atoi(e) != 0;
     const uint32_t nslots = cfg->frames_in_flight ? cfg->frames_in_flight : 4;
     c->cfg.frames_in_flight = nslots;
@@ -434,7 +439,7 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
         }
     }
     c->out_bytes = (opt.frame_rowmap ? (size_t)cfg->frame_h : c->local_rows.size()) * (size_t)cfg->frame_w * sizeof(float4);
-    const size_t nlaunch = 4 * (size_t)nl + 3;                            // upper bound of launches per batch
+    const size_t nlaunch = 5 * (size_t)nl + 3;                            // upper bound of launches per batch
     for (Slot& S : c->slots) {
         CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
         CHK(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
@@ -480,17 +485,19 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
             }
             if (cfg->flags & BHRAY_F_TEMPORAL) {
                 size_t cap = 0;
-                R.stamp.assign(nl, nullptr);
+                R.stamp.assign(nl, nullptr); R.need.assign(nl, nullptr);
                 for (uint32_t l = 0; l < nl; l++) {
                     const Level& L = c->levels[l];
                     cap += L.queue_cap;
                     const size_t npix = (size_t)L.w * (size_t)L.h;
                     CHK(hipMalloc(&R.stamp[l], npix * sizeof(uint32_t)));
                     CHK(hipMemset(R.stamp[l], 0, npix * sizeof(uint32_t)));
+                    CHK(hipMalloc(&R.need[l], npix));
+                    CHK(hipMemset(R.need[l], 0, npix));
                 }
-                for (int b = 0; b < 2; b++) if (cap) CHK(hipMalloc(&R.pred[b], cap * sizeof(uint32_t)));
-                CHK(hipMalloc(&R.pred_ctl, 4 * sizeof(uint32_t)));
-                CHK(hipMemset(R.pred_ctl, 0, 4 * sizeof(uint32_t)));
+                if (cap) CHK(hipMalloc(&R.pred_queue, cap * sizeof(uint32_t)));
+                CHK(hipMalloc(&R.pred_ctl, 2 * sizeof(uint32_t)));
+                CHK(hipMemset(R.pred_ctl, 0, 2 * sizeof(uint32_t)));
             }
             if (cfg->superset_levels) {
                 size_t cap = 0;
@@ -710,7 +717,7 @@ int launch_batch(bhray_dev* c) {
         args_used += (size_t)nb * sizeof(FrameLaunch);
         memset(h, 0, (size_t)nb * sizeof(FrameLaunch));
     };
-    struct Launch { int kind; const FrameLaunch* d; int blocks; bool count; std::vector<int> ev_before, ev_after; };   // kind 0 classify, 1 trace; timing events recorded around it
+    struct Launch { int kind; const FrameLaunch* d; int blocks; bool count; std::vector<int> ev_before, ev_after; int build = -1; };   // kind 0 classify, 1 trace; timing events recorded around it; build: -1 the ctx's trace build, 0 latency, 1 dense
     std::vector<Launch> seq;
     // Persistent trace grid: (resident blocks per CU) x CUs.  With several batches in flight each launch takes only
     // half of the block slots: the kernels of the other batches fill the rest, and a wave of a half-size grid pulls
@@ -750,7 +757,7 @@ int launch_batch(bhray_dev* c) {
         const Level& Lv = c->levels[l];
         const int span = (l == nl - 1) ? (int)c->cfg.frame_w : Lv.w;
         const int tiles = ((span + 7) / 8) * (((int)Lv.rows.size() + 7) / 8);
-        return (tiles + 3) / 4;
+        return (tiles + BHRAY_CLASSIFY_TILES_PER_BLOCK - 1) / BHRAY_CLASSIFY_TILES_PER_BLOCK;
     };
     const uint32_t ns = c->cfg.speculative_levels;
     uint32_t first_normal = 0;
@@ -806,10 +813,22 @@ int launch_batch(bhray_dev* c) {
         for (uint32_t k = 0; k < nb; k++) {
             FrameRes& R = S.fr[k];
             R.stamp_value++;
-            if (R.stamp_value == 0) R.stamp_value = 1;
-            const int cur = R.pred_cur, nxt = cur ^ 1;
-            HIPCHK(c, hipMemsetAsync(R.pred_ctl + 2 * cur + 1, 0, sizeof(uint32_t), st));        // entries taken
-            HIPCHK(c, hipMemsetAsync(R.pred_ctl + 2 * nxt, 0, 2 * sizeof(uint32_t), st));
+            if (R.stamp_value == 0) {                          // 32-bit stamps wrapped: start over with clean images
+                for (uint32_t l = 0; l < nl; l++) HIPCHK(c, hipMemsetAsync(R.stamp[l], 0, (size_t)c->levels[l].w * (size_t)c->levels[l].h * sizeof(uint32_t), st));
+                R.stamp_value = 1;
+            }
+            HIPCHK(c, hipMemsetAsync(R.pred_ctl, 0, 2 * sizeof(uint32_t), st));
+        }
+        // (0) the prediction: per level, the previous frame's traced set dilated by temporal_radius pixels -> one level-tagged queue
+        for (uint32_t l = 0; l < nl; l++) {
+            FrameLaunch* h; const FrameLaunch* d; next_launch(h, d);
+            for (uint32_t k = 0; k < nb; k++) {
+                const FrameRes& R = S.fr[k];
+                level_params(R, l, h[k].L);
+                h[k].L.tag = (int)l;
+                h[k].queue = R.pred_queue; h[k].qctl = R.pred_ctl; h[k].need = R.need[l]; h[k].radius = (int)c->temporal_radius;
+            }
+            seq.push_back({2, d, classify_blocks(l), false, l == 0 ? std::vector<int>{0} : std::vector<int>{}, {}});
         }
         {
             FrameLaunch* h; const FrameLaunch* d; next_launch(h, d);
@@ -822,10 +841,12 @@ int launch_batch(bhray_dev* c) {
                     SpecLevel& sl = h[k].SL.l[l];
                     sl.w = Lp.w; sl.h = Lp.h; sl.out = Lp.out; sl.out_pitch = Lp.out_pitch; sl.out_x0 = Lp.out_x0; sl.rowmap = Lp.rowmap; sl.stamp = R.stamp[l];
                 }
-                h[k].queue = R.pred[R.pred_cur]; h[k].qctl = R.pred_ctl + 2 * R.pred_cur; h[k].counters = count ? R.d_counters : nullptr;
+                h[k].queue = R.pred_queue; h[k].qctl = R.pred_ctl; h[k].counters = count ? R.d_counters : nullptr;
                 h[k].stamp_value = R.stamp_value; h[k].probe_empty = 1;
             }
-            seq.push_back({1, d, grid, count, {0}, {}});
+            // the predicted launch holds a whole frame's rays: the dense build (0.61 against 0.66 ms at 1080p); the fix-up launches are
+            // expected to be nearly empty: the latency build, which looks at the queue head before its first atomic
+            seq.push_back({1, d, c->num_cus * trace_blocks_per_cu(S.method, S.models, count, 1, literal), count, {}, {}, 1});
         }
         for (uint32_t l = 0; l < nl; l++) {
             FrameLaunch* h; const FrameLaunch* d; next_launch(h, d);
@@ -834,13 +855,12 @@ int launch_batch(bhray_dev* c) {
                 level_params(R, l, h[k].L);
                 h[k].L.pass = CLASSIFY_FIXUP; h[k].L.tag = (int)l;
                 h[k].queue = R.queue[l]; h[k].qctl = R.d_qctl + 2 * l; h[k].counters = count ? R.d_counters + l : nullptr;
-                h[k].pred_queue = R.pred[R.pred_cur ^ 1]; h[k].pred_ctl = R.pred_ctl + 2 * (R.pred_cur ^ 1);
+                h[k].need = R.need[l];
                 h[k].stamp = R.stamp[l]; h[k].stamp_value = R.stamp_value; h[k].probe_empty = 1;
             }
             seq.push_back({0, d, classify_blocks(l), count, l == 0 ? std::vector<int>{} : std::vector<int>{(int)(3 * l)}, {(int)(3 * l + 1)}});
-            seq.push_back({1, d, grid, count, {}, {(int)(3 * l + 2)}});
+            seq.push_back({1, d, c->num_cus * trace_blocks_per_cu(S.method, S.models, count, 0, literal), count, {}, {(int)(3 * l + 2)}, 0});
         }
-        for (uint32_t k = 0; k < nb; k++) S.fr[k].pred_cur ^= 1;
         first_normal = nl;
     }
     const uint32_t nu = temporal ? 0 : c->cfg.superset_levels;
@@ -913,8 +933,9 @@ int launch_batch(bhray_dev* c) {
     if (timing) { c->sky_recorded[ring] = 0; c->ring_frames[ring] = (uint8_t)nb; }
     for (const Launch& Ln : seq) {
         if (timing) for (int e : Ln.ev_before) HIPCHK(c, hipEventRecord(fev[e], st));
-        if (Ln.kind == 0) HIPCHK(c, launch_classify(dP, Ln.d, (int)nb, Ln.blocks, Ln.count, st));
-        else HIPCHK(c, launch_trace(dP, Ln.d, (int)nb, S.method, S.models, Ln.count, dense, literal, c->d_err, Ln.blocks, st));
+        if (Ln.kind == 2) HIPCHK(c, launch_predict(dP, Ln.d, (int)nb, Ln.blocks, st));
+        else if (Ln.kind == 0) HIPCHK(c, launch_classify(dP, Ln.d, (int)nb, Ln.blocks, Ln.count, st));
+        else HIPCHK(c, launch_trace(dP, Ln.d, (int)nb, S.method, S.models, Ln.count, Ln.build < 0 ? dense : Ln.build != 0, literal, c->d_err, Ln.blocks, st));
         if (timing) for (int e : Ln.ev_after) HIPCHK(c, hipEventRecord(fev[e], st));
     }
     HIPCHK(c, hipEventRecord(S.done, st));

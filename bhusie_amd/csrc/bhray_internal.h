@@ -110,13 +110,14 @@ struct FrameLaunch {
     Counters64* counters;  // nullptr unless BHRAY_F_COUNTERS
     // temporal speculation (BHRAY_F_TEMPORAL): the exact classification records every pixel that needs tracing for the NEXT frame's
     // predicted launch, and sends to this frame's queue only those the predicted launch has not traced already
-    uint32_t* pred_queue;  // level-tagged entries for the next frame (nullptr: off)
-    uint32_t* pred_ctl;    // [0] entries appended
+    uint8_t* need;         // this level's per-pixel mark "the shader traces this pixel" (written by the exact classification, read by predict_kernel)
+    int radius;            // predict_kernel: dilation of the previous frame's traced set, in pixels of this level
     const uint32_t* stamp; // this level's stamp image (classify); nullptr outside temporal mode
     uint32_t stamp_value;  // stamp of the current frame
     int probe_empty;       // trace: this launch is expected to find its queue (nearly) used up - look before the first atomic
 };
 
+#define BHRAY_CLASSIFY_TILES_PER_BLOCK 16   // classify / predict: 8x8-pixel tiles (one wave each) per 1024-thread block
 // launchers (bhray_kernels.hip); Pb / Fb are device arrays of nb entries
 hipError_t launch_classify(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int blocks, bool count, hipStream_t s);
 hipError_t launch_trace(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int method, bool models, bool count, bool dense, bool literal, int* err_flag,
@@ -126,6 +127,7 @@ int trace_blocks_per_cu(int method, int has_models, int count, int dense, int li
 // between the launches of a stream costs a cross-engine handshake each time)
 // and zeroes `nzero` 32-bit words at `zero` (the queue control words of the batch) in the same launch
 hipError_t launch_upload(const void* pinned_src, void* dst, size_t n16, uint32_t* zero, size_t nzero, hipStream_t s);
+hipError_t launch_predict(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int blocks, hipStream_t s);   // temporal speculation: F.need -> F.queue
 hipError_t launch_selftest(unsigned long long* bad3, hipStream_t s);   // [0]: 1/x mismatches, [1]: sqrt mismatches, [2]: places where bh_acos increases
 hipError_t launch_sky(const TexDev& sky, const float4* src, uint2* dst_rgba16f, size_t npix, hipStream_t s);
 

@@ -483,6 +483,31 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+// Append to a work queue from a whole block with ONE atomic: every wave counts its entries (ballot), the counts are summed through
+// LDS, wave 0 reserves the block's range, every wave writes its entries at its offset.  An atomic on one word costs ~12 ns whoever
+// issues it, so one per wave made the classification of a 1080p level (32 k waves) an atomic-bound 75 us for 30 us of memory work.
+#define BHRAY_CLASSIFY_THREADS 1024
+#define BHRAY_CLASSIFY_TILES (BHRAY_CLASSIFY_THREADS / 64)          // 8x8-pixel tiles per block, one per wave
+__device__ __forceinline__ void block_append(bool want, uint32_t entry, uint32_t* __restrict__ queue, uint32_t* __restrict__ qcount, uint32_t* lds /* [TILES + 1] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(want);
+    const uint32_t n = (uint32_t)__popcll(m);
+    if (lane == 0) lds[wave] = n;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t v = lane < BHRAY_CLASSIFY_TILES ? lds[lane] : 0u, incl = v;
+#pragma unroll
+        for (int off = 1; off < BHRAY_CLASSIFY_TILES; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, off); if (lane >= off) incl += o; }
+        const uint32_t total = (uint32_t)__shfl((int)incl, BHRAY_CLASSIFY_TILES - 1);
+        uint32_t base = 0;
+        if (lane == 0 && total) base = atomicAdd(qcount, total);
+        base = (uint32_t)__shfl((int)base, 0);
+        if (lane < BHRAY_CLASSIFY_TILES) lds[lane] = base + incl - v;                 // this wave's first slot
+    }
+    __syncthreads();
+    if (want) queue[lds[wave] + lanes_below(m)] = entry;
+}
+
 // ------------------------------------------------------------------------------------------
 // classify: ray.wgsl:167-243
 // ------------------------------------------------------------------------------------------
@@ -507,18 +532,19 @@ __device__ __forceinline__ size_t out_index(const LevelParams& L, int x, int y) 
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(256) void classify_kernel(const FrameParams* __restrict__ Pb, const FrameLaunch* __restrict__ Fb) {
+__global__ __launch_bounds__(BHRAY_CLASSIFY_THREADS) void classify_kernel(const FrameParams* __restrict__ Pb, const FrameLaunch* __restrict__ Fb) {
+    __shared__ uint32_t append_lds[BHRAY_CLASSIFY_TILES + 1];
     const FrameParams& P = Pb[blockIdx.y];
     const FrameLaunch& F = Fb[blockIdx.y];
     const LevelParams& L = F.L;
     uint32_t* __restrict__ queue = F.queue;
     uint32_t* __restrict__ qcount = F.qctl;
     Counters64* __restrict__ counters = F.counters;
-    // one wave = one 8x8 tile; 4 tiles per block side by side in x
+    // one wave = one 8x8 tile; BHRAY_CLASSIFY_TILES tiles per block side by side in x
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int tiles_x = (L.x1 - L.x0 + 7) >> 3;
-    const int tile = blockIdx.x * 4 + wave;
+    const int tile = blockIdx.x * BHRAY_CLASSIFY_TILES + wave;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int x = L.x0 + tx * 8 + (lane & 7);
     const int j = ty * 8 + (lane >> 3);
@@ -569,25 +595,13 @@ __global__ __launch_bounds__(256) void classify_kernel(const FrameParams* __rest
         }
     }
     if (L.pass == CLASSIFY_FIXUP) {
-        // every pixel the shader traces goes into the prediction of the next frame ...
-        const unsigned long long mp = __ballot(need_trace);
-        if (mp) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(F.pred_ctl, (uint32_t)__popcll(mp));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (need_trace) F.pred_queue[base + lanes_below(mp)] = ((uint32_t)L.tag << 30) | ((uint32_t)y << 15) | (uint32_t)x;
-        }
-        // ... and into this frame's own queue only if the predicted launch has not delivered it
+        // temporal speculation: remember, per pixel, whether the shader traces it (the next frame's prediction is built from these
+        // marks, predict_kernel), and send to this frame's own queue only what the predicted launch has not delivered (stamp)
+        if (valid) F.need[(size_t)y * (size_t)L.w + (size_t)x] = need_trace ? 1 : 0;
         if (need_trace && F.stamp[(size_t)y * (size_t)L.w + (size_t)x] == F.stamp_value) need_trace = false;
     }
-    // wave-ballot compaction: one atomic per wave, lanes keep tile order
-    const unsigned long long m = __ballot(need_trace);
-    if (m) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(qcount, (uint32_t)__popcll(m));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (need_trace) queue[base + lanes_below(m)] = ((uint32_t)L.tag << 30) | ((uint32_t)y << 15) | (uint32_t)x;
-    }
+    // block-wide compaction: one atomic per block, waves and lanes keep tile order (a pass that queues nothing has no queue)
+    if (queue) block_append(need_trace, ((uint32_t)L.tag << 30) | ((uint32_t)y << 15) | (uint32_t)x, queue, qcount, append_lds);
     if (COUNT) {
         const unsigned long long mv = __ballot(valid), m0 = __ballot(kind == 0), m1 = __ballot(kind == 1);
         if (lane == 0) {
@@ -1168,6 +1182,48 @@ hipError_t launch_selftest(unsigned long long* bad2, hipStream_t s) {
     return hipGetLastError();
 }
 
+// temporal speculation: the prediction of a level = every pixel that is not a copy position and has, within `radius` pixels, a pixel
+// the previous frame's exact classification had to trace (F.need).  radius 0 is last frame's traced set itself; radius 1 also
+// covers the pixels that region boundaries reach when the camera moves by up to a pixel per frame at that level - those are the
+// long rays (photon ring, disk edge), and a single one of them missing costs a whole dependent launch.  Same tiling as classify.
+template <int DUMMY>
+__global__ __launch_bounds__(BHRAY_CLASSIFY_THREADS) void predict_kernel(const FrameParams* __restrict__ Pb, const FrameLaunch* __restrict__ Fb) {
+    __shared__ uint32_t append_lds[BHRAY_CLASSIFY_TILES + 1];
+    const FrameLaunch& F = Fb[blockIdx.y];
+    const LevelParams& L = F.L;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tiles_x = (L.x1 - L.x0 + 7) >> 3;
+    const int tile = blockIdx.x * BHRAY_CLASSIFY_TILES + wave;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int x = L.x0 + tx * 8 + (lane & 7);
+    const int j = ty * 8 + (lane >> 3);
+    const bool valid = (x < L.x1) && (j < L.nrows);
+    const int y = valid ? L.rows[j] : 0;
+    bool predict = false;
+    if (valid) {
+        bool copy = false;
+        if (!(L.pw == 1 && L.ph == 1)) {
+            const float ppx = (float)x * L.rx, ppy = (float)y * L.ry;
+            copy = fabsf(floorf(ppx) - ppx) < 0.001f && fabsf(floorf(ppy) - ppy) < 0.001f;      // ray.wgsl:193: copied, never traced
+        }
+        if (!copy) {
+            const int r = F.radius;
+            const int xa = x - r < 0 ? 0 : x - r, xb = x + r > L.w - 1 ? L.w - 1 : x + r;
+            const int ya = y - r < 0 ? 0 : y - r, yb = y + r > L.h - 1 ? L.h - 1 : y + r;
+            for (int yy = ya; yy <= yb && !predict; yy++)
+                for (int xx = xa; xx <= xb; xx++) if (F.need[(size_t)yy * (size_t)L.w + (size_t)xx]) { predict = true; break; }
+        }
+    }
+    (void)lane;
+    block_append(predict, ((uint32_t)L.tag << 30) | ((uint32_t)y << 15) | (uint32_t)x, F.queue, F.qctl, append_lds);
+}
+hipError_t launch_predict(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int blocks, hipStream_t s) {
+    if (blocks <= 0 || nb <= 0) return hipSuccess;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(predict_kernel<0>, dim3(blocks, nb), dim3(BHRAY_CLASSIFY_THREADS), 0, s, Pb, Fb);
+    return hipGetLastError();
+}
+
 // argument-block upload (pinned host memory -> HBM) + reset of the batch's queue control words, see launch_upload
 __global__ __launch_bounds__(256) void upload_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16,
                                                      uint32_t* __restrict__ zero, size_t nzero) {
@@ -1190,8 +1246,8 @@ hipError_t launch_upload(const void* pinned_src, void* dst, size_t n16, uint32_t
 hipError_t launch_classify(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int blocks, bool count, hipStream_t s) {
     if (blocks <= 0 || nb <= 0) return hipSuccess;
     (void)hipGetLastError();
-    if (count) hipLaunchKernelGGL(classify_kernel<true>, dim3(blocks, nb), dim3(256), 0, s, Pb, Fb);
-    else hipLaunchKernelGGL(classify_kernel<false>, dim3(blocks, nb), dim3(256), 0, s, Pb, Fb);
+    if (count) hipLaunchKernelGGL(classify_kernel<true>, dim3(blocks, nb), dim3(BHRAY_CLASSIFY_THREADS), 0, s, Pb, Fb);
+    else hipLaunchKernelGGL(classify_kernel<false>, dim3(blocks, nb), dim3(BHRAY_CLASSIFY_THREADS), 0, s, Pb, Fb);
     return hipGetLastError();
 }
 

@@ -11,14 +11,16 @@ template <int MODE>
 __global__ void k(float* out, long long* cyc, int steps, float x0) {
     const F3 bpos = f3(0.0f, 0.0f, 0.0f);
     F3 pos = f3(x0 + threadIdx.x * 0.01f, 2.5f, -19.0f), dir = normalize(f3(0.01f * threadIdx.x, 0.02f, 1.0f));
-    float h = 0.15f, dist = length(pos - bpos), closest = dist;
+    F3 q = pos - bpos;
+    float h = 0.15f, dist = length(q), closest = dist;
     int hits = 0;
     long long t0 = clock64();
     for (int i = 0; i < steps; i++) {
         const F3 ppos = pos;
-        next_ray_rk(bpos, pos, dir, h, dist);
+        next_ray_rk(q, pos, dir, h, dist);
+        q = pos - bpos;
         if (MODE >= 1) {
-            const float cd = distance(pos, bpos);
+            const float cd = sqrt_rn(fdot(q, q));
             dist = cd;
             if (cd < closest) closest = cd;
         } else {

@@ -396,7 +396,7 @@ def test_frame_batch_switches_kernel_variant_and_partition(tmp_path):
             rp.set_uniforms(*u); rp.render()
         assert np.array_equal(rp.read_hdr(), want[3][rp.local_rows()])
     with pytest.raises(B.BhrayError):
-        B.RayPass(cfg, device=0, frames_per_batch=17)
+        B.RayPass(cfg, device=0, frames_per_batch=33)                # BHRAY_MAX_FRAMES_PER_BATCH = 32
 
 
 def test_exact_math_selftest():

@@ -71,7 +71,7 @@ def test_temporal_counters_and_perfect_prediction():
         rp.render()
         c = rp.counters()
         assert (c["pixels"], c["copied"], c["interpolated"]) == (cr["pixels"], cr["copied"], cr["interpolated"])
-        assert c["traced"] == cr["traced"] and c["steps"] == cr["steps"], (i, c, cr)      # nothing traced twice, nothing missed
+        assert c["traced"] == cr["traced"] and c["steps"] == cr["steps"], (i, c, cr)      # nothing traced twice, nothing missed (radius 0)
     with pytest.raises(B.BhrayError):
         B.RayPass(cfg, temporal=True, speculative_levels=2)
     with pytest.raises(B.BhrayError):
