@@ -117,7 +117,9 @@ struct FrameLaunch {
     int probe_empty;       // trace: this launch is expected to find its queue (nearly) used up - look before the first atomic
 };
 
-#define BHRAY_CLASSIFY_TILES_PER_BLOCK 16   // classify / predict: 8x8-pixel tiles (one wave each) per 1024-thread block
+#ifndef BHRAY_CLASSIFY_TILES_PER_BLOCK
+#define BHRAY_CLASSIFY_TILES_PER_BLOCK 4    // classify / predict: 8x8-pixel tiles (one wave each) per block of 64 x this many threads (measured: 2 / 4 / 8 / 16 -> 5 260 / 5 300 / 5 280 / 4 890 Mrays/s)
+#endif
 // launchers (bhray_kernels.hip); Pb / Fb are device arrays of nb entries
 hipError_t launch_classify(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int blocks, bool count, hipStream_t s);
 hipError_t launch_trace(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int method, bool models, bool count, bool dense, bool literal, int* err_flag,

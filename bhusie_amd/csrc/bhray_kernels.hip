@@ -485,9 +485,11 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
 
 // Append to a work queue from a whole block with ONE atomic: every wave counts its entries (ballot), the counts are summed through
 // LDS, wave 0 reserves the block's range, every wave writes its entries at its offset.  An atomic on one word costs ~12 ns whoever
-// issues it, so one per wave made the classification of a 1080p level (32 k waves) an atomic-bound 75 us for 30 us of memory work.
-#define BHRAY_CLASSIFY_THREADS 1024
-#define BHRAY_CLASSIFY_TILES (BHRAY_CLASSIFY_THREADS / 64)          // 8x8-pixel tiles per block, one per wave
+// issues it, so one per wave made the classification of a 1080p level (32 k waves) an atomic-bound 75 us for 25 us of memory work -
+// and, with 16-20 frames in flight, held the whole device back: one atomic per 4 waves is worth +8 % frames per second (4 900 ->
+// 5 300 Mrays/s); 16 waves per block (1 024 threads) classify fastest alone but find no room beside the persistent trace waves.
+#define BHRAY_CLASSIFY_THREADS (64 * BHRAY_CLASSIFY_TILES_PER_BLOCK)
+#define BHRAY_CLASSIFY_TILES BHRAY_CLASSIFY_TILES_PER_BLOCK          // 8x8-pixel tiles per block, one per wave
 __device__ __forceinline__ void block_append(bool want, uint32_t entry, uint32_t* __restrict__ queue, uint32_t* __restrict__ qcount, uint32_t* lds /* [TILES + 1] */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long m = __ballot(want);
@@ -758,7 +760,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
         // ---- refill finished lanes from the queue (wave ballot + prefix popcount)
         {
             const unsigned long long need = __ballot(mode == M_EMPTY);
-            if (need != 0ull && !exhausted) {
+            if (need != 0ull && !exhausted) {      // (refilling only when >= 4 .. 32 lanes are empty - fewer atomics on the queue head - changes nothing: measured)
                 const uint32_t n = (uint32_t)__popcll(need);
                 uint32_t base = 0;
                 if (lane == (int)__builtin_ctzll(need)) base = atomicAdd(qhead, n);
