@@ -756,8 +756,8 @@ int launch_batch(bhray_dev* c) {
     auto classify_blocks = [&](uint32_t l) {
         const Level& Lv = c->levels[l];
         const int span = (l == nl - 1) ? (int)c->cfg.frame_w : Lv.w;
-        const int tiles = ((span + 7) / 8) * (((int)Lv.rows.size() + 7) / 8);
-        return (tiles + BHRAY_CLASSIFY_TILES_PER_BLOCK - 1) / BHRAY_CLASSIFY_TILES_PER_BLOCK;
+        const int tiles_x = (span + 7) / 8, tiles_y = ((int)Lv.rows.size() + 7) / 8;
+        return ((tiles_x + BHRAY_CLASSIFY_BX - 1) / BHRAY_CLASSIFY_BX) * ((tiles_y + BHRAY_CLASSIFY_BY - 1) / BHRAY_CLASSIFY_BY);
     };
     const uint32_t ns = c->cfg.speculative_levels;
     uint32_t first_normal = 0;

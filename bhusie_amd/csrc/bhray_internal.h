@@ -117,8 +117,12 @@ struct FrameLaunch {
     int probe_empty;       // trace: this launch is expected to find its queue (nearly) used up - look before the first atomic
 };
 
-#ifndef BHRAY_CLASSIFY_TILES_PER_BLOCK
-#define BHRAY_CLASSIFY_TILES_PER_BLOCK 4    // classify / predict: 8x8-pixel tiles (one wave each) per block of 64 x this many threads (measured: 2 / 4 / 8 / 16 -> 5 260 / 5 300 / 5 280 / 4 890 Mrays/s)
+// classify / predict: a 256-thread block covers a rectangle of BX x BY 8x8-pixel tiles (4 waves, BX*BY/4 tiles each in turn)
+#ifndef BHRAY_CLASSIFY_BX
+#define BHRAY_CLASSIFY_BX 4
+#endif
+#ifndef BHRAY_CLASSIFY_BY
+#define BHRAY_CLASSIFY_BY 2    // measured at 1080p RK, 20 slots: 4x1 5 315, 2x2 5 290, 4x2 5 406, 2x4 5 380, 4x4 5 360, 8x1 5 328, 8x2 5 345 Mrays/s
 #endif
 // launchers (bhray_kernels.hip); Pb / Fb are device arrays of nb entries
 hipError_t launch_classify(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int blocks, bool count, hipStream_t s);

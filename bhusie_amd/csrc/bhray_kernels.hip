@@ -488,13 +488,40 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
 // issues it, so one per wave made the classification of a 1080p level (32 k waves) an atomic-bound 75 us for 25 us of memory work -
 // and, with 16-20 frames in flight, held the whole device back: one atomic per 4 waves is worth +8 % frames per second (4 900 ->
 // 5 300 Mrays/s); 16 waves per block (1 024 threads) classify fastest alone but find no room beside the persistent trace waves.
-#define BHRAY_CLASSIFY_THREADS (64 * BHRAY_CLASSIFY_TILES_PER_BLOCK)
-#define BHRAY_CLASSIFY_TILES BHRAY_CLASSIFY_TILES_PER_BLOCK          // 8x8-pixel tiles per block, one per wave
-__device__ __forceinline__ void block_append(bool want, uint32_t entry, uint32_t* __restrict__ queue, uint32_t* __restrict__ qcount, uint32_t* lds /* [TILES + 1] */) {
+// Geometry of a classify / predict block: 4 waves, each handling BHRAY_CLASSIFY_TPW 8x8-pixel tiles one after the other; the
+// block's BX x BY tiles form a rectangle of the level, and their queue entries are appended together, tile after tile in row-major
+// order of the rectangle.  Rays that are neighbours in the frame are then neighbours in the queue over a 2-D neighbourhood, and a
+// trace wave (64 consecutive entries, refills of a few consecutive entries) holds rays of similar length that take the rare paths
+// at the same steps.
+#define BHRAY_CLASSIFY_WAVES 4
+#define BHRAY_CLASSIFY_THREADS (64 * BHRAY_CLASSIFY_WAVES)
+#define BHRAY_CLASSIFY_TILES (BHRAY_CLASSIFY_BX * BHRAY_CLASSIFY_BY)
+#define BHRAY_CLASSIFY_TPW (BHRAY_CLASSIFY_TILES / BHRAY_CLASSIFY_WAVES)
+static_assert(BHRAY_CLASSIFY_TILES % BHRAY_CLASSIFY_WAVES == 0 && BHRAY_CLASSIFY_TILES <= 64, "classify block geometry");
+// pixel of lane `lane` in the t-th tile of wave `wave` of block `block`: level column x, index j into L.rows; false outside the level's region
+__device__ __forceinline__ bool classify_pixel(const LevelParams& L, int block, int wave, int t, int lane, int& x, int& j) {
+    const int tiles_x = (L.x1 - L.x0 + 7) >> 3;
+    const int blocks_x = (tiles_x + BHRAY_CLASSIFY_BX - 1) / BHRAY_CLASSIFY_BX;
+    const int q = t * BHRAY_CLASSIFY_WAVES + wave;                       // tile of the block, row-major in its BX x BY rectangle
+    const int tx = (block % blocks_x) * BHRAY_CLASSIFY_BX + q % BHRAY_CLASSIFY_BX;
+    const int ty = (block / blocks_x) * BHRAY_CLASSIFY_BY + q / BHRAY_CLASSIFY_BX;
+    x = L.x0 + tx * 8 + (lane & 7);
+    j = ty * 8 + (lane >> 3);
+    return tx < tiles_x && x < L.x1 && j < L.nrows;
+}
+// Append the block's entries with ONE atomic: every wave counts the entries of each of its tiles (ballot), the counts are summed
+// through LDS, wave 0 reserves the block's range, every wave writes its entries at its tiles' offsets.  An atomic on one word
+// costs ~12 ns whoever issues it: one per wave made the classification of a 1080p level (32 k waves) an atomic-bound 75 us for 25 us
+// of memory work and, with 16-20 frames in flight, held the whole device back.
+__device__ __forceinline__ void block_append(const bool (&want)[BHRAY_CLASSIFY_TPW], const uint32_t (&entry)[BHRAY_CLASSIFY_TPW],
+                                             uint32_t* __restrict__ queue, uint32_t* __restrict__ qcount, uint32_t* lds /* [TILES] */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long m = __ballot(want);
-    const uint32_t n = (uint32_t)__popcll(m);
-    if (lane == 0) lds[wave] = n;
+    unsigned long long m[BHRAY_CLASSIFY_TPW];
+#pragma unroll
+    for (int t = 0; t < BHRAY_CLASSIFY_TPW; t++) {
+        m[t] = __ballot(want[t]);
+        if (lane == 0) lds[t * BHRAY_CLASSIFY_WAVES + wave] = (uint32_t)__popcll(m[t]);
+    }
     __syncthreads();
     if (wave == 0) {
         uint32_t v = lane < BHRAY_CLASSIFY_TILES ? lds[lane] : 0u, incl = v;
@@ -504,10 +531,12 @@ __device__ __forceinline__ void block_append(bool want, uint32_t entry, uint32_t
         uint32_t base = 0;
         if (lane == 0 && total) base = atomicAdd(qcount, total);
         base = (uint32_t)__shfl((int)base, 0);
-        if (lane < BHRAY_CLASSIFY_TILES) lds[lane] = base + incl - v;                 // this wave's first slot
+        if (lane < BHRAY_CLASSIFY_TILES) lds[lane] = base + incl - v;                 // first slot of tile `lane`
     }
     __syncthreads();
-    if (want) queue[lds[wave] + lanes_below(m)] = entry;
+#pragma unroll
+    for (int t = 0; t < BHRAY_CLASSIFY_TPW; t++)
+        if (want[t]) queue[lds[t * BHRAY_CLASSIFY_WAVES + wave] + lanes_below(m[t])] = entry[t];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -535,22 +564,23 @@ __device__ __forceinline__ size_t out_index(const LevelParams& L, int x, int y) 
 
 template <bool COUNT>
 __global__ __launch_bounds__(BHRAY_CLASSIFY_THREADS) void classify_kernel(const FrameParams* __restrict__ Pb, const FrameLaunch* __restrict__ Fb) {
-    __shared__ uint32_t append_lds[BHRAY_CLASSIFY_TILES + 1];
+    __shared__ uint32_t append_lds[BHRAY_CLASSIFY_TILES];
     const FrameParams& P = Pb[blockIdx.y];
     const FrameLaunch& F = Fb[blockIdx.y];
     const LevelParams& L = F.L;
     uint32_t* __restrict__ queue = F.queue;
     uint32_t* __restrict__ qcount = F.qctl;
     Counters64* __restrict__ counters = F.counters;
-    // one wave = one 8x8 tile; BHRAY_CLASSIFY_TILES tiles per block side by side in x
+    // one wave = one 8x8 tile at a time, BHRAY_CLASSIFY_TPW tiles per wave (classify_pixel)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int tiles_x = (L.x1 - L.x0 + 7) >> 3;
-    const int tile = blockIdx.x * BHRAY_CLASSIFY_TILES + wave;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int x = L.x0 + tx * 8 + (lane & 7);
-    const int j = ty * 8 + (lane >> 3);
-    const bool valid = (x < L.x1) && (j < L.nrows);
+    bool want[BHRAY_CLASSIFY_TPW];
+    uint32_t entry[BHRAY_CLASSIFY_TPW];
+    unsigned long long cnt_valid = 0, cnt_copy = 0, cnt_interp = 0;
+#pragma unroll
+    for (int t = 0; t < BHRAY_CLASSIFY_TPW; t++) {
+    int x, j;
+    const bool valid = classify_pixel(L, (int)blockIdx.x, wave, t, lane, x, j);
     const int y = valid ? L.rows[j] : 0;
     bool need_trace = false;
     int kind = -1;                                   // 0 copy, 1 interpolate, 2 trace
@@ -602,17 +632,19 @@ __global__ __launch_bounds__(BHRAY_CLASSIFY_THREADS) void classify_kernel(const 
         if (valid) F.need[(size_t)y * (size_t)L.w + (size_t)x] = need_trace ? 1 : 0;
         if (need_trace && F.stamp[(size_t)y * (size_t)L.w + (size_t)x] == F.stamp_value) need_trace = false;
     }
-    // block-wide compaction: one atomic per block, waves and lanes keep tile order (a pass that queues nothing has no queue)
-    if (queue) block_append(need_trace, ((uint32_t)L.tag << 30) | ((uint32_t)y << 15) | (uint32_t)x, queue, qcount, append_lds);
-    if (COUNT) {
-        const unsigned long long mv = __ballot(valid), m0 = __ballot(kind == 0), m1 = __ballot(kind == 1);
-        if (lane == 0) {
-            atomicAdd(&counters->v[0], (unsigned long long)__popcll(mv));
-            atomicAdd(&counters->v[1], (unsigned long long)__popcll(m0));
-            atomicAdd(&counters->v[2], (unsigned long long)__popcll(m1));
-        }
+    want[t] = need_trace;
+    entry[t] = ((uint32_t)L.tag << 30) | ((uint32_t)y << 15) | (uint32_t)x;
+    if (COUNT) { cnt_valid += __popcll(__ballot(valid)); cnt_copy += __popcll(__ballot(kind == 0)); cnt_interp += __popcll(__ballot(kind == 1)); }
+    }   // tiles of this wave
+    // block-wide compaction: one atomic per block, tiles, waves and lanes keep their order (a pass that queues nothing has no queue)
+    if (queue) block_append(want, entry, queue, qcount, append_lds);
+    if (COUNT && lane == 0) {
+        atomicAdd(&counters->v[0], cnt_valid);
+        atomicAdd(&counters->v[1], cnt_copy);
+        atomicAdd(&counters->v[2], cnt_interp);
     }
 }
+
 
 // ------------------------------------------------------------------------------------------
 // trace: ray.wgsl:269-285 + 482-596
@@ -1190,34 +1222,36 @@ hipError_t launch_selftest(unsigned long long* bad2, hipStream_t s) {
 // long rays (photon ring, disk edge), and a single one of them missing costs a whole dependent launch.  Same tiling as classify.
 template <int DUMMY>
 __global__ __launch_bounds__(BHRAY_CLASSIFY_THREADS) void predict_kernel(const FrameParams* __restrict__ Pb, const FrameLaunch* __restrict__ Fb) {
-    __shared__ uint32_t append_lds[BHRAY_CLASSIFY_TILES + 1];
+    __shared__ uint32_t append_lds[BHRAY_CLASSIFY_TILES];
     const FrameLaunch& F = Fb[blockIdx.y];
     const LevelParams& L = F.L;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tiles_x = (L.x1 - L.x0 + 7) >> 3;
-    const int tile = blockIdx.x * BHRAY_CLASSIFY_TILES + wave;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int x = L.x0 + tx * 8 + (lane & 7);
-    const int j = ty * 8 + (lane >> 3);
-    const bool valid = (x < L.x1) && (j < L.nrows);
-    const int y = valid ? L.rows[j] : 0;
-    bool predict = false;
-    if (valid) {
-        bool copy = false;
-        if (!(L.pw == 1 && L.ph == 1)) {
-            const float ppx = (float)x * L.rx, ppy = (float)y * L.ry;
-            copy = fabsf(floorf(ppx) - ppx) < 0.001f && fabsf(floorf(ppy) - ppy) < 0.001f;      // ray.wgsl:193: copied, never traced
+    bool want[BHRAY_CLASSIFY_TPW];
+    uint32_t entry[BHRAY_CLASSIFY_TPW];
+#pragma unroll
+    for (int t = 0; t < BHRAY_CLASSIFY_TPW; t++) {
+        int x, j;
+        const bool valid = classify_pixel(L, (int)blockIdx.x, wave, t, lane, x, j);
+        const int y = valid ? L.rows[j] : 0;
+        bool predict = false;
+        if (valid) {
+            bool copy = false;
+            if (!(L.pw == 1 && L.ph == 1)) {
+                const float ppx = (float)x * L.rx, ppy = (float)y * L.ry;
+                copy = fabsf(floorf(ppx) - ppx) < 0.001f && fabsf(floorf(ppy) - ppy) < 0.001f;      // ray.wgsl:193: copied, never traced
+            }
+            if (!copy) {
+                const int r = F.radius;
+                const int xa = x - r < 0 ? 0 : x - r, xb = x + r > L.w - 1 ? L.w - 1 : x + r;
+                const int ya = y - r < 0 ? 0 : y - r, yb = y + r > L.h - 1 ? L.h - 1 : y + r;
+                for (int yy = ya; yy <= yb && !predict; yy++)
+                    for (int xx = xa; xx <= xb; xx++) if (F.need[(size_t)yy * (size_t)L.w + (size_t)xx]) { predict = true; break; }
+            }
         }
-        if (!copy) {
-            const int r = F.radius;
-            const int xa = x - r < 0 ? 0 : x - r, xb = x + r > L.w - 1 ? L.w - 1 : x + r;
-            const int ya = y - r < 0 ? 0 : y - r, yb = y + r > L.h - 1 ? L.h - 1 : y + r;
-            for (int yy = ya; yy <= yb && !predict; yy++)
-                for (int xx = xa; xx <= xb; xx++) if (F.need[(size_t)yy * (size_t)L.w + (size_t)xx]) { predict = true; break; }
-        }
+        want[t] = predict;
+        entry[t] = ((uint32_t)L.tag << 30) | ((uint32_t)y << 15) | (uint32_t)x;
     }
-    (void)lane;
-    block_append(predict, ((uint32_t)L.tag << 30) | ((uint32_t)y << 15) | (uint32_t)x, F.queue, F.qctl, append_lds);
+    block_append(want, entry, F.queue, F.qctl, append_lds);
 }
 hipError_t launch_predict(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int blocks, hipStream_t s) {
     if (blocks <= 0 || nb <= 0) return hipSuccess;
