@@ -23,9 +23,9 @@ def _port():
 
 def _line(r):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+    out = r.stdout.strip().splitlines()
+    assert len(out) == 1 and out[0].startswith("{"), "stdout must be exactly the one JSON line: " + r.stdout[-2000:]
+    return json.loads(out[0])
 
 
 @pytest.mark.parametrize("n,extra", [(2, []), (4, ["--gather-root", "3", "--frames-per-batch", "3"]), (8, [])])
