@@ -672,6 +672,10 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #ifndef BHRAY_TRACE_WAVES_DENSE
 #define BHRAY_TRACE_WAVES_DENSE 6
 #endif
+#ifndef BHRAY_REFILL_MIN
+#define BHRAY_REFILL_MIN 16      // refill from the queue (one atomic on its head + a dependent load) only when this many lanes are empty, or nobody is
+                                 // stepping: measured 1 / 8 / 16 / 24 / 32 / 48 -> 5 357 / 5 428 / 5 435 / 5 414 / 5 387 / 5 254 Mrays/s (Euler 8 009 -> 8 148 at 16)
+#endif
 #ifndef BHRAY_MAILBOX_T
 #define BHRAY_MAILBOX_T 0        // drain merging (measured, off: DESIGN.md §4): a wave with this many live rays or fewer parks them; 0 disables
 #endif
@@ -792,7 +796,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
         // ---- refill finished lanes from the queue (wave ballot + prefix popcount)
         {
             const unsigned long long need = __ballot(mode == M_EMPTY);
-            if (need != 0ull && !exhausted) {      // (refilling only when >= 4 .. 32 lanes are empty - fewer atomics on the queue head - changes nothing: measured)
+            if (need != 0ull && !exhausted && (BHRAY_REFILL_MIN <= 1 || __popcll(need) >= BHRAY_REFILL_MIN || !__any(mode == M_REL))) {
                 const uint32_t n = (uint32_t)__popcll(need);
                 uint32_t base = 0;
                 if (lane == (int)__builtin_ctzll(need)) base = atomicAdd(qhead, n);
