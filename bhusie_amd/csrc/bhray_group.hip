@@ -199,7 +199,7 @@ int group_gather(bhray_ctx* c, int si, uint32_t nb) {
     if (!R) return gfail(c, BHRAY_E_COMM, "%s", g_rccl.error.c_str());
     GroupSlot& G = c->gslots[(size_t)si];
     const size_t W = c->cfg.frame_w;
-    const bool timing = (c->cfg.flags & BHRAY_F_TIMING) != 0;
+    const bool timing = (c->cfg.flags & (BHRAY_F_TIMING | BHRAY_F_TIMING_SPARSE)) != 0;
     // the communication stream of every local rank waits for the renders whose rows it moves
     for (Part& p : c->parts) {
         if (!p.dev) continue;
@@ -512,7 +512,7 @@ int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
             CH(hipMemset(G.frames, 0xFF, (size_t)c->B * frame_pixels(c) * sizeof(float4)));
             if (c->staging_rows) CH(hipMalloc(&G.staging, c->staging_rows * W * sizeof(float4)));
             CH(hipEventCreateWithFlags(&G.frame_done, hipEventDisableTiming));
-            if (cfg->flags & BHRAY_F_TIMING) for (auto& e : G.tev) CH(hipEventCreate(&e));
+            if (cfg->flags & (BHRAY_F_TIMING | BHRAY_F_TIMING_SPARSE)) for (auto& e : G.tev) CH(hipEventCreate(&e));
         }
     }
     if (c->root_local) {
@@ -827,7 +827,7 @@ int bhray_get_counters(bhray_ctx* c, bhray_counters* out) {
 int bhray_get_timing(bhray_ctx* c, bhray_timing* out) {
     if (!c || !out) return BHRAY_E_INVALID;
     if (c->single) { DEV(c, c->parts[0].dev, dev_get_timing(c->parts[0].dev, out)); return BHRAY_OK; }
-    if (!(c->cfg.flags & BHRAY_F_TIMING)) return gfail(c, BHRAY_E_STATE, "ctx created without BHRAY_F_TIMING");
+    if (!(c->cfg.flags & (BHRAY_F_TIMING | BHRAY_F_TIMING_SPARSE))) return gfail(c, BHRAY_E_STATE, "ctx created without BHRAY_F_TIMING");
     { int rc = group_sync(c); if (rc) return rc; }
     // kernel times: the root partition's (or this rank's) launches; gather: the root's communication stream
     Part* src = c->root_local ? root_part(c) : &c->parts[c->cfg.row_rank];

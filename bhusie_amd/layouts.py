@@ -13,6 +13,7 @@ F_COUNTERS = 1
 F_TIMING = 2
 F_LITERAL = 4
 F_TEMPORAL = 8
+F_TIMING_SPARSE = 16
 TEX_TEMP_LUT, TEX_DISK, TEX_SKY = 0, 1, 2
 
 

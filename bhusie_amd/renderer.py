@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 
 from ._lib import lib
-from .layouts import (F_COUNTERS, F_LITERAL, F_TEMPORAL, F_TIMING, GATHER_RCCL, TEX_DISK, TEX_SKY, TEX_TEMP_LUT, BhrayConfig, BhrayCounters,
+from .layouts import (F_COUNTERS, F_LITERAL, F_TEMPORAL, F_TIMING, F_TIMING_SPARSE, GATHER_RCCL, TEX_DISK, TEX_SKY, TEX_TEMP_LUT, BhrayConfig, BhrayCounters,
                       BhrayGatherInfo, BhrayTiming, check)
 from .model import Model
 from .scene import BlackHole, Camera, RayDetails
@@ -72,7 +72,7 @@ class RayPass:
             assert len(comm_id) == 128
             cfg.gather = GATHER_RCCL
             C.memmove(cfg.comm_id, bytes(comm_id), 128)
-        cfg.flags = (F_COUNTERS if counters else 0) | (F_TIMING if timing else 0) | (F_LITERAL if literal else 0) | (F_TEMPORAL if temporal else 0)
+        cfg.flags = (F_COUNTERS if counters else 0) | (F_TIMING_SPARSE if timing == "sparse" else (F_TIMING if timing else 0)) | (F_LITERAL if literal else 0) | (F_TEMPORAL if temporal else 0)
         cfg.row_rank, cfg.row_world, cfg.stripe_rows = row_rank, row_world, stripe_rows
         cfg.frames_in_flight = frames_in_flight
         cfg.speculative_levels = speculative_levels

@@ -148,6 +148,8 @@ typedef struct bhray_model_desc {
 enum {                                  /* bhray_config.flags */
     BHRAY_F_COUNTERS   = 1u << 0,       /* kernels also accumulate bhray_counters (slower)   */
     BHRAY_F_TIMING     = 1u << 1,       /* record HIP events around every launch             */
+    BHRAY_F_TIMING_SPARSE = 1u << 4,    /* like BHRAY_F_TIMING, but only every 4th batch carries events (a recorded event is a packet in
+                                           the stream: 12 per frame cost a saturated device 1.6 %); bhray_get_timing aggregates those */
     BHRAY_F_TEMPORAL   = 1u << 3,       /* temporal speculation: one launch first traces, at every level, the pixels the previous frame
                                            had to trace; the ladder then only traces what that prediction missed.  Same pixels; the
                                            chain of dependent trace launches collapses when consecutive frames are similar (an
