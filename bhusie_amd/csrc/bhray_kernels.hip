@@ -1073,7 +1073,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
         }
 
         // ---- a batch of integrator steps (ray.wgsl:522-553) for lanes inside the sphere
-        for (int k = 0; k < BHRAY_REL_BATCH; k++) {
+        for (int k = 0; k < BHRAY_REL_BATCH; k++) {       // (unrolled by 2 / 4 to let prev = curr become renaming: -1 % / 0 %, measured)
             if (!__any(mode == M_REL)) break;
             if (COUNT && lane == 0) cnt[10]++;
             if (mode == M_REL) {
