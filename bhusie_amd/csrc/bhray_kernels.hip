@@ -191,19 +191,21 @@ __device__ __forceinline__ void shade_disk(const HotParams& P, F3 pos, F3 dir, f
 // Geometry only.  Returns true when the disk is the nearest hit (its parameter in td_out); the shading of that hit
 // (shade_disk) is run by the caller - the trace kernel defers it to a wave-uniform phase of its own.  rs holds the horizon
 // result (hit, t, colour 0, opacity 1) or "no hit".
-__device__ __forceinline__ bool hit_black_hole_geom(const HotParams& H, F3 pos, F3 dir, float pos_dist, float t_min, float t_max, Hit& rs, float& td_out) {
-    const F3 bpos = H.bh;
+// The two cull predicates of a step (see above): can the segment reach the horizon / the disk at all?
+__device__ __forceinline__ void black_hole_culls(const HotParams& H, F3 pos, float pos_dist, float t_max, bool& near_horizon, bool& near_disk) {
     const float reach = 1.05f * t_max + 0.05f;
+    near_horizon = pos_dist <= 1.0f + reach;
+    // signed plane distance from the hole-RELATIVE position: its rounding error (a few ulp of |pos - bh| <= outer + reach) does not
+    // grow with |bh|, unlike n.bh - n.pos for a hole far from the origin
+    const float numer = fdot(H.bh - pos, H.bn);
+    near_disk = pos_dist <= H.outer + reach && fabsf(numer) <= (1.01f * t_max) * H.bn_len + 1e-4f * H.bn_len;
+}
+__device__ __forceinline__ bool hit_black_hole_geom(const HotParams& H, F3 pos, F3 dir, bool near_horizon, bool near_disk, float t_min, float t_max, Hit& rs, float& td_out) {
+    const F3 bpos = H.bh;
     float ts = t_max, td = t_max;
     bool hs = false, hd = false;
-    if (pos_dist <= 1.0f + reach) hs = hit_sphere(pos, dir, 1.0f, bpos, t_min, t_max, ts);
-    if (pos_dist <= H.outer + reach) {
-        const F3 bn = H.bn;
-        // signed plane distance from the hole-RELATIVE position: its rounding error (a few ulp of |pos - bh| <= outer + reach)
-        // does not grow with |bh|, unlike n.bh - n.pos for a hole far from the origin
-        const float numer = fdot(bpos - pos, bn);
-        if (fabsf(numer) <= (1.01f * t_max) * H.bn_len + 1e-4f * H.bn_len) hd = hit_torus2d(pos, dir, H.inner, H.outer, bpos, bn, t_min, t_max, td);
-    }
+    if (near_horizon) hs = hit_sphere(pos, dir, 1.0f, bpos, t_min, t_max, ts);
+    if (near_disk) hd = hit_torus2d(pos, dir, H.inner, H.outer, bpos, H.bn, t_min, t_max, td);
     rs.hit = hs; rs.t = hs ? ts : t_max; rs.color = f3(0.0f, 0.0f, 0.0f); rs.opacity = hs ? 1.0f : 0.0f;
     td_out = td;
     return hd && td < rs.t;
@@ -1105,9 +1107,16 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                     dist_c = cd; cpos_dist = cd;                       // Euler: cpos is the integrator position; RK: cpos == rkpos here
                     if (cd < closest) closest = cd;
                     pdir = cdir;
-                    Hit crs; float td;
+                    // Everything that can end or alter the plain march - a horizon or disk test that is not culled, the sphere exit - sits
+                    // behind ONE branch: a wave that runs alone on its SIMD (the tail of every latency-bound launch) pays 30-40 cycles for
+                    // every compare -> exec mask -> branch, and the seven of the straightforward form cost it more than the RK step itself
+                    // (level 0 alone: 1.07 us per iteration, of which the step is 0.39).  `amount` changes only in there, so does its test.
                     const float seg = METHOD == 0 ? H.step_size : rkh;
-                    const bool disk = hit_black_hole_geom(H, ppos, pdir, ppos_dist, t_min, seg, crs, td);
+                    bool near_horizon, near_disk;
+                    black_hole_culls(H, ppos, ppos_dist, seg, near_horizon, near_disk);
+                    if (near_horizon || near_disk || cd > H.R) {
+                    Hit crs; float td;
+                    const bool disk = hit_black_hole_geom(H, ppos, pdir, near_horizon, near_disk, t_min, seg, crs, td);
                     if (cd > H.R) {
                         mode = M_FLAT;
                         const float fw = H.R * H.feather;
@@ -1133,6 +1142,9 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                         hit = true;
                     }
                     if (amount < 0.005f) mode = M_FINISH; else it++;
+                    } else {
+                        it++;
+                    }
                 }
             }
         }

@@ -61,9 +61,17 @@ void run(const char* what) {
     float* out; long long* cyc; long long h;
     hipMalloc(&out, 64 * sizeof(float)); hipMalloc(&cyc, sizeof(long long));
     const int steps = 300;
+    const int steps_long = 30000;                    // long enough for the wall clock to mean something
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 2; rep++) { hipLaunchKernelGGL((k<GUARD, ADAPT, DIST>), dim3(1), dim3(64), 0, 0, out, cyc, steps, 0.5f); hipDeviceSynchronize(); }
     hipMemcpy(&h, cyc, sizeof h, hipMemcpyDeviceToHost);
-    printf("%-44s %6.0f clock64 ticks per step\n", what, (double)h / steps);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k<GUARD, ADAPT, DIST>), dim3(1), dim3(64), 0, 0, out, cyc, steps_long, 0.5f);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    long long hl; hipMemcpy(&hl, cyc, sizeof hl, hipMemcpyDeviceToHost);
+    printf("%-44s %6.0f clock64 ticks per step; long run: %.0f ns per step, %.0f ticks per step -> tick = %.2f ns\n", what, (double)h / steps,
+           ms * 1e6 / steps_long, (double)hl / steps_long, ms * 1e6 / (double)hl);
     hipFree(out); hipFree(cyc);
 }
 
