@@ -198,7 +198,7 @@ __device__ __forceinline__ void black_hole_culls(const HotParams& H, F3 pos, flo
     // signed plane distance from the hole-RELATIVE position: its rounding error (a few ulp of |pos - bh| <= outer + reach) does not
     // grow with |bh|, unlike n.bh - n.pos for a hole far from the origin
     const float numer = fdot(H.bh - pos, H.bn);
-    near_disk = pos_dist <= H.outer + reach && fabsf(numer) <= (1.01f * t_max) * H.bn_len + 1e-4f * H.bn_len;
+    near_disk = (pos_dist <= H.outer + reach) & (fabsf(numer) <= (1.01f * t_max) * H.bn_len + 1e-4f * H.bn_len);     // & : no branch
 }
 __device__ __forceinline__ bool hit_black_hole_geom(const HotParams& H, F3 pos, F3 dir, bool near_horizon, bool near_disk, float t_min, float t_max, Hit& rs, float& td_out) {
     const F3 bpos = H.bh;
@@ -371,19 +371,57 @@ __device__ __forceinline__ float sqrt_corrected(float x) {
 }
 __device__ __forceinline__ bool rcp_in_range(float x) { return fabsf(x) >= 0x1p-125f && fabsf(x) < 0x1p126f; }
 __device__ __forceinline__ bool sqrt_in_range(float x) { return x >= 0x1p-95f && x <= 0x1p95f; }
+// The short sequence is computed unconditionally and REPLACED behind a wave-uniform, never-taken-in-practice branch: the result does
+// not wait for the range test and the step has one not-taken branch per use instead of a diamond (two) - a wave that runs
+// alone on its SIMD pays for every branch (profiles/ubench/lone_wave.hip).
 __device__ __forceinline__ float rcp_rn(float x) {                 // == 1.0f / x
-    if (__builtin_expect(__ballot(!rcp_in_range(x)) == 0ull, 1)) return rcp_newton(x);
-    return 1.0f / x;
+    float r = rcp_newton(x);
+    if (__builtin_expect(__ballot(!rcp_in_range(x)) != 0ull, 0)) r = 1.0f / x;
+    return r;
 }
 __device__ __forceinline__ float sqrt_rn(float x) {                // == sqrtf(x)
-    if (__builtin_expect(__ballot(!sqrt_in_range(x)) == 0ull, 1)) return sqrt_corrected(x);
-    return sqrtf(x);
+    float r = sqrt_corrected(x);
+    if (__builtin_expect(__ballot(!sqrt_in_range(x)) != 0ull, 0)) r = sqrtf(x);
+    return r;
 }
 // == fnormalize(a) (bhray_math.h): a * (1 / sqrt(fdot(a, a))); one guard covers both (sqrt of an in-range x is in rcp's range)
 __device__ __forceinline__ F3 fnormalize_rn(F3 a) {
     const float d = fdot(a, a);
-    if (__builtin_expect(__ballot(!sqrt_in_range(d)) == 0ull, 1)) return a * rcp_newton(sqrt_corrected(d));
-    return a * (1.0f / sqrtf(d));
+    float r = rcp_newton(sqrt_corrected(d));
+    if (__builtin_expect(__ballot(!sqrt_in_range(d)) != 0ull, 0)) r = 1.0f / sqrtf(d);
+    return a * r;
+}
+// == bh_pow_m001(x) (bhray_math.h) for every x > 0.00002f, the only values next_ray_rk passes (all of them, +inf included, checked
+// by bhray_selftest).  The portable form's NaN / negative / zero / denormal arms are dead there, +inf becomes a select, and the
+// quotient (m - 1) / (m + 1), m + 1 in [1.70, 2.42], is the short correctly rounded sequence: reciprocal, product, one residual
+// correction.  A stepping wave takes the step-size arm in most iterations (one lane of 64 suffices), so its length is paid by
+// every ray: 63 -> 46 instructions.
+__device__ __forceinline__ float pow_m001_step(float x) {
+    const uint32_t u = f2u(x);
+    int e = (int)(u >> 23) - 127;
+    float m = u2f((u & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421354f) { m = m * 0.5f; e = e + 1; }
+    const float num = m - 1.0f, den = m + 1.0f;
+    const float r = rcp_newton(den);
+    const float q0 = num * r;
+    const float s = __builtin_fmaf(__builtin_fmaf(-den, q0, num), r, q0);
+    const float s2 = s * s;
+    float p = 0.111111112f;
+    p = p * s2 + 0.142857149f;
+    p = p * s2 + 0.2f;
+    p = p * s2 + 0.333333343f;
+    p = p * s2 + 1.0f;
+    const float lnm = (2.0f * s) * p;
+    const float lnx = (float)e * 0.693147182f + lnm;
+    const float t = -0.001f * lnx;
+    float q = 0.00138888892f;
+    q = q * t + 0.00833333377f;
+    q = q * t + 0.0416666679f;
+    q = q * t + 0.166666672f;
+    q = q * t + 0.5f;
+    q = q * t + 1.0f;
+    q = q * t + 1.0f;
+    return x == u2f(0x7f800000u) ? 0.0f : q;
 }
 __device__ __forceinline__ float fdistance_rn(F3 a, F3 b) { const F3 v = a - b; return sqrt_rn(fdot(v, v)); }   // == fdistance(a, b)
 
@@ -427,7 +465,7 @@ __device__ __forceinline__ void next_ray_rk(F3 q0, F3& pos, F3& dir, float& h_io
     const F3 ds = fmadd3(K6, BA6, fmadd3(K5, BA5, fmadd3(K4, BA4, fmadd3(K3, BA3, K1 * BA1))));
     dir = fnormalize_rn(d0 + ds);
     pos = fmadd3(d0, h, p0);
-    if (e_max > 0.00002f) h_io = h * (0.9f * bh_pow_m001(e_max));
+    if (e_max > 0.00002f) h_io = h * (0.9f * pow_m001_step(e_max));
     else h_io = h * 1.0001f;
 }
 
@@ -794,7 +832,17 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
     unsigned long long cnt[13];           // [0..9] = bhray_counters' frame counters, [10] wave steps (lane 0), [11] rays adopted, [12] longest ray
     if (COUNT) { for (int k = 0; k < 13; k++) cnt[k] = 0; }
 
+#ifdef BHRAY_EXP_PROFILE                  // timing-only build: where does the time of one wave go? (profiles/r02_experiments.json: lone_wave_phases)
+    long long xp_t0 = clock64(), xp_last = xp_t0, xp_t[5] = {0, 0, 0, 0, 0}; int xp_c[5] = {0, 0, 0, 0, 0}, xp_n = 0, xp_rounds = 0;
+#define XP(k, active) { const long long now_ = clock64(); xp_t[k] += now_ - xp_last; xp_last = now_; xp_c[k] += (active) ? 1 : 0; }
+#else
+#define XP(k, active)
+#endif
     for (;;) {
+#ifdef BHRAY_EXP_PROFILE
+        xp_rounds++;
+        const bool xp_refill = __any(mode == M_EMPTY);
+#endif
         // ---- refill finished lanes from the queue (wave ballot + prefix popcount)
         {
             const unsigned long long need = __ballot(mode == M_EMPTY);
@@ -938,6 +986,10 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
             }
         }
 
+        XP(0, xp_refill)
+#ifdef BHRAY_EXP_PROFILE
+        const bool xp_shade = __any(mode >= M_SHADE_REL), xp_flat = __any(mode == M_FLAT);
+#endif
         // ---- deferred disk shading (ray.wgsl:612-663 and the hit bookkeeping of 537-552) for lanes that paused on a disk hit
         if (__any(mode >= M_SHADE_REL)) {
             if (mode >= M_SHADE_REL) {
@@ -956,6 +1008,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
             }
         }
 
+        XP(1, xp_shade)
         // ---- flat-space iterations (ray.wgsl:554-569), one per lane that is in flat space.
         // With meshes a flat iteration is a BVH traversal executed by the whole wave for the few lanes that need it,
         // so those lanes are batched: the phase runs when enough of them wait, when nobody is integrating, or at the
@@ -1027,6 +1080,10 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
         }
 
         // ---- epilogue (ray.wgsl:583-595) for lanes whose loop ended
+        XP(2, xp_flat)
+#ifdef BHRAY_EXP_PROFILE
+        const bool xp_fin = __any(mode == M_FINISH);
+#endif
         if (__any(mode == M_FINISH)) {
             if (mode == M_FINISH) {
                 float4 o;
@@ -1074,10 +1131,14 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
             }
         }
 
+        XP(3, xp_fin)
         // ---- a batch of integrator steps (ray.wgsl:522-553) for lanes inside the sphere
         for (int k = 0; k < BHRAY_REL_BATCH; k++) {       // (unrolled by 2 / 4 to let prev = curr become renaming: -1 % / 0 %, measured)
             if (!__any(mode == M_REL)) break;
             if (COUNT && lane == 0) cnt[10]++;
+#ifdef BHRAY_EXP_PROFILE
+            xp_n++;
+#endif
             if (mode == M_REL) {
                 if (it >= H.max_iter) {
                     mode = M_FINISH;
@@ -1148,7 +1209,13 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                 }
             }
         }
+        XP(4, true)
     }
+#ifdef BHRAY_EXP_PROFILE
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        printf("xp: total %lld rounds %d iterations %d | refill %lld (%d) shade %lld (%d) flat %lld (%d) finish %lld (%d) steps %lld\n", (long long)(clock64() - xp_t0), xp_rounds, xp_n,
+               xp_t[0], xp_c[0], xp_t[1], xp_c[1], xp_t[2], xp_c[2], xp_t[3], xp_c[3], xp_t[4]);
+#endif
 
     if (COUNT) {
         for (int k = 3; k < 12; k++) {
@@ -1211,6 +1278,7 @@ __global__ __launch_bounds__(256) void selftest_kernel(unsigned long long* __res
         if (f2u(a) != f2u(b) && !(a != a && b != b)) nr++;
         const float c = sqrt_rn(x), d = sqrtf(x);
         if (f2u(c) != f2u(d) && !(c != c && d != d)) ns++;
+        if (x > 0.00002f && f2u(pow_m001_step(x)) != f2u(bh_pow_m001(x))) nr++;      // the step-size power on its whole domain
     }
     if (nr) atomicAdd(&bad[0], nr);
     if (ns) atomicAdd(&bad[1], ns);

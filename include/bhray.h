@@ -376,7 +376,7 @@ int bhray_get_level_counters(bhray_ctx* ctx, uint32_t level, bhray_counters* out
  * rounded 1/x and sqrt(x) with short gfx950 sequences — run against the IEEE lowering on all 2^32 binary32 bit patterns;
  * (ii) the grid classification replaces `acos(c) < threshold` by `c > c*` — the portable acos must be monotone over every
  * binary32 value of [-1, 1].  Returns the number of violating inputs of each (all must be 0).  ~20 ms.              */
-int bhray_selftest(bhray_ctx* ctx, uint64_t mismatches[3]);    /* [0] = 1/x, [1] = sqrt, [2] = acos monotonicity */
+int bhray_selftest(bhray_ctx* ctx, uint64_t mismatches[3]);    /* [0] = 1/x and the step-size power, [1] = sqrt, [2] = acos monotonicity */
 
 /* HIP-event timing of every launch (events recorded on the ctx stream).  bhray_get_timing sums
  * over the batches launched since the previous call (at most BHRAY_TIMING_RING of them).     */
