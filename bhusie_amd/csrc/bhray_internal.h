@@ -56,6 +56,7 @@ struct FrameParams {
     int max_iter;
     float thr;
     float acos_cstar;      // largest c with bh_acos(c) >= thr (host, binary search): bh_acos(c) < thr <=> c > acos_cstar on [-1, 1]
+    float acos_cstar_near; // the same for thr * temporal_margin (<= thr): temporal speculation also predicts the pixels this close to being traced
     int model_count;
     TexDev temp, disk, sky;
     ModelDev models[BHRAY_MAX_MODELS];
