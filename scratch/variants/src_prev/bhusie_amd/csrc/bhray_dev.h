@@ -1,0 +1,63 @@
+// bhray_dev.h — the per-device engine behind the public bhray_ctx.
+//
+// A bhray_dev renders ONE row partition of the frame on ONE GPU (bhray_api.hip): ladder levels, frame slots, frame batches,
+// speculative levels.  The public bhray_ctx (bhray_group.hip) owns one bhray_dev per local partition and, when the frame is
+// split over several partitions, the gather of the row tiles to the root partition's GPU (RCCL) and the de-interleave into
+// the frame.  Nothing here is exported; the C ABI is include/bhray.h.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/bhray.h"
+
+struct bhray_dev;
+
+namespace bhray {
+struct DevOptions {
+    bool external_out = false;   // the ctx binds every frame's destination (send buffer / assembled frame): no own output buffers
+    bool frame_rowmap = false;   // the destination is a whole frame_h x frame_w frame: row r of the frame lands in row r (root partition of a gather)
+};
+}  // namespace bhray
+
+const char* dev_last_error(const bhray_dev* c);            // c may be NULL: last create error of this thread
+void dev_set_create_error(const char* msg);
+int  dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev** out);
+void dev_destroy(bhray_dev* c);
+int  dev_set_texture(bhray_dev* c, int slot, const uint8_t* rgba8, uint32_t w, uint32_t h);
+int  dev_upload_model_uniform(bhray_dev* c, uint32_t model_index, const void* bytes, size_t size);
+int  dev_upload_model(bhray_dev* c, uint32_t model_index, const bhray_model_desc* desc);
+int  dev_set_model_transform(bhray_dev* c, uint32_t model_index, const float position[3], int32_t visible);
+int  dev_set_uniforms(bhray_dev* c, const void* cam32, const void* bh132, const void* det32);
+int  dev_render(bhray_dev* c);
+int  dev_flush(bhray_dev* c);
+int  dev_sync(bhray_dev* c);
+uint32_t dev_local_rows(const bhray_dev* c);
+int  dev_local_row_index(const bhray_dev* c, uint32_t i, uint32_t* frame_row);
+int  dev_read_hdr(bhray_dev* c, float* dst, size_t pitch);
+int  dev_read_level(bhray_dev* c, uint32_t level, float* dst, size_t pitch);
+int  dev_hdr_device_ptr(bhray_dev* c, void** p, size_t* bytes);
+int  dev_bind_output(bhray_dev* c, void* p, size_t bytes);     // destination of the NEXT dev_render only
+int  dev_resolve_sky(bhray_dev* c);
+int  dev_read_sky(bhray_dev* c, uint16_t* dst, size_t pitch);
+int  dev_sky_device_ptr(bhray_dev* c, void** p, size_t* bytes);
+int  dev_wait_event(bhray_dev* c, hipEvent_t ev);             // the next render's launches start after ev (ev is owned by the caller)
+int  dev_next_stream(bhray_dev* c, void** s);
+int  dev_signal_stream(bhray_dev* c, void* s);
+int  dev_selftest(bhray_dev* c, uint64_t mismatches[3]);
+int  dev_get_level_counters(bhray_dev* c, uint32_t level, bhray_counters* out);
+int  dev_get_counters(bhray_dev* c, bhray_counters* out);
+int  dev_get_timing(bhray_dev* c, bhray_timing* out);
+
+// hooks for the gather (bhray_group.hip)
+int  dev_device(const bhray_dev* c);
+// Position (slot, index in the batch) the next dev_render will stage its frame at.  A staged batch of another kernel variant
+// (integrator, mesh) than the current uniforms need is launched first, so the position is final.
+int  dev_next_position(bhray_dev* c, int* slot, uint32_t* sub);
+// True when launches were enqueued since the last call; reports the slot and the number of frames of the (last) launched batch.
+bool dev_take_launched(bhray_dev* c, int* slot, uint32_t* frames);
+hipStream_t dev_slot_stream(bhray_dev* c, int slot);
+hipEvent_t  dev_slot_done(bhray_dev* c, int slot);            // recorded behind the slot's last launch
+// sky.wgsl over an arbitrary RGBA32F image resident on this device, with this partition's sky texture
+int  dev_launch_sky(bhray_dev* c, const void* src_rgba32f, void* dst_rgba16f, size_t npix, hipStream_t stream);

@@ -1,0 +1,854 @@
+// bhray_group.hip — the public bhray_ctx: one or several row partitions of the frame, and the gather.
+//
+// The reference renders on one device from one thread (src/app.rs:108-114, src/renderer/mod.rs:415-420: one compute pass,
+// one submit).  This file keeps that host model and puts the multi-GPU row tiling BEHIND the C ABI:
+//
+//   bhray_ctx = N row partitions (frame row r -> partition (r / stripe_rows) % N), each rendered by a per-device engine
+//   (bhray_dev, bhray_api.hip) — all N by this process (bhray_config.device_count = N), or one of them by this process as
+//   rank row_rank of a communicator whose id the launcher distributes (one process per GPU).  Scene and uniforms are
+//   replicated; every partition recomputes the coarse ladder rows its stripes depend on, so nothing is exchanged until the
+//   frame's last level is done.  Then, per launched batch and on dedicated communication streams:
+//       non-root partitions   ncclSend(packed rows of the batch's frames)            -> root rank      \  one RCCL group:
+//       root partition        ncclRecv(... from every other partition) into staging                    /  7 links in parallel
+//                             deinterleave_kernel: staging rows -> their frame rows (the root's own rows are written
+//                             straight into the frame by its trace kernel)
+//   so bhray_render stays asynchronous and the gather of batch k overlaps the render of batch k+1.
+//
+// RCCL is used directly (no PyTorch): loaded with dlopen on first use, because librccl.so is ~570 MB and a single-GPU host
+// (the reference's normal case) must not pay for it.  Partitions that live on the same device (functional tests on a
+// one-GPU box: devices = {0,0,...}) share one RCCL rank and exchange their tiles as send/recv-to-self inside the same group
+// (RCCL refuses a communicator with a duplicated device; self send/recv inside a group is supported and matches in order).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "bhray_dev.h"
+#include "bhray_internal.h"
+
+using namespace bhray;
+
+// ------------------------------------------------------------------------------------------
+// RCCL, bound at run time: types and prototypes from <rccl/rccl.h>, entry points through dlsym (nothing links librccl)
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct Rccl {
+    void* so = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    int version = 0;
+    std::string error;
+};
+
+Rccl g_rccl;
+std::mutex g_rccl_mutex;
+
+// nullptr + g_rccl.error when RCCL cannot be loaded
+Rccl* rccl() {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.so) return &g_rccl;
+    void* so = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!so) { g_rccl.error = std::string("dlopen(librccl.so.1): ") + dlerror(); return nullptr; }
+    Rccl r; r.so = so;
+#define SYM(field, name)                                                                       \
+    do {                                                                                       \
+        *(void**)(&r.field) = dlsym(so, name);                                                 \
+        if (!r.field) { g_rccl.error = std::string("librccl: missing symbol ") + name; dlclose(so); return nullptr; } \
+    } while (0)
+    SYM(GetVersion, "ncclGetVersion"); SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitAll, "ncclCommInitAll");
+    SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy"); SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    if (r.GetVersion(&r.version) != ncclSuccess) r.version = 0;
+    g_rccl = r;
+    return &g_rccl;
+}
+
+// ------------------------------------------------------------------------------------------
+// row partition arithmetic (shared by the host tables, the ABI helpers and — through the tables — the kernel)
+// ------------------------------------------------------------------------------------------
+// frame row of packed row i of partition `part`: stripes of `stripe` rows are dealt round-robin
+inline uint64_t part_row(uint32_t world, uint32_t stripe, uint32_t part, uint32_t i) {
+    return ((uint64_t)(i / stripe) * world + part) * stripe + (i % stripe);
+}
+inline uint32_t part_rows(uint32_t frame_h, uint32_t world, uint32_t stripe, uint32_t part) {
+    const uint64_t cycle = (uint64_t)world * stripe;              // rows of one round over all partitions
+    const uint64_t full = frame_h / cycle, rem = frame_h % cycle;
+    uint64_t n = full * stripe;
+    const uint64_t lo = (uint64_t)part * stripe;                  // this partition's stripe inside the last, partial round
+    if (rem > lo) n += (rem - lo < stripe) ? (rem - lo) : stripe;
+    return (uint32_t)n;
+}
+
+// One staging row of the root: where it comes from and which frame row it is.
+struct RowDesc { uint32_t src_row0; uint32_t part_rows; uint32_t frame_row; uint32_t pad; };
+struct FramePtrs { float4* p[BHRAY_MAX_FRAMES_PER_BATCH]; };
+
+// De-interleave: row j of the concatenated non-root tiles of frame k of the batch -> its row of frame k.
+// HBM-bound copy (16 B read + 16 B written per pixel); one block per row, consecutive lanes on consecutive float4s.
+__global__ __launch_bounds__(256) void deinterleave_kernel(const float4* __restrict__ staging, const FramePtrs frames,
+                                                           const RowDesc* __restrict__ table, const int width) {
+    const RowDesc t = table[blockIdx.x];
+    const int k = blockIdx.y;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v* __restrict__ src = (const f4v*)(staging + ((size_t)t.src_row0 + (size_t)k * t.part_rows) * (size_t)width);
+    f4v* __restrict__ dst = (f4v*)(frames.p[k] + (size_t)t.frame_row * (size_t)width);
+    for (int x = threadIdx.x; x < width; x += 256) dst[x] = __builtin_nontemporal_load(src + x);   // staging is read once
+}
+
+struct Part {                      // one row partition of the frame
+    bhray_dev* dev = nullptr;      // non-null: rendered by this ctx
+    int device = -1;
+    int rank = -1;                 // rank of the communicator this partition's tiles leave from / arrive at
+    uint32_t rows = 0;
+    size_t stage_row0 = 0;         // root staging: first row of this partition's block (units of rows, for batch index 0)
+};
+
+struct CommRank {                  // a local rank of the communicator: one GPU of this process
+    int device = -1;
+    int rank = -1;
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;  // communication stream of that GPU (sends / receives / de-interleave)
+};
+
+struct GroupSlot {                 // per batch slot (same index as the devices' slots)
+    float4* frames = nullptr;                 // root: B assembled frames
+    float4* staging = nullptr;                // root: tiles of the other partitions, [part][frame of batch][row][x]
+    std::vector<float4*> send;                // per partition: packed rows of the batch's frames (local non-root partitions)
+    std::vector<hipEvent_t> sent;             // per partition: recorded behind its send
+    hipEvent_t frame_done = nullptr;          // root: recorded behind the de-interleave
+    float4* dst[BHRAY_MAX_FRAMES_PER_BATCH];  // root: destination of each frame of the batch staged here (own or caller-bound)
+    uint2* sky[BHRAY_MAX_FRAMES_PER_BATCH];   // root: RGBA16F images of bhray_resolve_sky (allocated on first use)
+    hipEvent_t tev[3] = {nullptr, nullptr, nullptr};   // timing: before receive, after receive, after de-interleave
+    bool timed = false;
+};
+
+}  // namespace
+
+struct bhray_ctx {
+    bhray_config cfg{};
+    std::vector<Part> parts;
+    std::vector<CommRank> ranks;           // local ranks
+    bool single = true;                    // one partition, no gather: every call goes straight to parts[0].dev
+    bool gather = false;
+    uint32_t root = 0;
+    bool root_local = false;
+    uint32_t world = 1;                    // partitions
+    uint32_t comm_size = 0;
+    uint32_t B = 1, nslots = 1;
+    std::vector<GroupSlot> gslots;
+    RowDesc* d_table = nullptr; uint32_t table_rows = 0;      // root GPU
+    size_t staging_rows = 0;               // rows of one staging buffer (all non-root partitions, B frames)
+    float4* bound = nullptr;               // bhray_bind_output: destination of the next frame (one-shot)
+    hipEvent_t wait_ev = nullptr;          // bhray_wait_stream
+    int last_slot = 0; uint32_t last_sub = 0;
+    bool rendered = false;
+    float gather_ms = 0, deint_ms = 0; uint32_t gathers = 0;
+    std::string err;
+};
+
+namespace {
+
+int gfail(bhray_ctx* c, int code, const char* fmt, ...) {
+    char buf[640];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (c) c->err = buf; else dev_set_create_error(buf);
+    return code;
+}
+// error of a per-device call: carry the device's message
+int dfail(bhray_ctx* c, const bhray_dev* d, int rc) { if (rc) c->err = dev_last_error(d); return rc; }
+
+#define GHIP(c, call)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) return gfail(c, BHRAY_E_HIP, "%s: %s", #call, hipGetErrorString(e_));    \
+    } while (0)
+#define GNCCL(c, R, call)                                                                              \
+    do {                                                                                               \
+        ncclResult_t r_ = (call);                                                                      \
+        if (r_ != ncclSuccess) return gfail(c, BHRAY_E_COMM, "%s: %s", #call, (R)->GetErrorString(r_));          \
+    } while (0)
+#define DEV(c, d, call) do { int rc_ = (call); if (rc_) return dfail(c, d, rc_); } while (0)
+
+Part* root_part(bhray_ctx* c) { return &c->parts[c->root]; }
+CommRank* rank_of(bhray_ctx* c, const Part& p) {
+    for (CommRank& r : c->ranks) if (r.rank == p.rank) return &r;
+    return nullptr;
+}
+size_t frame_pixels(const bhray_ctx* c) { return (size_t)c->cfg.frame_w * (size_t)c->cfg.frame_h; }
+
+// Gather of one launched batch (nb frames staged in slot si): sends, receives, de-interleave; see the file header.
+int group_gather(bhray_ctx* c, int si, uint32_t nb) {
+    Rccl* R = rccl();
+    if (!R) return gfail(c, BHRAY_E_COMM, "%s", g_rccl.error.c_str());
+    GroupSlot& G = c->gslots[(size_t)si];
+    const size_t W = c->cfg.frame_w;
+    const bool timing = (c->cfg.flags & (BHRAY_F_TIMING | BHRAY_F_TIMING_SPARSE)) != 0;
+    // the communication stream of every local rank waits for the renders whose rows it moves
+    for (Part& p : c->parts) {
+        if (!p.dev) continue;
+        CommRank* cr = rank_of(c, p);
+        GHIP(c, hipSetDevice(p.device));
+        GHIP(c, hipStreamWaitEvent(cr->stream, dev_slot_done(p.dev, si), 0));
+    }
+    Part& rp = *root_part(c);
+    CommRank* rr = c->root_local ? rank_of(c, rp) : nullptr;
+    if (rr && timing) { GHIP(c, hipSetDevice(rr->device)); GHIP(c, hipEventRecord(G.tev[0], rr->stream)); }
+    // ONE group: every tile of the batch.  Sends and receives are issued in partition order, so the messages between
+    // a pair of ranks (several partitions may share a rank) match in order.
+    GNCCL(c, R, R->GroupStart());
+    for (uint32_t q = 0; q < c->world; q++) {
+        Part& p = c->parts[q];
+        if (q == c->root || !p.dev || p.rows == 0) continue;
+        CommRank* cr = rank_of(c, p);
+        GHIP(c, hipSetDevice(p.device));
+        GNCCL(c, R, R->Send(G.send[q], (size_t)nb * p.rows * W * 4, ncclFloat32, rp.rank, cr->comm, cr->stream));
+    }
+    if (rr) {
+        GHIP(c, hipSetDevice(rr->device));
+        for (uint32_t q = 0; q < c->world; q++) {
+            const Part& p = c->parts[q];
+            if (q == c->root || p.rows == 0) continue;
+            GNCCL(c, R, R->Recv(G.staging + p.stage_row0 * W, (size_t)nb * p.rows * W * 4, ncclFloat32, p.rank, rr->comm, rr->stream));
+        }
+    }
+    GNCCL(c, R, R->GroupEnd());
+    // a slot's next batch may overwrite its send buffer only after the send has read it
+    for (uint32_t q = 0; q < c->world; q++) {
+        Part& p = c->parts[q];
+        if (q == c->root || !p.dev) continue;
+        CommRank* cr = rank_of(c, p);
+        GHIP(c, hipSetDevice(p.device));
+        GHIP(c, hipEventRecord(G.sent[q], cr->stream));
+        GHIP(c, hipStreamWaitEvent(dev_slot_stream(p.dev, si), G.sent[q], 0));
+    }
+    if (rr) {
+        GHIP(c, hipSetDevice(rr->device));
+        if (timing) GHIP(c, hipEventRecord(G.tev[1], rr->stream));
+        if (c->table_rows) {
+            FramePtrs fp; memset(&fp, 0, sizeof fp);
+            for (uint32_t k = 0; k < nb; k++) fp.p[k] = G.dst[k];
+            (void)hipGetLastError();          // a stale error of an unrelated earlier call must not be blamed on this launch
+            hipLaunchKernelGGL(deinterleave_kernel, dim3(c->table_rows, nb), dim3(256), 0, rr->stream, G.staging, fp, c->d_table, (int)W);
+            GHIP(c, hipGetLastError());
+        }
+        if (timing) { GHIP(c, hipEventRecord(G.tev[2], rr->stream)); G.timed = true; }
+        GHIP(c, hipEventRecord(G.frame_done, rr->stream));
+        // the root's next render into this slot writes its own rows into the frames the de-interleave is filling: keep them ordered
+        GHIP(c, hipStreamWaitEvent(dev_slot_stream(rp.dev, si), G.frame_done, 0));
+    }
+    c->gathers++;
+    return BHRAY_OK;
+}
+
+// after a call that may have launched a batch on every local partition: enqueue its gather
+int after_launch(bhray_ctx* c) {
+    int slot = -1; uint32_t nb = 0; bool any = false;
+    for (Part& p : c->parts) {
+        if (!p.dev) continue;
+        int s; uint32_t n;
+        if (dev_take_launched(p.dev, &s, &n)) {
+            if (any && (s != slot || n != nb)) return gfail(c, BHRAY_E_STATE, "internal: partitions out of step");
+            slot = s; nb = n; any = true;
+        } else if (any) {
+            return gfail(c, BHRAY_E_STATE, "internal: partitions out of step");
+        }
+    }
+    if (!any) return BHRAY_OK;
+    // timing of an earlier gather held by this slot is folded in before its events are re-recorded
+    GroupSlot& G = c->gslots[(size_t)slot];
+    if (G.timed && c->root_local) {
+        CommRank* rr = rank_of(c, *root_part(c));
+        GHIP(c, hipSetDevice(rr->device));
+        GHIP(c, hipEventSynchronize(G.tev[2]));
+        float a = 0, b = 0;
+        GHIP(c, hipEventElapsedTime(&a, G.tev[0], G.tev[1])); GHIP(c, hipEventElapsedTime(&b, G.tev[1], G.tev[2]));
+        c->gather_ms += a; c->deint_ms += b; G.timed = false;
+    }
+    return group_gather(c, slot, nb);
+}
+
+int group_flush(bhray_ctx* c) {
+    for (Part& p : c->parts) if (p.dev) DEV(c, p.dev, dev_flush(p.dev));
+    return after_launch(c);
+}
+
+int group_sync(bhray_ctx* c) {
+    { int rc = group_flush(c); if (rc) return rc; }
+    for (Part& p : c->parts) if (p.dev) DEV(c, p.dev, dev_sync(p.dev));
+    for (CommRank& r : c->ranks) { GHIP(c, hipSetDevice(r.device)); GHIP(c, hipStreamSynchronize(r.stream)); }
+    return BHRAY_OK;
+}
+
+void group_free(bhray_ctx* c) {
+    Rccl* R = g_rccl.so ? &g_rccl : nullptr;
+    for (CommRank& r : c->ranks) if (r.stream) { (void)hipSetDevice(r.device); (void)hipStreamSynchronize(r.stream); }
+    for (Part& p : c->parts) if (p.dev) { dev_destroy(p.dev); p.dev = nullptr; }
+    for (uint32_t q = 0; q < c->parts.size(); q++) {
+        const Part& p = c->parts[q];
+        if (p.device < 0) continue;
+        (void)hipSetDevice(p.device);
+        for (GroupSlot& G : c->gslots) {
+            if (q < G.send.size() && G.send[q]) (void)hipFree(G.send[q]);
+            if (q < G.sent.size() && G.sent[q]) (void)hipEventDestroy(G.sent[q]);
+        }
+    }
+    if (c->root_local) {
+        (void)hipSetDevice(c->parts[c->root].device);
+        for (GroupSlot& G : c->gslots) {
+            if (G.frames) (void)hipFree(G.frames);
+            if (G.staging) (void)hipFree(G.staging);
+            if (G.frame_done) (void)hipEventDestroy(G.frame_done);
+            for (auto& e : G.tev) if (e) (void)hipEventDestroy(e);
+            for (auto& s : G.sky) if (s) (void)hipFree(s);
+        }
+        if (c->d_table) (void)hipFree(c->d_table);
+    }
+    for (CommRank& r : c->ranks) {
+        (void)hipSetDevice(r.device);
+        if (r.comm && R) (void)R->CommDestroy(r.comm);
+        if (r.stream) (void)hipStreamDestroy(r.stream);
+    }
+    if (c->wait_ev) (void)hipEventDestroy(c->wait_ev);
+}
+
+// destination of the frame about to be staged at (slot, sub): every local partition's output binding
+int bind_partitions(bhray_ctx* c, int si, uint32_t sub) {
+    GroupSlot& G = c->gslots[(size_t)si];
+    const size_t W = c->cfg.frame_w;
+    for (uint32_t q = 0; q < c->world; q++) {
+        Part& p = c->parts[q];
+        if (!p.dev) continue;
+        if (q == c->root) {
+            float4* dst = c->bound ? c->bound : G.frames + (size_t)sub * frame_pixels(c);
+            G.dst[sub] = dst;
+            DEV(c, p.dev, dev_bind_output(p.dev, dst, frame_pixels(c) * sizeof(float4)));
+        } else if (p.rows) {
+            DEV(c, p.dev, dev_bind_output(p.dev, G.send[q] + (size_t)sub * p.rows * W, (size_t)p.rows * W * sizeof(float4)));
+        }
+    }
+    c->bound = nullptr;
+    return BHRAY_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t bhray_partition_rows(uint32_t frame_h, uint32_t world, uint32_t stripe_rows, uint32_t part) {
+    if (world < 1 || stripe_rows < 1 || part >= world) return 0;
+    return part_rows(frame_h, world, stripe_rows, part);
+}
+
+int bhray_partition_row_index(uint32_t frame_h, uint32_t world, uint32_t stripe_rows, uint32_t part, uint32_t i, uint32_t* frame_row) {
+    if (!frame_row || world < 1 || stripe_rows < 1 || part >= world) return BHRAY_E_INVALID;
+    const uint64_t r = part_row(world, stripe_rows, part, i);
+    if (r >= frame_h) return BHRAY_E_INVALID;
+    *frame_row = (uint32_t)r;
+    return BHRAY_OK;
+}
+
+int bhray_comm_unique_id(uint8_t id[BHRAY_COMM_ID_BYTES]) {
+    if (!id) return BHRAY_E_INVALID;
+    Rccl* R = rccl();
+    if (!R) return gfail(nullptr, BHRAY_E_COMM, "%s", g_rccl.error.c_str());
+    ncclUniqueId u;
+    ncclResult_t r = R->GetUniqueId(&u);
+    if (r != ncclSuccess) return gfail(nullptr, BHRAY_E_COMM, "ncclGetUniqueId: %s", R->GetErrorString(r));
+    static_assert(sizeof(ncclUniqueId) == BHRAY_COMM_ID_BYTES, "ncclUniqueId size");
+    memcpy(id, u.internal, BHRAY_COMM_ID_BYTES);
+    return BHRAY_OK;
+}
+
+const char* bhray_last_error(const bhray_ctx* c) { return c ? c->err.c_str() : dev_last_error(nullptr); }
+
+void bhray_destroy(bhray_ctx* c) {
+    if (!c) return;
+    group_free(c);
+    delete c;
+}
+
+int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
+    if (!cfg || !out) return gfail(nullptr, BHRAY_E_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(bhray_config)) return gfail(nullptr, BHRAY_E_INVALID, "bhray_config.struct_size mismatch (%u, library expects %zu)", cfg->struct_size, sizeof(bhray_config));
+    if (cfg->device_count > BHRAY_MAX_DEVICES) return gfail(nullptr, BHRAY_E_INVALID, "device_count > %d", BHRAY_MAX_DEVICES);
+    if (cfg->gather > BHRAY_GATHER_RCCL) return gfail(nullptr, BHRAY_E_INVALID, "unknown gather mode %u", cfg->gather);
+    bhray_ctx* c = new (std::nothrow) bhray_ctx();
+    if (!c) return gfail(nullptr, BHRAY_E_NOMEM, "host allocation failed");
+    c->cfg = *cfg;
+    const bool multi_dev = cfg->device_count >= 2;                                   // one process, N GPUs
+    const bool multi_proc = !multi_dev && cfg->gather == BHRAY_GATHER_RCCL && cfg->row_world > 1;   // one process per GPU
+    c->gather = multi_dev || multi_proc;
+    c->single = !c->gather;
+#define FAIL(code, ...) do { int rc_ = gfail(nullptr, code, __VA_ARGS__); bhray_destroy(c); return rc_; } while (0)
+    if (c->single) {
+        bhray_config one = *cfg;
+        if (cfg->device_count == 1) one.device = cfg->devices[0];
+        c->parts.resize(1);
+        int rc = dev_create(&one, DevOptions(), &c->parts[0].dev);
+        if (rc) { bhray_destroy(c); return rc; }
+        c->parts[0].device = one.device;
+        c->cfg = one; c->cfg.device_count = cfg->device_count;
+        c->world = one.row_world ? one.row_world : 1;
+        *out = c;
+        return BHRAY_OK;
+    }
+    // ---- partitions
+    c->world = multi_dev ? cfg->device_count : cfg->row_world;
+    if (multi_dev && cfg->row_world > 1 && cfg->row_world != cfg->device_count) FAIL(BHRAY_E_INVALID, "row_world must be 0, 1 or device_count when device_count >= 2");
+    if (multi_proc && cfg->row_rank >= cfg->row_world) FAIL(BHRAY_E_INVALID, "bad row partition");
+    if (cfg->gather_root >= c->world) FAIL(BHRAY_E_INVALID, "gather_root %u is not a partition (%u partitions)", cfg->gather_root, c->world);
+    if (cfg->frame_w < 1 || cfg->frame_h < 1) FAIL(BHRAY_E_INVALID, "frame window outside the last level");
+    c->root = cfg->gather_root;
+    c->cfg.row_world = c->world;
+    const uint32_t stripe = cfg->stripe_rows ? cfg->stripe_rows : 27;
+    c->cfg.stripe_rows = stripe;
+    c->parts.resize(c->world);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) FAIL(BHRAY_E_NO_DEVICE, "no HIP device visible (libbhray has no CPU path)");
+    // ranks: distinct devices of this process in list order (one process per GPU: the launcher's rank)
+    std::vector<int> rank_dev;
+    for (uint32_t q = 0; q < c->world; q++) {
+        Part& p = c->parts[q];
+        p.rows = part_rows(cfg->frame_h, c->world, stripe, q);
+        if (multi_dev) {
+            if (cfg->devices[q] < 0 || cfg->devices[q] >= ndev) FAIL(BHRAY_E_NO_DEVICE, "device %d not present (%d visible)", cfg->devices[q], ndev);
+            p.device = cfg->devices[q];
+            int r = -1;
+            for (size_t k = 0; k < rank_dev.size(); k++) if (rank_dev[k] == p.device) r = (int)k;
+            if (r < 0) { r = (int)rank_dev.size(); rank_dev.push_back(p.device); }
+            p.rank = r;
+        } else {
+            p.rank = (int)q;
+            if (q == cfg->row_rank) {
+                const int d = cfg->device_count == 1 ? cfg->devices[0] : cfg->device;
+                if (d < 0 || d >= ndev) FAIL(BHRAY_E_NO_DEVICE, "device %d not present (%d visible)", d, ndev);
+                p.device = d;
+            }
+        }
+    }
+    c->comm_size = multi_dev ? (uint32_t)rank_dev.size() : c->world;
+    c->root_local = multi_dev || cfg->row_rank == c->root;
+    c->nslots = cfg->frames_in_flight ? cfg->frames_in_flight : 4;
+    c->B = cfg->frames_per_batch ? cfg->frames_per_batch : 1;
+    if (c->nslots > BHRAY_MAX_FRAMES_IN_FLIGHT) FAIL(BHRAY_E_INVALID, "frames_in_flight > %d", BHRAY_MAX_FRAMES_IN_FLIGHT);
+    if (c->B > BHRAY_MAX_FRAMES_PER_BATCH) FAIL(BHRAY_E_INVALID, "frames_per_batch > %d", BHRAY_MAX_FRAMES_PER_BATCH);
+    // ---- per-device engines
+    for (uint32_t q = 0; q < c->world; q++) {
+        Part& p = c->parts[q];
+        if (p.device < 0) continue;
+        bhray_config one = *cfg;
+        one.device = p.device; one.device_count = 0; one.gather = BHRAY_GATHER_NONE;
+        one.row_rank = q; one.row_world = c->world; one.stripe_rows = stripe;
+        DevOptions opt; opt.external_out = true; opt.frame_rowmap = (q == c->root);
+        int rc = dev_create(&one, opt, &p.dev);
+        if (rc) { bhray_destroy(c); return rc; }
+        if (dev_local_rows(p.dev) != p.rows) FAIL(BHRAY_E_STATE, "internal: partition %u has %u rows, expected %u", q, dev_local_rows(p.dev), p.rows);
+    }
+    // ---- communicator
+    Rccl* R = rccl();
+    if (!R) FAIL(BHRAY_E_COMM, "%s", g_rccl.error.c_str());
+#define CH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) FAIL(BHRAY_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
+#define CN(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) FAIL(BHRAY_E_COMM, "%s: %s", #call, R->GetErrorString(r_)); } while (0)
+    if (multi_dev) {
+        std::vector<ncclComm_t> comms(rank_dev.size(), nullptr);
+        CN(R->CommInitAll(comms.data(), (int)rank_dev.size(), rank_dev.data()));
+        for (size_t k = 0; k < rank_dev.size(); k++) { CommRank r; r.device = rank_dev[k]; r.rank = (int)k; r.comm = comms[k]; c->ranks.push_back(r); }
+    } else {
+        Part& me = c->parts[cfg->row_rank];
+        CH(hipSetDevice(me.device));
+        ncclUniqueId id; memcpy(id.internal, cfg->comm_id, BHRAY_COMM_ID_BYTES);
+        CommRank r; r.device = me.device; r.rank = (int)cfg->row_rank;
+        CN(R->CommInitRank(&r.comm, (int)c->world, id, (int)cfg->row_rank));
+        c->ranks.push_back(r);
+    }
+    for (CommRank& r : c->ranks) { CH(hipSetDevice(r.device)); CH(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking)); }
+    // ---- buffers
+    const size_t W = cfg->frame_w;
+    size_t row0 = 0;
+    std::vector<RowDesc> table;
+    for (uint32_t q = 0; q < c->world; q++) {
+        Part& p = c->parts[q];
+        if (q == c->root) continue;
+        p.stage_row0 = row0;
+        for (uint32_t i = 0; i < p.rows; i++) {
+            RowDesc d; d.src_row0 = (uint32_t)(row0 + i); d.part_rows = p.rows; d.frame_row = (uint32_t)part_row(c->world, stripe, q, i); d.pad = 0;
+            table.push_back(d);
+        }
+        row0 += (size_t)c->B * p.rows;
+    }
+    c->staging_rows = row0;
+    c->gslots.resize(c->nslots);
+    for (GroupSlot& G : c->gslots) {
+        memset(G.dst, 0, sizeof G.dst); memset(G.sky, 0, sizeof G.sky);
+        G.send.assign(c->world, nullptr); G.sent.assign(c->world, nullptr);
+        for (uint32_t q = 0; q < c->world; q++) {
+            Part& p = c->parts[q];
+            if (!p.dev || q == c->root) continue;
+            CH(hipSetDevice(p.device));
+            if (p.rows) { CH(hipMalloc(&G.send[q], (size_t)c->B * p.rows * W * sizeof(float4))); CH(hipMemset(G.send[q], 0xFF, (size_t)c->B * p.rows * W * sizeof(float4))); }
+            CH(hipEventCreateWithFlags(&G.sent[q], hipEventDisableTiming));
+        }
+        if (c->root_local) {
+            CH(hipSetDevice(c->parts[c->root].device));
+            CH(hipMalloc(&G.frames, (size_t)c->B * frame_pixels(c) * sizeof(float4)));
+            CH(hipMemset(G.frames, 0xFF, (size_t)c->B * frame_pixels(c) * sizeof(float4)));
+            if (c->staging_rows) CH(hipMalloc(&G.staging, c->staging_rows * W * sizeof(float4)));
+            CH(hipEventCreateWithFlags(&G.frame_done, hipEventDisableTiming));
+            if (cfg->flags & (BHRAY_F_TIMING | BHRAY_F_TIMING_SPARSE)) for (auto& e : G.tev) CH(hipEventCreate(&e));
+        }
+    }
+    if (c->root_local) {
+        CH(hipSetDevice(c->parts[c->root].device));
+        c->table_rows = (uint32_t)table.size();
+        if (!table.empty()) {
+            CH(hipMalloc(&c->d_table, table.size() * sizeof(RowDesc)));
+            CH(hipMemcpy(c->d_table, table.data(), table.size() * sizeof(RowDesc), hipMemcpyHostToDevice));
+        }
+    }
+#undef CH
+#undef CN
+#undef FAIL
+    *out = c;
+    return BHRAY_OK;
+}
+
+int bhray_get_gather_info(const bhray_ctx* c, bhray_gather_info* out) {
+    if (!c || !out) return BHRAY_E_INVALID;
+    memset(out, 0, sizeof *out);
+    out->partitions = c->world;
+    out->root = c->root;
+    const uint64_t rowb = (uint64_t)c->cfg.frame_w * 16u;
+    for (uint32_t q = 0; q < c->parts.size(); q++) {
+        const Part& p = c->parts[q];
+        if (p.dev) out->local_partitions++;
+        if (!c->gather) continue;
+        if (p.dev && q != c->root) out->bytes_sent_per_frame += p.rows * rowb;
+        if (c->root_local && q != c->root) out->bytes_received_per_frame += p.rows * rowb;
+    }
+    out->root_is_local = c->gather ? (c->root_local ? 1u : 0u) : 1u;
+    out->comm_ranks = c->gather ? c->comm_size : 0;
+    out->rccl_version = g_rccl.so ? (uint32_t)g_rccl.version : 0;
+    return BHRAY_OK;
+}
+
+// ---- scene state: replicated on every local partition ---------------------------------------
+int bhray_set_texture(bhray_ctx* c, int slot, const uint8_t* rgba8, uint32_t w, uint32_t h) {
+    if (!c) return BHRAY_E_INVALID;
+    if (c->gather) { int rc = group_sync(c); if (rc) return rc; }
+    for (Part& p : c->parts) if (p.dev) DEV(c, p.dev, dev_set_texture(p.dev, slot, rgba8, w, h));
+    return BHRAY_OK;
+}
+int bhray_upload_model_uniform(bhray_ctx* c, uint32_t mi, const void* bytes, size_t size) {
+    if (!c) return BHRAY_E_INVALID;
+    if (c->gather) { int rc = group_sync(c); if (rc) return rc; }
+    for (Part& p : c->parts) if (p.dev) DEV(c, p.dev, dev_upload_model_uniform(p.dev, mi, bytes, size));
+    return BHRAY_OK;
+}
+int bhray_upload_model(bhray_ctx* c, uint32_t mi, const bhray_model_desc* d) {
+    if (!c) return BHRAY_E_INVALID;
+    if (c->gather) { int rc = group_sync(c); if (rc) return rc; }
+    for (Part& p : c->parts) if (p.dev) DEV(c, p.dev, dev_upload_model(p.dev, mi, d));
+    return BHRAY_OK;
+}
+int bhray_set_model_transform(bhray_ctx* c, uint32_t mi, const float position[3], int32_t visible) {
+    if (!c) return BHRAY_E_INVALID;
+    for (Part& p : c->parts) if (p.dev) DEV(c, p.dev, dev_set_model_transform(p.dev, mi, position, visible));
+    return BHRAY_OK;
+}
+int bhray_set_materials(bhray_ctx* c, const void* bytes, size_t size) {
+    if (!c) return BHRAY_E_INVALID;
+    if (!bytes || size != 16u * BHRAY_MAX_MATERIALS) return gfail(c, BHRAY_E_INVALID, "materials must be %u bytes (MaterialUniform x %d)", 16u * BHRAY_MAX_MATERIALS, BHRAY_MAX_MATERIALS);
+    return BHRAY_OK;                      // bound at binding 3, never read by the shader (ray.wgsl:8)
+}
+int bhray_set_uniforms(bhray_ctx* c, const void* cam32, const void* bh132, const void* det32) {
+    if (!c) return BHRAY_E_INVALID;
+    for (Part& p : c->parts) if (p.dev) DEV(c, p.dev, dev_set_uniforms(p.dev, cam32, bh132, det32));
+    return BHRAY_OK;
+}
+
+// ---- dispatch --------------------------------------------------------------------------------
+int bhray_render(bhray_ctx* c) {
+    if (!c) return BHRAY_E_INVALID;
+    if (c->single) {
+        bhray_dev* d = c->parts[0].dev;
+        if (c->bound) { DEV(c, d, dev_bind_output(d, c->bound, (size_t)-1)); c->bound = nullptr; }
+        DEV(c, d, dev_render(d));
+        c->rendered = true;
+        return BHRAY_OK;
+    }
+    // staged frames of another kernel variant are launched (and gathered) first: the staging position is then final
+    int si = -1; uint32_t sub = 0;
+    for (Part& p : c->parts) {
+        if (!p.dev) continue;
+        int s; uint32_t k;
+        DEV(c, p.dev, dev_next_position(p.dev, &s, &k));
+        if (si >= 0 && (s != si || k != sub)) return gfail(c, BHRAY_E_STATE, "internal: partitions out of step");
+        si = s; sub = k;
+    }
+    { int rc = after_launch(c); if (rc) return rc; }
+    { int rc = bind_partitions(c, si, sub); if (rc) return rc; }
+    for (Part& p : c->parts) if (p.dev) DEV(c, p.dev, dev_render(p.dev));
+    c->last_slot = si; c->last_sub = sub; c->rendered = true;
+    return after_launch(c);
+}
+
+int bhray_flush(bhray_ctx* c) {
+    if (!c) return BHRAY_E_INVALID;
+    if (c->single) { DEV(c, c->parts[0].dev, dev_flush(c->parts[0].dev)); return BHRAY_OK; }
+    return group_flush(c);
+}
+
+int bhray_sync(bhray_ctx* c) {
+    if (!c) return BHRAY_E_INVALID;
+    if (c->single) { DEV(c, c->parts[0].dev, dev_sync(c->parts[0].dev)); return BHRAY_OK; }
+    return group_sync(c);
+}
+
+// ---- output ----------------------------------------------------------------------------------
+uint32_t bhray_local_rows(const bhray_ctx* c) {
+    if (!c) return 0;
+    if (c->single) return dev_local_rows(c->parts[0].dev);
+    return c->root_local ? c->cfg.frame_h : 0;
+}
+
+int bhray_local_row_index(const bhray_ctx* c, uint32_t i, uint32_t* frame_row) {
+    if (!c || !frame_row) return BHRAY_E_INVALID;
+    if (c->single) return dev_local_row_index(c->parts[0].dev, i, frame_row);
+    if (!c->root_local || i >= c->cfg.frame_h) return BHRAY_E_INVALID;
+    *frame_row = i;
+    return BHRAY_OK;
+}
+
+int bhray_read_hdr(bhray_ctx* c, float* dst, size_t pitch) {
+    if (!c) return BHRAY_E_INVALID;
+    if (c->single) { DEV(c, c->parts[0].dev, dev_read_hdr(c->parts[0].dev, dst, pitch)); return BHRAY_OK; }
+    { int rc = group_sync(c); if (rc) return rc; }
+    if (!c->root_local) return BHRAY_OK;                        // the frame lives on another rank
+    if (!c->rendered) return gfail(c, BHRAY_E_STATE, "nothing rendered yet");
+    const size_t rowb = (size_t)c->cfg.frame_w * sizeof(float4);
+    if (!dst || pitch < rowb) return gfail(c, BHRAY_E_INVALID, "bad destination / pitch");
+    GHIP(c, hipSetDevice(root_part(c)->device));
+    GHIP(c, hipMemcpy2D(dst, pitch, c->gslots[(size_t)c->last_slot].dst[c->last_sub], rowb, rowb, c->cfg.frame_h, hipMemcpyDeviceToHost));
+    return BHRAY_OK;
+}
+
+int bhray_read_level(bhray_ctx* c, uint32_t level, float* dst, size_t pitch) {
+    if (!c) return BHRAY_E_INVALID;
+    if (c->single) { DEV(c, c->parts[0].dev, dev_read_level(c->parts[0].dev, level, dst, pitch)); return BHRAY_OK; }
+    // every partition computed the level rows its stripes depend on: overlay them (unrendered pixels are NaN-filled; pixels
+    // computed by several partitions are identical)
+    if (level >= c->cfg.levels) return gfail(c, BHRAY_E_INVALID, "level out of range");
+    { int rc = group_sync(c); if (rc) return rc; }
+    const size_t w = c->cfg.level_w[level], h = c->cfg.level_h[level], rowb = w * sizeof(float4);
+    if (!dst || pitch < rowb) return gfail(c, BHRAY_E_INVALID, "bad destination / pitch");
+    for (size_t y = 0; y < h; y++) memset((uint8_t*)dst + y * pitch, 0xFF, rowb);
+    std::vector<uint32_t> tmp(w * h * 4);
+    const bool last = level + 1 == c->cfg.levels;
+    for (uint32_t q = 0; q < c->world; q++) {
+        Part& p = c->parts[q];
+        if (!p.dev) continue;
+        if (last) {
+            // a partition's last-level image is its output binding: the root's is the assembled frame, read through the ctx
+            if (q != c->root) continue;
+            std::vector<float> fr(frame_pixels(c) * 4);
+            int rc = bhray_read_hdr(c, fr.data(), (size_t)c->cfg.frame_w * 16);
+            if (rc) return rc;
+            for (size_t y = 0; y < c->cfg.frame_h; y++)
+                memcpy((uint8_t*)dst + (y + c->cfg.crop_y) * pitch + (size_t)c->cfg.crop_x * 16, fr.data() + y * c->cfg.frame_w * 4, (size_t)c->cfg.frame_w * 16);
+            continue;
+        }
+        DEV(c, p.dev, dev_read_level(p.dev, level, (float*)tmp.data(), rowb));
+        for (size_t y = 0; y < h; y++) {
+            const uint32_t* s = tmp.data() + y * w * 4;
+            uint32_t* d = (uint32_t*)((uint8_t*)dst + y * pitch);
+            for (size_t x = 0; x < w; x++) {
+                const uint32_t* px = s + 4 * x;
+                if (px[0] == 0xFFFFFFFFu && px[1] == 0xFFFFFFFFu && px[2] == 0xFFFFFFFFu && px[3] == 0xFFFFFFFFu) continue;
+                memcpy(d + 4 * x, px, 16);
+            }
+        }
+    }
+    return BHRAY_OK;
+}
+
+int bhray_hdr_device_ptr(bhray_ctx* c, void** p, size_t* bytes) {
+    if (!c || !p) return BHRAY_E_INVALID;
+    if (c->single) { DEV(c, c->parts[0].dev, dev_hdr_device_ptr(c->parts[0].dev, p, bytes)); return BHRAY_OK; }
+    *p = c->root_local ? (void*)c->gslots[(size_t)c->last_slot].dst[c->last_sub] : nullptr;
+    if (bytes) *bytes = c->root_local ? frame_pixels(c) * sizeof(float4) : 0;
+    return BHRAY_OK;
+}
+
+int bhray_bind_output(bhray_ctx* c, void* p, size_t bytes) {
+    if (!c) return BHRAY_E_INVALID;
+    if (!p) { c->bound = nullptr; return BHRAY_OK; }
+    size_t need;
+    if (c->single) { void* q; DEV(c, c->parts[0].dev, dev_hdr_device_ptr(c->parts[0].dev, &q, &need)); }
+    else need = c->root_local ? frame_pixels(c) * sizeof(float4) : 0;
+    if (bytes < need) return gfail(c, BHRAY_E_INVALID, "output binding needs %zu bytes", need);
+    if (((uintptr_t)p & 15u) != 0) return gfail(c, BHRAY_E_INVALID, "output binding must be 16-byte aligned");
+    c->bound = (float4*)p;
+    return BHRAY_OK;
+}
+
+// ---- ordering against caller streams ------------------------------------------------------------
+int bhray_wait_stream(bhray_ctx* c, void* s) {
+    if (!c) return BHRAY_E_INVALID;
+    const int dev = c->single ? c->parts[0].device : (c->root_local ? root_part(c)->device : c->ranks[0].device);
+    GHIP(c, hipSetDevice(dev));
+    if (!c->wait_ev) GHIP(c, hipEventCreateWithFlags(&c->wait_ev, hipEventDisableTiming));
+    GHIP(c, hipEventRecord(c->wait_ev, (hipStream_t)s));
+    for (Part& p : c->parts) if (p.dev) DEV(c, p.dev, dev_wait_event(p.dev, c->wait_ev));
+    return BHRAY_OK;
+}
+
+int bhray_next_stream(bhray_ctx* c, void** s) {
+    if (!c || !s) return BHRAY_E_INVALID;
+    if (c->single) { DEV(c, c->parts[0].dev, dev_next_stream(c->parts[0].dev, s)); return BHRAY_OK; }
+    CommRank* rr = c->root_local ? rank_of(c, *root_part(c)) : &c->ranks[0];
+    *s = (void*)rr->stream;               // the gather and the de-interleave of every batch run on this stream
+    return BHRAY_OK;
+}
+
+int bhray_signal_stream(bhray_ctx* c, void* s) {
+    if (!c) return BHRAY_E_INVALID;
+    if (c->single) { DEV(c, c->parts[0].dev, dev_signal_stream(c->parts[0].dev, s)); return BHRAY_OK; }
+    if (!c->rendered) return BHRAY_OK;
+    { int rc = group_flush(c); if (rc) return rc; }
+    if (c->root_local) {
+        GHIP(c, hipSetDevice(root_part(c)->device));
+        GHIP(c, hipStreamWaitEvent((hipStream_t)s, c->gslots[(size_t)c->last_slot].frame_done, 0));
+    } else {
+        const Part& me = c->parts[c->cfg.row_rank];
+        GHIP(c, hipSetDevice(me.device));
+        GHIP(c, hipStreamWaitEvent((hipStream_t)s, c->gslots[(size_t)c->last_slot].sent[c->cfg.row_rank], 0));
+    }
+    return BHRAY_OK;
+}
+
+// ---- sky resolve -----------------------------------------------------------------------------------
+int bhray_resolve_sky(bhray_ctx* c) {
+    if (!c) return BHRAY_E_INVALID;
+    if (c->single) { DEV(c, c->parts[0].dev, dev_resolve_sky(c->parts[0].dev)); return BHRAY_OK; }
+    if (!c->rendered) return gfail(c, BHRAY_E_STATE, "nothing rendered yet");
+    { int rc = group_flush(c); if (rc) return rc; }
+    if (!c->root_local) return BHRAY_OK;
+    Part& rp = *root_part(c);
+    CommRank* rr = rank_of(c, rp);
+    GroupSlot& G = c->gslots[(size_t)c->last_slot];
+    GHIP(c, hipSetDevice(rp.device));
+    if (!G.sky[c->last_sub]) GHIP(c, hipMalloc(&G.sky[c->last_sub], frame_pixels(c) * sizeof(uint2)));
+    DEV(c, rp.dev, dev_launch_sky(rp.dev, G.dst[c->last_sub], G.sky[c->last_sub], frame_pixels(c), rr->stream));   // behind the de-interleave
+    GHIP(c, hipEventRecord(G.frame_done, rr->stream));
+    return BHRAY_OK;
+}
+
+int bhray_read_sky(bhray_ctx* c, uint16_t* dst, size_t pitch) {
+    if (!c) return BHRAY_E_INVALID;
+    if (c->single) { DEV(c, c->parts[0].dev, dev_read_sky(c->parts[0].dev, dst, pitch)); return BHRAY_OK; }
+    { int rc = group_sync(c); if (rc) return rc; }
+    if (!c->root_local) return BHRAY_OK;
+    const size_t rowb = (size_t)c->cfg.frame_w * sizeof(uint2);
+    if (!dst || pitch < rowb) return gfail(c, BHRAY_E_INVALID, "bad destination / pitch");
+    uint2* src = c->gslots[(size_t)c->last_slot].sky[c->last_sub];
+    if (!src) return gfail(c, BHRAY_E_STATE, "bhray_resolve_sky has not been called for this frame");
+    GHIP(c, hipSetDevice(root_part(c)->device));
+    GHIP(c, hipMemcpy2D(dst, pitch, src, rowb, rowb, c->cfg.frame_h, hipMemcpyDeviceToHost));
+    return BHRAY_OK;
+}
+
+int bhray_sky_device_ptr(bhray_ctx* c, void** p, size_t* bytes) {
+    if (!c || !p) return BHRAY_E_INVALID;
+    if (c->single) { DEV(c, c->parts[0].dev, dev_sky_device_ptr(c->parts[0].dev, p, bytes)); return BHRAY_OK; }
+    *p = c->root_local ? (void*)c->gslots[(size_t)c->last_slot].sky[c->last_sub] : nullptr;
+    if (bytes) *bytes = c->root_local ? frame_pixels(c) * sizeof(uint2) : 0;
+    return BHRAY_OK;
+}
+
+// ---- measurement -------------------------------------------------------------------------------------
+int bhray_selftest(bhray_ctx* c, uint64_t mismatches[3]) {
+    if (!c || !mismatches) return BHRAY_E_INVALID;
+    uint64_t sum[3] = {0, 0, 0};
+    for (Part& p : c->parts) {
+        if (!p.dev) continue;
+        uint64_t m[3];
+        DEV(c, p.dev, dev_selftest(p.dev, m));
+        for (int k = 0; k < 3; k++) sum[k] += m[k];
+    }
+    for (int k = 0; k < 3; k++) mismatches[k] = sum[k];
+    return BHRAY_OK;
+}
+
+int bhray_get_level_counters(bhray_ctx* c, uint32_t level, bhray_counters* out) {
+    if (!c || !out) return BHRAY_E_INVALID;
+    if (c->gather) { int rc = group_sync(c); if (rc) return rc; }
+    memset(out, 0, sizeof *out);
+    for (Part& p : c->parts) {                                   // local partitions only: whole-frame work = sum over all
+        if (!p.dev) continue;
+        bhray_counters t;
+        DEV(c, p.dev, dev_get_level_counters(p.dev, level, &t));
+        const uint64_t* a = (const uint64_t*)&t; uint64_t* b = (uint64_t*)out;
+        for (size_t k = 0; k < sizeof(bhray_counters) / 8; k++) { if (k == 12) b[k] = a[k] > b[k] ? a[k] : b[k]; else b[k] += a[k]; }   // [12] max_ray_iterations
+    }
+    return BHRAY_OK;
+}
+
+int bhray_get_counters(bhray_ctx* c, bhray_counters* out) {
+    if (!c || !out) return BHRAY_E_INVALID;
+    memset(out, 0, sizeof *out);
+    for (uint32_t l = 0; l < c->cfg.levels; l++) {
+        bhray_counters t;
+        int rc = bhray_get_level_counters(c, l, &t);
+        if (rc) return rc;
+        const uint64_t* a = (const uint64_t*)&t; uint64_t* b = (uint64_t*)out;
+        for (size_t k = 0; k < sizeof(bhray_counters) / 8; k++) { if (k == 12) b[k] = a[k] > b[k] ? a[k] : b[k]; else b[k] += a[k]; }   // [12] max_ray_iterations
+    }
+    return BHRAY_OK;
+}
+
+int bhray_get_timing(bhray_ctx* c, bhray_timing* out) {
+    if (!c || !out) return BHRAY_E_INVALID;
+    if (c->single) { DEV(c, c->parts[0].dev, dev_get_timing(c->parts[0].dev, out)); return BHRAY_OK; }
+    if (!(c->cfg.flags & (BHRAY_F_TIMING | BHRAY_F_TIMING_SPARSE))) return gfail(c, BHRAY_E_STATE, "ctx created without BHRAY_F_TIMING");
+    { int rc = group_sync(c); if (rc) return rc; }
+    // kernel times: the root partition's (or this rank's) launches; gather: the root's communication stream
+    Part* src = c->root_local ? root_part(c) : &c->parts[c->cfg.row_rank];
+    for (Part& p : c->parts) {
+        if (!p.dev) continue;
+        bhray_timing t;
+        DEV(c, p.dev, dev_get_timing(p.dev, &t));               // resets every partition's aggregation
+        if (&p == src) *out = t;
+    }
+    if (c->root_local) {
+        GHIP(c, hipSetDevice(root_part(c)->device));
+        for (GroupSlot& G : c->gslots) {
+            if (!G.timed) continue;
+            float a = 0, b = 0;
+            GHIP(c, hipEventElapsedTime(&a, G.tev[0], G.tev[1])); GHIP(c, hipEventElapsedTime(&b, G.tev[1], G.tev[2]));
+            c->gather_ms += a; c->deint_ms += b; G.timed = false;
+        }
+    }
+    out->gather_ms = c->gather_ms; out->deinterleave_ms = c->deint_ms; out->gathers = c->gathers;
+    c->gather_ms = 0; c->deint_ms = 0; c->gathers = 0;
+    return BHRAY_OK;
+}
+
+}  // extern "C"

@@ -591,20 +591,18 @@ __device__ __forceinline__ float4 load_prev(const LevelParams& L, int x, int y) 
 // [-1, 1] (checked exhaustively: bhray_selftest), so  bh_acos(c) < thr  <=>  c > cstar  for the host-computed
 // cstar = largest c with bh_acos(c) >= thr (FrameParams::acos_cstar); c outside [-1, 1] or NaN gives acos = NaN = "not smaller",
 // as before.  Same decisions, 4 x ~60 instructions less per classified pixel; the square roots use the exact short sequence (N8).
-__device__ __forceinline__ float angle_cosine(float4 a, float4 b) {
+__device__ __forceinline__ bool angle_below_threshold(float4 a, float4 b, float cstar) {
     F3 v1 = f3(a.x, a.y, a.z), v2 = f3(b.x, b.y, b.z);
     float d = dot(v1, v2);
-    return d / (sqrt_rn(dot(v1, v1)) * sqrt_rn(dot(v2, v2)));
+    float c = d / (sqrt_rn(dot(v1, v1)) * sqrt_rn(dot(v2, v2)));
+    return c > cstar && c <= 1.0f;
 }
-__device__ __forceinline__ bool cosine_below_threshold(float c, float cstar) { return c > cstar && c <= 1.0f; }
 __device__ __forceinline__ size_t out_index(const LevelParams& L, int x, int y) {
     const int oy = L.rowmap ? L.rowmap[y] : y;
     return (size_t)oy * (size_t)L.out_pitch + (size_t)(x - L.out_x0);
 }
 
-// FIXUP: the exact per-level classification of the temporal mode (LevelParams::pass == CLASSIFY_FIXUP), its own instantiation so that
-// the other passes keep their short-circuited angle tests (the merged kernel cost the saturated pass 2 %).
-template <bool COUNT, bool FIXUP>
+template <bool COUNT>
 __global__ __launch_bounds__(BHRAY_CLASSIFY_THREADS) void classify_kernel(const FrameParams* __restrict__ Pb, const FrameLaunch* __restrict__ Fb) {
     __shared__ uint32_t append_lds[BHRAY_CLASSIFY_TILES];
     const FrameParams& P = Pb[blockIdx.y];
@@ -625,7 +623,6 @@ __global__ __launch_bounds__(BHRAY_CLASSIFY_THREADS) void classify_kernel(const 
     const bool valid = classify_pixel(L, (int)blockIdx.x, wave, t, lane, x, j);
     const int y = valid ? L.rows[j] : 0;
     bool need_trace = false;
-    bool near_trace = false;                         // interpolated, but within the temporal margin of being traced
     int kind = -1;                                   // 0 copy, 1 interpolate, 2 trace
     if (valid) {
         if (L.pw == 1 && L.ph == 1) {
@@ -647,15 +644,8 @@ __global__ __launch_bounds__(BHRAY_CLASSIFY_THREADS) void classify_kernel(const 
                 bool interp = false;
                 if (alphas0) {                       // a PENDING neighbour (alpha 2) fails this test: the pixel is queued, conservatively
                     const float cs = P.acos_cstar;
-                    if (FIXUP) {      // temporal mode also wants to know how close an interpolated pixel came to being traced
-                        const float cn = P.acos_cstar_near;
-                        const float c0 = angle_cosine(c_bl, c_tl), c1 = angle_cosine(c_br, c_tr), c2 = angle_cosine(c_tl, c_tr), c3 = angle_cosine(c_bl, c_br);
-                        interp = cosine_below_threshold(c0, cs) && cosine_below_threshold(c1, cs) && cosine_below_threshold(c2, cs) && cosine_below_threshold(c3, cs);
-                        near_trace = interp && !(cosine_below_threshold(c0, cn) && cosine_below_threshold(c1, cn) && cosine_below_threshold(c2, cn) && cosine_below_threshold(c3, cn));
-                    } else {
-                        interp = cosine_below_threshold(angle_cosine(c_bl, c_tl), cs) && cosine_below_threshold(angle_cosine(c_br, c_tr), cs) &&
-                                 cosine_below_threshold(angle_cosine(c_tl, c_tr), cs) && cosine_below_threshold(angle_cosine(c_bl, c_br), cs);
-                    }
+                    interp = angle_below_threshold(c_bl, c_tl, cs) && angle_below_threshold(c_br, c_tr, cs) &&
+                             angle_below_threshold(c_tl, c_tr, cs) && angle_below_threshold(c_bl, c_br, cs);
                 }
                 if (interp) {
                     const float tx_ = ppx - tlx, ty_ = ppy - tly;
@@ -676,10 +666,10 @@ __global__ __launch_bounds__(BHRAY_CLASSIFY_THREADS) void classify_kernel(const 
             need_trace = false;
         }
     }
-    if (FIXUP) {
+    if (L.pass == CLASSIFY_FIXUP) {
         // temporal speculation: remember, per pixel, whether the shader traces it (the next frame's prediction is built from these
         // marks, predict_kernel), and send to this frame's own queue only what the predicted launch has not delivered (stamp)
-        if (valid) F.need[(size_t)y * (size_t)L.w + (size_t)x] = (need_trace || near_trace) ? 1 : 0;
+        if (valid) F.need[(size_t)y * (size_t)L.w + (size_t)x] = need_trace ? 1 : 0;
         if (need_trace && F.stamp[(size_t)y * (size_t)L.w + (size_t)x] == F.stamp_value) need_trace = false;
     }
     want[t] = need_trace;
@@ -700,9 +690,6 @@ __global__ __launch_bounds__(BHRAY_CLASSIFY_THREADS) void classify_kernel(const 
 // trace: ray.wgsl:269-285 + 482-596
 // ------------------------------------------------------------------------------------------
 enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, M_SHADE_FLAT = 5 };   // M_SHADE_x: a disk hit waits for its shading, then continues in mode x
-#ifndef BHRAY_THIN_WAVES
-#define BHRAY_THIN_WAVES 1024    // latency build: a short queue is dealt out evenly over this many waves (MI355X: 256 CUs x 4 SIMDs); 0 = off
-#endif
 #ifndef BHRAY_REL_BATCH
 #define BHRAY_REL_BATCH 16       // integrator steps between refill / flat / epilogue phases
 #endif
@@ -823,20 +810,6 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
     // in the latency build and in launches the host expects to be nearly empty (probe_empty): in the dense build even the untaken
     // branch costs a saturated device 2 % (measured: 4 930 -> 4 835 Mrays/s).
     if (!DENSE && F.probe_empty && __hip_atomic_load(qhead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= qcount) continue;
-    // Latency build, a queue with fewer rays than one wave per SIMD has lanes (coarse ladder levels, fix-up launches): the rays are dealt
-    // out evenly over the first BHRAY_THIN_WAVES waves (one per SIMD: the first blocks of a grid land on different CUs) - wave w takes
-    // entries [w * share, (w + 1) * share) once, without an atomic - instead of 64 to each of the first waves.  (Over ALL waves of the
-    // grid, four per SIMD, the waves hold each other up: level 0+1 0.333 -> 0.374 ms.)
-    // Such a launch lasts as long as its longest ray, and what that ray pays per iteration is what its wave executes: with 63
-    // lane-mates nearly every iteration includes the step-size power and the hit tests (one lane of 64 suffices), with a few
-    // lane-mates mostly only what the ray itself needs.  Scheduling only: every ray is the same sequence of operations.
-    uint32_t thin_share = 0;
-    if (!DENSE && BHRAY_THIN_WAVES > 0) {
-        const uint32_t total = gridDim.x * (BHRAY_TRACE_THREADS / 64);
-        const uint32_t waves = total < (uint32_t)BHRAY_THIN_WAVES ? total : (uint32_t)BHRAY_THIN_WAVES;
-        const uint32_t share = (qcount + waves - 1) / waves;
-        if (share < 64u) thin_share = share > 0u ? share : 1u;
-    }
     const HotParams H = load_hot(P);
     const F3 bpos = H.bh;
     const float t_max = 1e5f, t_min = 1e-8f;
@@ -874,20 +847,13 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
         {
             const unsigned long long need = __ballot(mode == M_EMPTY);
             if (need != 0ull && !exhausted && (BHRAY_REFILL_MIN <= 1 || __popcll(need) >= BHRAY_REFILL_MIN || !__any(mode == M_REL))) {
-                uint32_t n = (uint32_t)__popcll(need);
+                const uint32_t n = (uint32_t)__popcll(need);
                 uint32_t base = 0;
-                if (!DENSE && thin_share != 0u) {                 // this wave's share, once (all lanes are empty: n == 64 > share)
-                    n = thin_share;
-                    base = (blockIdx.x * (BHRAY_TRACE_THREADS / 64) + (threadIdx.x >> 6)) * thin_share;
-                    exhausted = true;
-                } else {
-                    if (lane == (int)__builtin_ctzll(need)) base = atomicAdd(qhead, n);
-                    base = (uint32_t)__shfl((int)base, (int)__builtin_ctzll(need));
-                    if (base + n >= qcount) exhausted = true;
-                }
-                const uint32_t rank = lanes_below(need);
-                const uint32_t idx = base + rank;
-                if (mode == M_EMPTY && (DENSE || rank < n) && idx < qcount) {
+                if (lane == (int)__builtin_ctzll(need)) base = atomicAdd(qhead, n);
+                base = (uint32_t)__shfl((int)base, (int)__builtin_ctzll(need));
+                if (base + n >= qcount) exhausted = true;
+                const uint32_t idx = base + lanes_below(need);
+                if (mode == M_EMPTY && idx < qcount) {
                     const uint32_t pix = queue[idx];
                     cold.set_pix(pix);
                     const int px = (int)(pix & 0x7fffu), py = (int)((pix >> 15) & 0x7fffu);
@@ -1357,12 +1323,8 @@ __global__ __launch_bounds__(BHRAY_CLASSIFY_THREADS) void predict_kernel(const F
             if (!(L.pw == 1 && L.ph == 1)) {
                 const float ppx = (float)x * L.rx, ppy = (float)y * L.ry;
                 copy = fabsf(floorf(ppx) - ppx) < 0.001f && fabsf(floorf(ppy) - ppy) < 0.001f;      // ray.wgsl:193: copied, never traced
-                // A pixel of the level's last column / row interpolates between a coarse pixel and ITSELF (the neighbour index clamps,
-                // ray.wgsl:196-199): the shader's test is then acos(v.v / (|v| |v|)) < threshold, and whether that quotient rounds to 1
-                // or to 1 + ulp (acos = NaN: "trace") depends on the last bits of v - it flips with any camera motion.  Always predicted.
-                if (!copy && ((int)floorf(ppx) + 1 > L.pw - 1 || (int)floorf(ppy) + 1 > L.ph - 1)) predict = true;
             }
-            if (!copy && !predict) {
+            if (!copy) {
                 const int r = F.radius;
                 const int xa = x - r < 0 ? 0 : x - r, xb = x + r > L.w - 1 ? L.w - 1 : x + r;
                 const int ya = y - r < 0 ? 0 : y - r, yb = y + r > L.h - 1 ? L.h - 1 : y + r;
@@ -1401,17 +1363,11 @@ hipError_t launch_upload(const void* pinned_src, void* dst, size_t n16, uint32_t
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-hipError_t launch_classify(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int blocks, bool count, bool fixup, hipStream_t s) {
+hipError_t launch_classify(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int blocks, bool count, hipStream_t s) {
     if (blocks <= 0 || nb <= 0) return hipSuccess;
     (void)hipGetLastError();
-    const dim3 g(blocks, nb), b(BHRAY_CLASSIFY_THREADS);
-    if (fixup) {
-        if (count) hipLaunchKernelGGL((classify_kernel<true, true>), g, b, 0, s, Pb, Fb);
-        else hipLaunchKernelGGL((classify_kernel<false, true>), g, b, 0, s, Pb, Fb);
-    } else {
-        if (count) hipLaunchKernelGGL((classify_kernel<true, false>), g, b, 0, s, Pb, Fb);
-        else hipLaunchKernelGGL((classify_kernel<false, false>), g, b, 0, s, Pb, Fb);
-    }
+    if (count) hipLaunchKernelGGL(classify_kernel<true>, dim3(blocks, nb), dim3(BHRAY_CLASSIFY_THREADS), 0, s, Pb, Fb);
+    else hipLaunchKernelGGL(classify_kernel<false>, dim3(blocks, nb), dim3(BHRAY_CLASSIFY_THREADS), 0, s, Pb, Fb);
     return hipGetLastError();
 }
 
