@@ -831,7 +831,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
     // lane-mates nearly every iteration includes the step-size power and the hit tests (one lane of 64 suffices), with a few
     // lane-mates mostly only what the ray itself needs.  Scheduling only: every ray is the same sequence of operations.
     uint32_t thin_share = 0;
-    if (!DENSE && BHRAY_THIN_WAVES > 0) {
+    if (!DENSE && nb == 1 && BHRAY_THIN_WAVES > 0) {      // (a batch: a wave would finish its share of one frame before it starts the next)
         const uint32_t total = gridDim.x * (BHRAY_TRACE_THREADS / 64);
         const uint32_t waves = total < (uint32_t)BHRAY_THIN_WAVES ? total : (uint32_t)BHRAY_THIN_WAVES;
         const uint32_t share = (qcount + waves - 1) / waves;
