@@ -20,6 +20,7 @@
 // explicit fused forms of N7, so results are bit-identical to the CPU oracle except for the shading-only optical-depth
 // powf(.,1.3) (device libm, 1-2 ulp, not amplified).
 #include <hip/hip_fp16.h>
+#include <type_traits>
 
 #include "bhray_internal.h"
 #include "bhray_math.h"
@@ -765,6 +766,9 @@ template <> struct ColdState<true> {
     __device__ __forceinline__ void set_pend_t(float v) { b[7 * S] = v; }
 };
 
+#ifdef BHRAY_EXP_PROFILE
+__device__ long long xp_dump[8192 * 16];
+#endif
 template <int METHOD, bool MODELS, bool COUNT, bool DENSE, bool LIT = false>
 __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHRAY_TRACE_WAVES_DENSE : BHRAY_TRACE_WAVES)) void trace_kernel(const FrameParams* __restrict__ Pb, const FrameLaunch* __restrict__ Fb, const int nb, int* __restrict__ err_flag) {
     const int lane = threadIdx.x & 63;
@@ -853,7 +857,9 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
     float cpos_dist = P.ray_distance_f;   // flength(cpos - bpos): equals dist_c except in RK mode after a hit moved cpos
     F3 qrel = f3(0, 0, 0);                // integrator position - bpos (the operand of dist_c), carried with it: the next step's q0
     int it = 0;
-    bool hit = false;
+    // "a hit happened" (0 / 1).  As a bool it lives in an SGPR pair and costs three scalar operations at every control-flow join of the
+    // step loop, taken or not - the latency build keeps it in a VGPR; the dense build has no VGPR to spare (80: 6 waves per SIMD).
+    typename std::conditional<COLD_LDS, bool, int>::type hit = 0;
     bool exhausted = false;
     int flat_round = 0;
     unsigned long long cnt[13];           // [0..9] = bhray_counters' frame counters, [10] wave steps (lane 0), [11] rays adopted, [12] longest ray
@@ -864,6 +870,9 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
 #define XP(k, active) { const long long now_ = clock64(); xp_t[k] += now_ - xp_last; xp_last = now_; xp_c[k] += (active) ? 1 : 0; }
 #else
 #define XP(k, active)
+#endif
+#ifdef BHRAY_EXP_PROFILE_FINE
+    long long xf_prev = clock64(), xf_loop = 0, xf_step = 0, xf_cull = 0, xf_tail = 0;
 #endif
     for (;;) {
 #ifdef BHRAY_EXP_PROFILE
@@ -911,7 +920,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                     rkpos = cam; rkdir = rdir; rkh = P.step_size;
                     cold.set_color(f3(0, 0, 0)); amount = 1.0f; closest = H.ray_distance;
                     dist_c = P.ray_distance_f; cpos_dist = P.ray_distance_f; qrel = cam - bpos;
-                    it = 0; hit = false;
+                    it = 0; hit = 0;
                     mode = P.relativity0 ? M_REL : M_FLAT;
                     if (COUNT) cnt[3]++;
                 }
@@ -957,7 +966,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                             cold.set_pend_t(sp[32 * MB_CAP]);
                             cold.set_pix(__float_as_uint(sp[33 * MB_CAP]));
                             const int mh = __float_as_int(sp[34 * MB_CAP]);
-                            mode = mh & 0xff; hit = (mh >> 8) != 0;
+                            mode = mh & 0xff; hit = (mh >> 8) != 0 ? 1 : 0;
                             it = __float_as_int(sp[35 * MB_CAP]);
                             if (COUNT) cnt[11]++;
                         }
@@ -1036,7 +1045,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                 const F3 cc = f3(clamp_(crs.color.x, 0.0f, 1.0f), clamp_(crs.color.y, 0.0f, 1.0f), clamp_(crs.color.z, 0.0f, 1.0f));
                 cold.set_color(cold.color() + cc * (amount * crs.opacity));
                 amount *= 1.0f - crs.opacity;
-                hit = true;
+                hit = 1;
                 if (amount < 0.005f) mode = M_FINISH;
                 else { it++; mode = (mode == M_SHADE_FLAT) ? M_FLAT : M_REL; }
             }
@@ -1105,7 +1114,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                             const F3 cc = f3(clamp_(crs.color.x, 0.0f, 1.0f), clamp_(crs.color.y, 0.0f, 1.0f), clamp_(crs.color.z, 0.0f, 1.0f));
                             cold.set_color(cold.color() + cc * (amount * crs.opacity));
                             amount *= 1.0f - crs.opacity;
-                            hit = true;
+                            hit = 1;
                         }
                         if (amount < 0.005f) mode = M_FINISH; else it++;
                     }
@@ -1172,83 +1181,34 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
             if (COUNT && lane == 0) cnt[10]++;
 #ifdef BHRAY_EXP_PROFILE
             xp_n++;
+#ifdef BHRAY_EXP_PROFILE_FINE
+            const long long xf_a = clock64(); long long xf_b = xf_a, xf_c = xf_a; xf_loop += xf_a - xf_prev;
 #endif
-            if (mode == M_REL) {
-                if (it >= H.max_iter) {
-                    mode = M_FINISH;
-                } else {
-                    if (COUNT) cnt[4]++;
-                    ppos = cpos; pdir = cdir;
-                    const float ppos_dist = cpos_dist;
-                    float cd;
-                    if (LIT) {
-                        if (METHOD == 0) {
-                            next_ray_euler_literal(bpos, cpos, cdir, H.step_size);
-                        } else {
-                            next_ray_rk_literal(bpos, rkpos, rkdir, rkh);
-                            cpos = rkpos; cdir = rkdir;
-                        }
-                        cd = distance(cpos, bpos);                        // ray.wgsl:533, operator by operator
-                    } else {
-                    if (METHOD == 0) {
-                        next_ray_euler(qrel, cpos, cdir, H.step_size, dist_c);
-                    } else {
-                        next_ray_rk(qrel, rkpos, rkdir, rkh, dist_c);
-                        cpos = rkpos; cdir = rkdir;
-                    }
-                    qrel = cpos - bpos;
-                    cd = sqrt_rn(fdot(qrel, qrel));               // N7: the integrator's distance (ray.wgsl:533) = fdistance(cpos, bpos)
-                    }
-                    dist_c = cd; cpos_dist = cd;                       // Euler: cpos is the integrator position; RK: cpos == rkpos here
-                    if (cd < closest) closest = cd;
-                    pdir = cdir;
-                    // Everything that can end or alter the plain march - a horizon or disk test that is not culled, the sphere exit - sits
-                    // behind ONE branch: a wave that runs alone on its SIMD (the tail of every latency-bound launch) pays 30-40 cycles for
-                    // every compare -> exec mask -> branch, and the seven of the straightforward form cost it more than the RK step itself
-                    // (level 0 alone: 1.07 us per iteration, of which the step is 0.39).  `amount` changes only in there, so does its test.
-                    const float seg = METHOD == 0 ? H.step_size : rkh;
-                    bool near_horizon, near_disk;
-                    black_hole_culls(H, ppos, ppos_dist, seg, near_horizon, near_disk);
-                    if (near_horizon || near_disk || cd > H.R) {
-                    Hit crs; float td;
-                    const bool disk = hit_black_hole_geom(H, ppos, pdir, near_horizon, near_disk, t_min, seg, crs, td);
-                    if (cd > H.R) {
-                        mode = M_FLAT;
-                        const float fw = H.R * H.feather;
-                        const float fs = H.R - fw;
-                        const float lin = clamp_((closest - fs) / fw, 0.0f, 1.0f);
-                        const float m = lin * lin;
-                        cdir = mix3(cdir, cold.rdir(), m);
-                    }
-                    if (disk) {
-                        // The shading of a disk hit (~700 instructions, needed by 1-5 lanes of a stepping wave) is deferred to the
-                        // shade phase: the lane pauses with ppos / pdir / td intact and resumes in the mode it has now.
-                        cold.set_pend_t(td);
-                        mode = (mode == M_FLAT) ? M_SHADE_FLAT : M_SHADE_REL;
-                        continue;
-                    }
-                    if (crs.hit) {                               // horizon: colour 0, opacity 1
-                        cpos = cpos + pdir * crs.t;
-                        cpos_dist = fdistance(cpos, bpos);
-                        if (METHOD == 0) { dist_c = cpos_dist; qrel = cpos - bpos; }
-                        const F3 cc = f3(clamp_(crs.color.x, 0.0f, 1.0f), clamp_(crs.color.y, 0.0f, 1.0f), clamp_(crs.color.z, 0.0f, 1.0f));
-                        cold.set_color(cold.color() + cc * (amount * crs.opacity));
-                        amount *= 1.0f - crs.opacity;
-                        hit = true;
-                    }
-                    if (amount < 0.005f) mode = M_FINISH; else it++;
-                    } else {
-                        it++;
-                    }
-                }
+#endif
+            if (DENSE || MODELS) {                    // see bhray_step.inc
+#define BHRAY_STEP_LEAN 0
+#include "bhray_step.inc"
+#undef BHRAY_STEP_LEAN
+            } else {
+#define BHRAY_STEP_LEAN 1
+#include "bhray_step.inc"
+#undef BHRAY_STEP_LEAN
             }
+#ifdef BHRAY_EXP_PROFILE_FINE
+            { const long long xf_d = clock64(); xf_step += xf_b - xf_a; xf_cull += xf_c - xf_b; xf_tail += xf_d - xf_c; xf_prev = xf_d; }
+#endif
         }
         XP(4, true)
     }
 #ifdef BHRAY_EXP_PROFILE
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        printf("xp: total %lld rounds %d iterations %d | refill %lld (%d) shade %lld (%d) flat %lld (%d) finish %lld (%d) steps %lld\n", (long long)(clock64() - xp_t0), xp_rounds, xp_n,
-               xp_t[0], xp_c[0], xp_t[1], xp_c[1], xp_t[2], xp_c[2], xp_t[3], xp_c[3], xp_t[4]);
+    if (lane == 0) {
+        long long* d = xp_dump + (size_t)(blockIdx.x * (BHRAY_TRACE_THREADS / 64) + (threadIdx.x >> 6)) * 16;
+        d[0] = clock64() - xp_t0; d[1] = xp_rounds; d[2] = xp_n;
+        for (int k = 0; k < 5; k++) { d[3 + k] = xp_t[k]; d[8 + k] = xp_c[k]; }
+#ifdef BHRAY_EXP_PROFILE_FINE
+        d[8] = xf_loop; d[9] = xf_step; d[10] = xf_cull; d[11] = xf_tail;
+#endif
+    }
 #endif
 
     if (COUNT) {
@@ -1464,3 +1424,9 @@ int trace_blocks_per_cu(int method, int has_models, int count, int dense, int li
 }
 
 }  // namespace bhray
+
+#ifdef BHRAY_EXP_PROFILE
+extern "C" int bhray_debug_read_profile(long long* out, size_t n) {      // timing-only build: per-wave phase clocks of the last trace launch
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bhray::xp_dump), n * sizeof(long long));
+}
+#endif

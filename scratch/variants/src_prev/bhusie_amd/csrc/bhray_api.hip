@@ -119,7 +119,14 @@ struct bhray_dev {
     uint8_t ring_frames[BHRAY_TIMING_RING] = {0};   // frames of the batch held by each timing-ring entry
     int* d_err = nullptr;
     int num_cus = 256;
-    uint32_t temporal_radius = 0;          // BHRAY_F_TEMPORAL: dilation of the previous frame's traced set in pixels (BHRAY_TEMPORAL_RADIUS; measured: a
+    // BHRAY_F_TEMPORAL: what is predicted beyond the pixels the previous frame traced (measured at 1080p on a camera orbiting at 0.002
+    // and 0.02 rad per frame, profiles/r02_experiments.json "temporal_prediction"): interpolated pixels whose widest neighbour angle
+    // exceeded 0.8 x the threshold, pixels within 4 (levels below the last) / 1 (last level) pixels of a predicted one, and the clamped
+    // border pixels (predict_kernel).  +8 % rays; the levels below the last then miss nothing, the last level a few hundred aliased
+    // pixels: ONE fix-up launch instead of three.  BHRAY_TEMPORAL_MARGIN / BHRAY_TEMPORAL_RADIUS="last[,below]" override (tuning).
+    float temporal_margin = 0.8f;
+    uint32_t temporal_radius_coarse = 4;
+    uint32_t temporal_radius = 1;
                                            // radius of 1-2 adds 2-4 % rays and does not shorten a moving camera's frames - the misses are scattered interpolate/trace flips)
     int bpc_override = 0;                  // BHRAY_TRACE_BLOCKS_PER_CU (tuning experiments only)
     int grid_override = 0;                 // BHRAY_TRACE_GRID: absolute number of persistent trace blocks (tuning experiments only)
@@ -208,6 +215,7 @@ void derive_frame(const bhray_dev* c, FrameParams& P) {
     P.time = d.time; P.time_rot = d.time * bh.rotation_speed; P.method = d.integration_method != 0 ? 1 : 0; P.step_size = d.step_size;
     P.max_iter = d.max_iterations; P.thr = d.angle_division_threshold;
     P.acos_cstar = acos_threshold(P.thr);
+    P.acos_cstar_near = c->temporal_margin < 1.0f ? acos_threshold(P.thr * c->temporal_margin) : P.acos_cstar;
     int mc = d.model_count; if (mc < 0) mc = 0; if (mc > BHRAY_MAX_MODELS) mc = BHRAY_MAX_MODELS;
     int usable = 0;
     for (int i = 0; i < mc; i++) {
@@ -399,7 +407,14 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = getenv("BHRAY_TRACE_BLOCKS_PER_CU")) c->bpc_override = atoi(e);
     if (const char* e = getenv("BHRAY_TRACE_GRID")) c->grid_override = atoi(e);
-    if (const char* e = getenv("BHRAY_TEMPORAL_RADIUS")) { const int r = atoi(e); c->temporal_radius = r < 0 ? 0 : (r > 4 ? 4 : (uint32_t)r); }
+    if (const char* e = getenv("BHRAY_TEMPORAL_MARGIN")) { const float m = (float)atof(e); c->temporal_margin = m < 0.05f ? 0.05f : (m > 1.0f ? 1.0f : m); }
+    if (const char* e = getenv("BHRAY_TEMPORAL_RADIUS")) {          // "fine[,coarse]": the last level, the levels below it
+        int rf = 0, rc = -1;
+        const int n = sscanf(e, "%d,%d", &rf, &rc);
+        if (n < 2) rc = rf;
+        c->temporal_radius = rf < 0 ? 0 : (rf > 4 ? 4 : (uint32_t)rf);
+        c->temporal_radius_coarse = rc < 0 ? 0 : (rc > 4 ? 4 : (uint32_t)rc);
+    }
     if (const char* e = getenv("BHRAY_TRACE_DENSE")) c->dense_override = atoi(e) != 0;
     const uint32_t nslots = cfg->frames_in_flight ? cfg->frames_in_flight : 4;
     c->cfg.frames_in_flight = nslots;
@@ -725,7 +740,7 @@ int launch_batch(bhray_dev* c) {
         args_used += (size_t)nb * sizeof(FrameLaunch);
         memset(h, 0, (size_t)nb * sizeof(FrameLaunch));
     };
-    struct Launch { int kind; const FrameLaunch* d; int blocks; bool count; std::vector<int> ev_before, ev_after; int build = -1; };   // kind 0 classify, 1 trace; timing events recorded around it; build: -1 the ctx's trace build, 0 latency, 1 dense
+    struct Launch { int kind; const FrameLaunch* d; int blocks; bool count; std::vector<int> ev_before, ev_after; int build = -1; bool fixup = false; };   // kind 0 classify, 1 trace; timing events recorded around it; build: -1 the ctx's trace build, 0 latency, 1 dense
     std::vector<Launch> seq;
     // Persistent trace grid: (resident blocks per CU) x CUs.  With several batches in flight each launch takes only
     // half of the block slots: the kernels of the other batches fill the rest, and a wave of a half-size grid pulls
@@ -834,7 +849,7 @@ int launch_batch(bhray_dev* c) {
                 const FrameRes& R = S.fr[k];
                 level_params(R, l, h[k].L);
                 h[k].L.tag = (int)l;
-                h[k].queue = R.pred_queue; h[k].qctl = R.pred_ctl; h[k].need = R.need[l]; h[k].radius = (int)c->temporal_radius;
+                h[k].queue = R.pred_queue; h[k].qctl = R.pred_ctl; h[k].need = R.need[l]; h[k].radius = (int)(l + 1 == nl ? c->temporal_radius : c->temporal_radius_coarse);
             }
             seq.push_back({2, d, classify_blocks(l), false, l == 0 ? std::vector<int>{0} : std::vector<int>{}, {}});
         }
@@ -866,7 +881,7 @@ int launch_batch(bhray_dev* c) {
                 h[k].need = R.need[l];
                 h[k].stamp = R.stamp[l]; h[k].stamp_value = R.stamp_value; h[k].probe_empty = 1;
             }
-            seq.push_back({0, d, classify_blocks(l), count, l == 0 ? std::vector<int>{} : std::vector<int>{(int)(3 * l)}, {(int)(3 * l + 1)}});
+            seq.push_back({0, d, classify_blocks(l), count, l == 0 ? std::vector<int>{} : std::vector<int>{(int)(3 * l)}, {(int)(3 * l + 1)}, -1, true});
             seq.push_back({1, d, c->num_cus * trace_blocks_per_cu(S.method, S.models, count, 0, literal), count, {}, {(int)(3 * l + 2)}, 0});
         }
         first_normal = nl;
@@ -942,7 +957,7 @@ int launch_batch(bhray_dev* c) {
     for (const Launch& Ln : seq) {
         if (timing) for (int e : Ln.ev_before) HIPCHK(c, hipEventRecord(fev[e], st));
         if (Ln.kind == 2) HIPCHK(c, launch_predict(dP, Ln.d, (int)nb, Ln.blocks, st));
-        else if (Ln.kind == 0) HIPCHK(c, launch_classify(dP, Ln.d, (int)nb, Ln.blocks, Ln.count, st));
+        else if (Ln.kind == 0) HIPCHK(c, launch_classify(dP, Ln.d, (int)nb, Ln.blocks, Ln.count, Ln.fixup, st));
         else HIPCHK(c, launch_trace(dP, Ln.d, (int)nb, S.method, S.models, Ln.count, Ln.build < 0 ? dense : Ln.build != 0, literal, c->d_err, Ln.blocks, st));
         if (timing) for (int e : Ln.ev_after) HIPCHK(c, hipEventRecord(fev[e], st));
     }
@@ -1200,6 +1215,19 @@ int dev_get_level_counters(bhray_dev* c, uint32_t level, bhray_counters* out) {
     if (rc) return rc;
     static_assert(sizeof(bhray_counters) == sizeof(Counters64), "counter layout");
     HIPCHK(c, hipMemcpy(out, c->slots[(size_t)c->last_slot].fr[(size_t)c->last_sub].d_counters + level, sizeof(Counters64), hipMemcpyDeviceToHost));
+    return BHRAY_OK;
+}
+
+// diagnostics (not part of include/bhray.h): the entries the last frame's own queue of `level` held (temporal mode: the fix-up set)
+int dev_debug_read_queue(bhray_dev* c, uint32_t level, uint32_t* out, uint32_t cap, uint32_t* count) {
+    if (!c || !count || level >= c->cfg.levels) return BHRAY_E_INVALID;
+    int rc = dev_sync(c);
+    if (rc) return rc;
+    const FrameRes& R = c->slots[(size_t)c->last_slot].fr[(size_t)c->last_sub];
+    uint32_t n = 0;
+    HIPCHK(c, hipMemcpy(&n, R.d_qctl + 2 * level, sizeof n, hipMemcpyDeviceToHost));
+    *count = n;
+    if (out && R.queue[level]) HIPCHK(c, hipMemcpy(out, R.queue[level], (size_t)(n < cap ? n : cap) * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return BHRAY_OK;
 }
 

@@ -47,6 +47,7 @@ int  dev_next_stream(bhray_dev* c, void** s);
 int  dev_signal_stream(bhray_dev* c, void* s);
 int  dev_selftest(bhray_dev* c, uint64_t mismatches[3]);
 int  dev_get_level_counters(bhray_dev* c, uint32_t level, bhray_counters* out);
+int  dev_debug_read_queue(bhray_dev* c, uint32_t level, uint32_t* out, uint32_t cap, uint32_t* count);   // diagnostics only
 int  dev_get_counters(bhray_dev* c, bhray_counters* out);
 int  dev_get_timing(bhray_dev* c, bhray_timing* out);
 

@@ -549,6 +549,12 @@ int bhray_get_gather_info(const bhray_ctx* c, bhray_gather_info* out) {
     return BHRAY_OK;
 }
 
+// diagnostics, not declared in include/bhray.h (scratch experiments read the temporal fix-up sets through it); single-partition ctx only
+int bhray_debug_read_queue(bhray_ctx* c, uint32_t level, uint32_t* out, uint32_t cap, uint32_t* count) {
+    if (!c || !c->single) return BHRAY_E_INVALID;
+    return dev_debug_read_queue(c->parts[0].dev, level, out, cap, count);
+}
+
 // ---- scene state: replicated on every local partition ---------------------------------------
 int bhray_set_texture(bhray_ctx* c, int slot, const uint8_t* rgba8, uint32_t w, uint32_t h) {
     if (!c) return BHRAY_E_INVALID;

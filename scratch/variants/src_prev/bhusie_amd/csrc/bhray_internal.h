@@ -56,6 +56,7 @@ struct FrameParams {
     int max_iter;
     float thr;
     float acos_cstar;      // largest c with bh_acos(c) >= thr (host, binary search): bh_acos(c) < thr <=> c > acos_cstar on [-1, 1]
+    float acos_cstar_near; // the same for thr * temporal_margin (<= thr): temporal speculation also predicts the pixels this close to being traced
     int model_count;
     TexDev temp, disk, sky;
     ModelDev models[BHRAY_MAX_MODELS];
@@ -125,7 +126,7 @@ struct FrameLaunch {
 #define BHRAY_CLASSIFY_BY 2    // measured at 1080p RK, 20 slots: 4x1 5 315, 2x2 5 290, 4x2 5 406, 2x4 5 380, 4x4 5 360, 8x1 5 328, 8x2 5 345 Mrays/s
 #endif
 // launchers (bhray_kernels.hip); Pb / Fb are device arrays of nb entries
-hipError_t launch_classify(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int blocks, bool count, hipStream_t s);
+hipError_t launch_classify(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int blocks, bool count, bool fixup, hipStream_t s);
 hipError_t launch_trace(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int method, bool models, bool count, bool dense, bool literal, int* err_flag,
                         int grid_blocks, hipStream_t s);
 int trace_blocks_per_cu(int method, int has_models, int count, int dense, int literal);
