@@ -153,7 +153,11 @@ enum {                                  /* bhray_config.flags */
     BHRAY_F_TEMPORAL   = 1u << 3,       /* temporal speculation: one launch first traces, at every level, the pixels the previous frame
                                            had to trace; the ladder then only traces what that prediction missed.  Same pixels; the
                                            chain of dependent trace launches collapses when consecutive frames are similar (an
-                                           interactive host, one frame at a time).  levels <= 4, no speculative / superset levels. */
+                                           interactive host, one frame at a time).  The prediction is a superset of last frame's
+                                           traced set (pixels close to the interpolation threshold, a few pixels around, the clamped
+                                           border pixels: DESIGN.md §4), +8 % rays; 1080p, one frame at a time: 0.81 ms with a static
+                                           camera, 0.89 ms with a moving one, 1.21 ms without the flag.  levels <= 4, no
+                                           speculative / superset levels.                                                    */
     BHRAY_F_LITERAL    = 1u << 2        /* the integrator (ray.wgsl:401-480, 533) operator by operator: one binary32 operation per
                                            WGSL operator in source order, no fused multiply-add, no reassociation.  Slower; exists
                                            to MEASURE how far the default evaluation (DESIGN.md §2, N3/N7/N9/N10 — permitted by
