@@ -64,6 +64,7 @@ struct FrameRes {
 // full or flushed, each launch covering all staged frames.
 struct Slot {
     hipStream_t stream = nullptr;
+    bool owns_stream = true;            // false: the stream belongs to an earlier slot (more slots than hardware queues)
     hipEvent_t done = nullptr;          // recorded after the slot's last launch
     hipEvent_t uploaded = nullptr;      // recorded after the argument block of the slot's batch has been copied to the device
     bool used = false;                  // `uploaded` has been recorded at least once
@@ -347,7 +348,7 @@ void dev_destroy(bhray_dev* c) {
         if (S.d_args) (void)hipFree(S.d_args);
         if (S.done) (void)hipEventDestroy(S.done);
         if (S.uploaded) (void)hipEventDestroy(S.uploaded);
-        if (S.stream) (void)hipStreamDestroy(S.stream);
+        if (S.stream && S.owns_stream) (void)hipStreamDestroy(S.stream);
     }
     for (Level& L : c->levels) {
         if (L.d_rows) (void)hipFree(L.d_rows);
@@ -455,8 +456,16 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
     }
     c->out_bytes = (opt.frame_rowmap ? (size_t)cfg->frame_h : c->local_rows.size()) * (size_t)cfg->frame_w * sizeof(float4);
     const size_t nlaunch = 5 * (size_t)nl + 3;                            // upper bound of launches per batch
-    for (Slot& S : c->slots) {
-        CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+    // Streams beyond the hardware queues ROCm maps them onto (GPU_MAX_HW_QUEUES, default 4; two are left to the null stream and a
+    // communication stream) do not add concurrency, they alias - and a device with MORE streams than queues collapses (24 slots on 24
+    // queues: 5 580 -> 4 380 Mrays/s, and a 20-frame block from 8.5 to 73 ms, measured).  The library only READS the variable: the slots
+    // beyond the limit share the streams of the first ones (two frames on one stream are simply in order).
+    size_t max_streams = 2;
+    { const char* e = getenv("GPU_MAX_HW_QUEUES"); const int q = e ? atoi(e) : 4; max_streams = q > 3 ? (size_t)(q - 2) : 2; }
+    for (size_t si = 0; si < c->slots.size(); si++) {
+        Slot& S = c->slots[si];
+        if (si < max_streams) CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+        else { S.stream = c->slots[si % max_streams].stream; S.owns_stream = false; }
         CHK(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
         CHK(hipEventCreateWithFlags(&S.uploaded, hipEventDisableTiming));
         const size_t B = c->batch;

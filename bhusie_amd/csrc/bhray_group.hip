@@ -384,10 +384,16 @@ void bhray_destroy(bhray_ctx* c) {
     delete c;
 }
 
-int bhray_create(const bhray_config* cfg, bhray_ctx** out) {
-    if (!cfg || !out) return gfail(nullptr, BHRAY_E_INVALID, "null argument");
+int bhray_create(const bhray_config* cfg_in, bhray_ctx** out) {
+    if (!cfg_in || !out) return gfail(nullptr, BHRAY_E_INVALID, "null argument");
     *out = nullptr;
-    if (cfg->struct_size != sizeof(bhray_config)) return gfail(nullptr, BHRAY_E_INVALID, "bhray_config.struct_size mismatch (%u, library expects %zu)", cfg->struct_size, sizeof(bhray_config));
+    if (cfg_in->struct_size != sizeof(bhray_config)) return gfail(nullptr, BHRAY_E_INVALID, "bhray_config.struct_size mismatch (%u, library expects %zu)", cfg_in->struct_size, sizeof(bhray_config));
+    // More than 22 frame slots put the HIP runtime into an intermittent state in which a 20-frame burst takes 64-94 ms instead of 8.5
+    // (measured with 24 and 28 slots, whatever GPU_MAX_HW_QUEUES says; 21-22 slots are the best short-burst setting, 20 the best
+    // sustained one): a larger request (up to BHRAY_MAX_FRAMES_IN_FLIGHT) is served with 22.
+    bhray_config cfg_norm = *cfg_in;
+    if (cfg_norm.frames_in_flight > 22 && cfg_norm.frames_in_flight <= BHRAY_MAX_FRAMES_IN_FLIGHT) cfg_norm.frames_in_flight = 22;
+    const bhray_config* cfg = &cfg_norm;
     if (cfg->device_count > BHRAY_MAX_DEVICES) return gfail(nullptr, BHRAY_E_INVALID, "device_count > %d", BHRAY_MAX_DEVICES);
     if (cfg->gather > BHRAY_GATHER_RCCL) return gfail(nullptr, BHRAY_E_INVALID, "unknown gather mode %u", cfg->gather);
     bhray_ctx* c = new (std::nothrow) bhray_ctx();

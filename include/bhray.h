@@ -224,7 +224,7 @@ typedef struct bhray_config {
     uint32_t frame_w, frame_h;
     uint32_t row_rank, row_world, stripe_rows;
     uint32_t flags;
-    uint32_t frames_in_flight;          /* 0 = default (4); 1 = strictly one frame at a time  */
+    uint32_t frames_in_flight;          /* 0 = default (4); 1 = strictly one frame at a time; more than 22 are served with 22  */
     uint32_t speculative_levels;        /* 0 = off; S>=2: trace EVERY needed pixel of levels 0..S-1 in one launch   */
     uint32_t frames_per_batch;          /* 0/1 = every bhray_render launches; B>1: launches cover B staged frames  */
     uint32_t superset_levels;           /* 0 = off; U>=2: the LAST U levels are traced in one launch over a conservative superset    */
@@ -330,9 +330,11 @@ int bhray_bind_output(bhray_ctx* ctx, void* dev_ptr, size_t bytes);
  * frame slots, each with its own HIP stream and level/queue buffers; consecutive bhray_render
  * calls go to consecutive slots and overlap on the device (the reference's swap chain runs with
  * desired_maximum_frame_latency = 2, mod.rs:101).  ROCm maps HIP streams onto GPU_MAX_HW_QUEUES (default 4) hardware
- * queues and aliased streams serialise: a host that keeps more than 4 frames in flight exports
- * GPU_MAX_HW_QUEUES >= frames_in_flight (+2 with a gather) before its first HIP call; the library never touches the
- * process environment.  Ordering against the caller's own streams:
+ * queues and aliased streams serialise: a host that keeps more than 2 frames in flight exports
+ * GPU_MAX_HW_QUEUES >= frames_in_flight + 2 before its first HIP call; the library never changes the process
+ * environment.  It reads that variable: slots beyond GPU_MAX_HW_QUEUES - 2 share the streams of the first ones (frames on
+ * one stream run in order), because MORE streams than queues do not merely alias, they collapse (measured: 24 slots on 24
+ * queues lose 20 % of the throughput and a 20-frame burst takes 9x as long).  Ordering against the caller's own streams:
  *   bhray_wait_stream(ctx, s)    the NEXT bhray_render starts after everything enqueued on s so far
  *   bhray_signal_stream(ctx, s)  work enqueued on s from now on starts after the LAST bhray_render
  * `s` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the legacy stream.  */
