@@ -1035,6 +1035,9 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
 #endif
         // ---- deferred disk shading (ray.wgsl:612-663 and the hit bookkeeping of 537-552) for lanes that paused on a disk hit
         if (__any(mode >= M_SHADE_REL)) {
+#ifdef BHRAY_EXP_POWSTAT              /* counting-only build: wave-level invocations of the shade phase (triangles counter) */
+            if (COUNT && lane == (int)__builtin_ctzll(__ballot(true))) cnt[7]++;
+#endif
             if (mode >= M_SHADE_REL) {
                 const float pend_t = cold.pend_t();
                 Hit crs; crs.hit = true; crs.t = pend_t; crs.color = f3(0.0f, 0.0f, 0.0f); crs.opacity = 0.0f;

@@ -16,4 +16,5 @@ for method in (1,):
         cc = BhrayCounters(); L().bhray_get_level_counters(rp._h, l, C.byref(cc))
         s = cc.scheduling()
         print("level", l, "steps", c["steps"], "wave_steps", s.get("wave_steps"), "lanes that took the power", s.get("rays_adopted"), "wave-steps with the power", c["node_pairs"],
-              "-> lanes %.3f of lane-steps, wave-steps %.3f" % (s.get("rays_adopted") / max(1, c["steps"]), c["node_pairs"] / max(1, s.get("wave_steps"))))
+              "-> lanes %.5f of lane-steps, wave-steps %.4f" % (s.get("rays_adopted") / max(1, c["steps"]), c["node_pairs"] / max(1, s.get("wave_steps"))),
+              "| disk hits", c["disk_hits"], "shade-phase invocations", c["triangles"], "-> %.2f lanes per invocation" % (c["disk_hits"] / max(1, c["triangles"])))

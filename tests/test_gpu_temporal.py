@@ -132,3 +132,47 @@ def test_temporal_latency_at_the_bench_frame():
         rp.close()
     print("latency ms per 1920x1080 frame, one frame in flight:", res)
     assert res["temporal static"] < res["S2 static"]
+
+
+def test_moving_camera_leaves_one_fixup_launch_at_the_bench_frame():
+    """The prediction's superset (threshold margin, radius, clamped border pixels: predict_kernel) is sized so that a camera in motion
+    misses nothing below the last level — the frame then costs ONE fix-up launch, not one per level.  Orbit of 0.002 rad + 0.03 up per
+    frame (half a pixel of the last level) and bench.py's 0.02 rad + 0.3: levels 1 and 2 trace nothing in their fix-up launches, the
+    last level a few hundred aliased pixels, and every frame equals the plain ladder's."""
+    tex = T.textures(small=False)
+    cfg = B.ladder_for_frame((1920, 1080), 3, 4)
+    for da, dy in ((0.002, 0.03), (0.02, 0.3)):
+        rp = B.RayPass(cfg, temporal=True, frames_in_flight=1, counters=True)
+        rp.set_textures(*tex)
+        for i in range(6):
+            a = da * i
+            pos = (19.0 * np.sin(a), dy * i, -19.0 * np.cos(a))
+            fwd = tuple(float(v) for v in -np.array(pos) / np.linalg.norm(pos))
+            u = T.uniforms(integration_method=1, camera=B.Camera(position=tuple(float(v) for v in pos), forward=fwd))
+            rp.set_uniforms(*u)
+            rp.render()
+            if i >= 2:
+                fix = [rp.level_counters(l)["traced"] for l in (1, 2, 3)]
+                assert fix[0] == 0 and fix[1] == 0, (da, i, fix)
+                assert 0 < fix[2] < 4000, (da, i, fix)
+            if i == 5:
+                assert np.array_equal(rp.read_hdr().view(np.uint32), _plain(cfg, u, tex).view(np.uint32))
+        rp.close()
+
+
+def test_more_than_22_frame_slots_are_served_with_22():
+    """bhray_create clamps the slots (24+ put the HIP runtime into an intermittent stall): a ctx asked for 28 behaves,
+    frames are the single-slot frames."""
+    tex = T.textures()
+    cfg = B.ladder_from_base((24, 14), 3, 3)
+    u = T.uniforms(integration_method=1)
+    want = _plain(cfg, u, tex)
+    rp = B.RayPass(cfg, frames_in_flight=28)
+    rp.set_textures(*tex); rp.set_uniforms(*u)
+    for _ in range(60):
+        rp.render()
+    assert np.array_equal(rp.read_hdr().view(np.uint32), want.view(np.uint32))
+    rp.close()
+    with pytest.raises(B.BhrayError):
+        B.RayPass(cfg, frames_in_flight=33)
+
