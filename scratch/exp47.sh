@@ -1,3 +1,3 @@
 #!/bin/bash
 cd /root/repo; mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_temporal.py -x -q > gpurun_out/exp47.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "latency_build" > gpurun_out/exp47.log 2>&1

@@ -467,3 +467,26 @@ def test_production_configuration_is_invariant_at_full_size():
         seen[rows] = True
         rp.close()
     assert seen.all()
+
+
+@pytest.mark.parametrize("method", [1, 0])
+def test_latency_build_and_dense_build_deliver_the_same_frame(method, monkeypatch):
+    """One frame slot selects the latency build (lean step form, short queues dealt out one wave per SIMD: bhray_step.inc, trace_kernel),
+    four slots the dense build; BHRAY_TRACE_DENSE forces either.  Same pixels at every level, same counters — scheduling and control
+    flow differ, the operations of a ray do not."""
+    tex = T.textures()
+    u = T.uniforms(integration_method=method)
+    cfg = B.ladder_for_frame((400, 225), 3, 3)
+    got = {}
+    for name, env, fif in (("latency", "0", 1), ("dense", "1", 1), ("auto 1 slot", None, 1), ("auto 4 slots", None, 4)):
+        monkeypatch.delenv("BHRAY_TRACE_DENSE", raising=False)
+        if env is not None:
+            monkeypatch.setenv("BHRAY_TRACE_DENSE", env)
+        rp = run_gpu(cfg, *u, tex, frames_in_flight=fif, counters=True)
+        got[name] = ([rp.read_level(l) for l in range(3)], rp.counters())
+        rp.close()
+    ref_levels, ref_counters = got["latency"]
+    for name, (levels, counters) in got.items():
+        for a, b in zip(levels, ref_levels):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name
+        assert counters == ref_counters, name
