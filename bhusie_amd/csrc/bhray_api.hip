@@ -46,7 +46,7 @@ struct FrameRes {
     uint32_t* super_queue = nullptr;    // superset speculation: merged, level-tagged queue of the last U levels
     // temporal speculation (BHRAY_F_TEMPORAL): the pixels the previous frame held here had to trace, all levels, level-tagged
     uint32_t* pred_queue = nullptr;     // the predicted launch's queue: built by predict_kernel from the previous frame's marks
-    uint32_t* pred_ctl = nullptr;       // [0] entries [1] entries taken
+    uint32_t* pred_ctl = nullptr;       // [0] entries [1] entries taken: the control words of level BHRAY_MAX_LEVELS-1 in d_qctl (temporal mode has <= 4 levels), reset with them
     std::vector<uint8_t*> need;         // per level: need[y * w + x] = the last exact classification had to trace that pixel
     std::vector<uint32_t*> stamp;       // per level: stamp[y * w + x] == stamp_value <=> the predicted launch traced that pixel this frame
     uint32_t stamp_value = 0;
@@ -337,7 +337,6 @@ void dev_destroy(bhray_dev* c) {
             if (R.super_queue) (void)hipFree(R.super_queue);
             if (R.pred_queue) (void)hipFree(R.pred_queue);
             for (auto p : R.need) if (p) (void)hipFree(p);
-            if (R.pred_ctl) (void)hipFree(R.pred_ctl);
             for (auto p : R.stamp) if (p) (void)hipFree(p);
             if (R.own_out) (void)hipFree(R.own_out);
             if (R.sky_out) (void)hipFree(R.sky_out);
@@ -520,8 +519,8 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
                     CHK(hipMemset(R.need[l], 0, npix));
                 }
                 if (cap) CHK(hipMalloc(&R.pred_queue, cap * sizeof(uint32_t)));
-                CHK(hipMalloc(&R.pred_ctl, 2 * sizeof(uint32_t)));
-                CHK(hipMemset(R.pred_ctl, 0, 2 * sizeof(uint32_t)));
+                static_assert(BHRAY_MAX_SPEC_LEVELS < BHRAY_MAX_LEVELS, "the predicted queue borrows the last level's control words");
+                R.pred_ctl = R.d_qctl + 2 * (BHRAY_MAX_LEVELS - 1);
             }
             if (cfg->superset_levels) {
                 size_t cap = 0;
@@ -749,7 +748,7 @@ int launch_batch(bhray_dev* c) {
         args_used += (size_t)nb * sizeof(FrameLaunch);
         memset(h, 0, (size_t)nb * sizeof(FrameLaunch));
     };
-    struct Launch { int kind; const FrameLaunch* d; int blocks; bool count; std::vector<int> ev_before, ev_after; int build = -1; bool fixup = false; };   // kind 0 classify, 1 trace; timing events recorded around it; build: -1 the ctx's trace build, 0 latency, 1 dense
+    struct Launch { int kind; const FrameLaunch* d; int blocks; bool count; std::vector<int> ev_before, ev_after; int build = -1; bool fixup = false; int levels = 1; };   // kind 0 classify, 1 trace; timing events recorded around it; build: -1 the ctx's trace build, 0 latency, 1 dense
     std::vector<Launch> seq;
     // Persistent trace grid: (resident blocks per CU) x CUs.  With several batches in flight each launch takes only
     // half of the block slots: the kernels of the other batches fill the rest, and a wave of a half-size grid pulls
@@ -849,9 +848,9 @@ int launch_batch(bhray_dev* c) {
                 for (uint32_t l = 0; l < nl; l++) HIPCHK(c, hipMemsetAsync(R.stamp[l], 0, (size_t)c->levels[l].w * (size_t)c->levels[l].h * sizeof(uint32_t), st));
                 R.stamp_value = 1;
             }
-            HIPCHK(c, hipMemsetAsync(R.pred_ctl, 0, 2 * sizeof(uint32_t), st));
         }
         // (0) the prediction: per level, the previous frame's traced set dilated by temporal_radius pixels -> one level-tagged queue
+        const FrameLaunch* pred_first = nullptr; int pred_blocks = 0;
         for (uint32_t l = 0; l < nl; l++) {
             FrameLaunch* h; const FrameLaunch* d; next_launch(h, d);
             for (uint32_t k = 0; k < nb; k++) {
@@ -860,8 +859,11 @@ int launch_batch(bhray_dev* c) {
                 h[k].L.tag = (int)l;
                 h[k].queue = R.pred_queue; h[k].qctl = R.pred_ctl; h[k].need = R.need[l]; h[k].radius = (int)(l + 1 == nl ? c->temporal_radius : c->temporal_radius_coarse);
             }
-            seq.push_back({2, d, classify_blocks(l), false, l == 0 ? std::vector<int>{0} : std::vector<int>{}, {}});
+            for (uint32_t k = 0; k < nb; k++) h[k].blocks = classify_blocks(l);
+            if (l == 0) { pred_first = d; pred_blocks = 0; }
+            if (classify_blocks(l) > pred_blocks) pred_blocks = classify_blocks(l);
         }
+        seq.push_back({2, pred_first, pred_blocks, false, {0}, {}, -1, false, (int)nl});      // ONE launch, blockIdx.z = level (the entries are contiguous)
         {
             FrameLaunch* h; const FrameLaunch* d; next_launch(h, d);
             for (uint32_t k = 0; k < nb; k++) {
@@ -965,7 +967,7 @@ int launch_batch(bhray_dev* c) {
     if (timing) { c->sky_recorded[ring] = 0; c->ring_frames[ring] = (uint8_t)nb; }
     for (const Launch& Ln : seq) {
         if (timing) for (int e : Ln.ev_before) HIPCHK(c, hipEventRecord(fev[e], st));
-        if (Ln.kind == 2) HIPCHK(c, launch_predict(dP, Ln.d, (int)nb, Ln.blocks, st));
+        if (Ln.kind == 2) HIPCHK(c, launch_predict(dP, Ln.d, (int)nb, Ln.levels, Ln.blocks, st));
         else if (Ln.kind == 0) HIPCHK(c, launch_classify(dP, Ln.d, (int)nb, Ln.blocks, Ln.count, Ln.fixup, st));
         else HIPCHK(c, launch_trace(dP, Ln.d, (int)nb, S.method, S.models, Ln.count, Ln.build < 0 ? dense : Ln.build != 0, literal, c->d_err, Ln.blocks, st));
         if (timing) for (int e : Ln.ev_after) HIPCHK(c, hipEventRecord(fev[e], st));

@@ -116,6 +116,7 @@ struct FrameLaunch {
     const uint32_t* stamp; // this level's stamp image (classify); nullptr outside temporal mode
     uint32_t stamp_value;  // stamp of the current frame
     int probe_empty;       // trace: this launch is expected to find its queue (nearly) used up - look before the first atomic
+    int blocks;            // predict (one launch, all levels): this level's own block count
 };
 
 // classify / predict: a 256-thread block covers a rectangle of BX x BY 8x8-pixel tiles (4 waves, BX*BY/4 tiles each in turn)
@@ -134,7 +135,7 @@ int trace_blocks_per_cu(int method, int has_models, int count, int dense, int li
 // between the launches of a stream costs a cross-engine handshake each time)
 // and zeroes `nzero` 32-bit words at `zero` (the queue control words of the batch) in the same launch
 hipError_t launch_upload(const void* pinned_src, void* dst, size_t n16, uint32_t* zero, size_t nzero, hipStream_t s);
-hipError_t launch_predict(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int blocks, hipStream_t s);   // temporal speculation: F.need -> F.queue
+hipError_t launch_predict(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int levels, int blocks, hipStream_t s);   // temporal speculation: F.need -> F.queue
 hipError_t launch_selftest(unsigned long long* bad3, hipStream_t s);   // [0]: 1/x mismatches, [1]: sqrt mismatches, [2]: places where bh_acos increases
 hipError_t launch_sky(const TexDev& sky, const float4* src, uint2* dst_rgba16f, size_t npix, hipStream_t s);
 

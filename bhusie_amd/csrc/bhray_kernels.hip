@@ -1304,8 +1304,11 @@ hipError_t launch_selftest(unsigned long long* bad2, hipStream_t s) {
 template <int DUMMY>
 __global__ __launch_bounds__(BHRAY_CLASSIFY_THREADS) void predict_kernel(const FrameParams* __restrict__ Pb, const FrameLaunch* __restrict__ Fb) {
     __shared__ uint32_t append_lds[BHRAY_CLASSIFY_TILES];
-    const FrameLaunch& F = Fb[blockIdx.y];
+    // one launch for all levels: blockIdx.z = level (its FrameLaunch entries follow the previous level's), blockIdx.y = frame; the
+    // grid is as wide as the largest level needs, the blocks beyond a level's own count leave at once
+    const FrameLaunch& F = Fb[blockIdx.z * gridDim.y + blockIdx.y];
     const LevelParams& L = F.L;
+    if ((int)blockIdx.x >= F.blocks) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bool want[BHRAY_CLASSIFY_TPW];
     uint32_t entry[BHRAY_CLASSIFY_TPW];
@@ -1338,10 +1341,10 @@ __global__ __launch_bounds__(BHRAY_CLASSIFY_THREADS) void predict_kernel(const F
     }
     block_append(want, entry, F.queue, F.qctl, append_lds);
 }
-hipError_t launch_predict(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int blocks, hipStream_t s) {
-    if (blocks <= 0 || nb <= 0) return hipSuccess;
+hipError_t launch_predict(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int levels, int blocks, hipStream_t s) {
+    if (blocks <= 0 || nb <= 0 || levels <= 0) return hipSuccess;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(predict_kernel<0>, dim3(blocks, nb), dim3(BHRAY_CLASSIFY_THREADS), 0, s, Pb, Fb);
+    hipLaunchKernelGGL(predict_kernel<0>, dim3(blocks, nb, levels), dim3(BHRAY_CLASSIFY_THREADS), 0, s, Pb, Fb);
     return hipGetLastError();
 }
 
