@@ -155,8 +155,8 @@ enum {                                  /* bhray_config.flags */
                                            chain of dependent trace launches collapses when consecutive frames are similar (an
                                            interactive host, one frame at a time).  The prediction is a superset of last frame's
                                            traced set (pixels close to the interpolation threshold, a few pixels around, the clamped
-                                           border pixels: DESIGN.md §4), +8 % rays; 1080p, one frame at a time: 0.81 ms with a static
-                                           camera, 0.89 ms with a moving one, 1.21 ms without the flag.  levels <= 4, no
+                                           border pixels: DESIGN.md §4), +8 % rays; 1080p, one frame at a time: 0.78 ms with a static
+                                           camera, 0.84-0.87 ms with a moving one, 1.20 ms without the flag.  levels <= 4, no
                                            speculative / superset levels.                                                    */
     BHRAY_F_LITERAL    = 1u << 2        /* the integrator (ray.wgsl:401-480, 533) operator by operator: one binary32 operation per
                                            WGSL operator in source order, no fused multiply-add, no reassociation.  Slower; exists
