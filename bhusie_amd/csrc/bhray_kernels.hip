@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
 #endif
         // ---- deferred disk shading (ray.wgsl:612-663 and the hit bookkeeping of 537-552) for lanes that paused on a disk hit
         if (__any(mode >= M_SHADE_REL)) {
-#ifdef BHRAY_EXP_POWSTAT              /* counting-only build: wave-level invocations of the shade phase (triangles counter) */
+#if defined(BHRAY_EXP_POWSTAT) || defined(BHRAY_EXP_PHASESTAT)   /* counting-only build: wave-level invocations of the shade phase (triangles counter) */
             if (COUNT && lane == (int)__builtin_ctzll(__ballot(true))) cnt[7]++;
 #endif
             if (mode >= M_SHADE_REL) {
@@ -1067,6 +1067,9 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
             if (run_flat) flat_round = 0;
         }
         if (run_flat && __any(mode == M_FLAT)) {
+#ifdef BHRAY_EXP_PHASESTAT            /* counting-only build: wave-level invocations of the flat phase (node_pairs) and the epilogue (rays_adopted) */
+            if (COUNT && lane == (int)__builtin_ctzll(__ballot(true))) cnt[6]++;
+#endif
             if (mode == M_FLAT) {
                 if (it >= H.max_iter) {
                     mode = M_FINISH;
@@ -1131,6 +1134,9 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
         const bool xp_fin = __any(mode == M_FINISH);
 #endif
         if (__any(mode == M_FINISH)) {
+#ifdef BHRAY_EXP_PHASESTAT
+            if (COUNT && lane == (int)__builtin_ctzll(__ballot(true))) cnt[11]++;
+#endif
             if (mode == M_FINISH) {
                 float4 o;
                 F3 color = cold.color();
