@@ -210,3 +210,41 @@ def test_angle_threshold_values(thr):
     rp = B.RayPass(cfg, device=0, counters=True); rp.set_textures(*tex); rp.set_uniforms(*u); rp.render()
     check(rp.read_hdr(), want[-1], f"threshold {thr}")
     assert rp.counters() == cnt.as_dict()
+
+
+def test_fuzz_every_build_and_mode_delivers_the_same_frame(monkeypatch):
+    """Seeded random scenes (camera, hole, disk, step size, iteration limit, threshold, time, frame size, 1-4 levels, both integrators):
+    the latency build (lean step form, short queues dealt out), the dense build, the speculative ladder on four slots and the temporal
+    mode (third frame of a static sequence) deliver the same bits — except the SIGN of a NaN, which neither WGSL nor the contract
+    specifies (the builds select different instructions for the same operation: 0x7fc00000 / 0xffc00000 in the same pixels)."""
+    rng = np.random.default_rng(1234)
+    tex = T.textures()
+    for trial in range(14):
+        method = int(rng.integers(0, 2))
+        pos = rng.normal(size=3) * np.array([12.0, 4.0, 12.0]); pos[2] -= 18.0
+        fwd = -pos / np.linalg.norm(pos) + rng.normal(size=3) * 0.15; fwd /= np.linalg.norm(fwd)
+        cam = B.Camera(position=tuple(float(v) for v in pos), forward=tuple(float(v) for v in fwd), fov=float(rng.uniform(0.6, 1.6)))
+        bh = B.BlackHole(position=tuple(float(v) for v in rng.normal(size=3) * 2.0), relativity_sphere_radius=float(rng.uniform(8.0, 30.0)),
+                         accretion_disk_inner=float(rng.uniform(1.5, 4.0)), accretion_disk_outer=float(rng.uniform(5.0, 12.0)))
+        u = T.uniforms(integration_method=method, camera=cam, black_hole=bh, step_size=float(rng.uniform(0.05, 0.3)), max_iterations=int(rng.integers(50, 2500)),
+                       angle_division_threshold=float(rng.uniform(0.005, 0.08)), time=float(rng.uniform(0, 5)))
+        cfg = B.ladder_for_frame((int(rng.integers(60, 420)), int(rng.integers(40, 260))), 3, int(rng.integers(1, 5)))
+        nl = len(cfg.sizes())
+        frames = {}
+        for name, env, kw, renders in (("latency", "0", dict(frames_in_flight=1), 1), ("dense", "1", dict(frames_in_flight=1), 1),
+                                       ("speculative, 4 slots", None, dict(frames_in_flight=4, speculative_levels=2 if nl >= 3 else 0), 1),
+                                       ("temporal", None, dict(frames_in_flight=1, temporal=True), 3)):
+            monkeypatch.delenv("BHRAY_TRACE_DENSE", raising=False)
+            if env is not None:
+                monkeypatch.setenv("BHRAY_TRACE_DENSE", env)
+            rp = B.RayPass(cfg, **kw)
+            rp.set_textures(*tex); rp.set_uniforms(*u)
+            for _ in range(renders):
+                rp.render()
+            frames[name] = rp.read_hdr()
+            rp.close()
+        ref = frames["latency"]
+        for name, f in frames.items():
+            both_nan = np.isnan(f) & np.isnan(ref)
+            a, b = np.where(both_nan, 0.0, f).astype(np.float32), np.where(both_nan, 0.0, ref).astype(np.float32)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"trial {trial}: {name} differs from the latency build ({cfg.sizes()}, method {method})"
