@@ -11,6 +11,8 @@ import os as _os
 # Frame slots run on separate HIP streams and ROCm maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues; aliased
 # streams serialise.  This host layer keeps up to 16 frames in flight (+ the communication streams of a gather), so it raises
 # the limit unless the user set one — it must happen before the first HIP call.  (libbhray itself never touches the environment.)
+# SIDE EFFECT: the variable is process-wide, so it also applies to torch or any other HIP user that initialises after this
+# import; export GPU_MAX_HW_QUEUES yourself (any value, e.g. the ROCm default 4) before importing bhusie_amd to opt out.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 from ._lib import lib, LibraryMissing, LIB_PATH  # noqa: F401
@@ -19,4 +21,4 @@ from .layouts import (BhrayConfig, BhrayCounters, BhrayTiming, BhrayDetails, Bhr
                       BhrayError, check)
 from .scene import Camera, BlackHole, RayDetails  # noqa: F401
 from .model import Model, load_model  # noqa: F401
-from .renderer import RayPass, Renderer, ladder_from_base, ladder_for_frame, comm_unique_id, partition_rows  # noqa: F401
+from .renderer import RayPass, Renderer, PinnedFrame, ladder_from_base, ladder_for_frame, comm_unique_id, partition_rows  # noqa: F401

@@ -29,6 +29,10 @@ namespace {
 
 thread_local std::string g_create_error;
 
+#define BHRAY_COPY_STREAMS 2
+#define BHRAY_READ_RING 64
+constexpr int SPAN_MAX = BHRAY_MAX_LEVELS + 2;      // trace launches per batch (per-level, + speculative / predicted)
+
 struct Level {                      // geometry of one ladder level (shared by all frame slots)
     int w = 0, h = 0;
     std::vector<int32_t> rows;      // rows to compute
@@ -114,10 +118,14 @@ struct bhray_dev {
     bhray_black_hole_uniform bh{};
     bhray_details det{};
     bool have_uniforms = false;
-    std::vector<hipEvent_t> events;        // ring: [BHRAY_TIMING_RING][levels][3] (before classify, before trace, after trace)
+    std::vector<hipEvent_t> events;        // ring: [BHRAY_TIMING_RING][3 * levels + 4]: per level (before classify, before trace, after trace), 2 around the sky pass, 2 around the temporal mode's prediction + predicted trace
     uint64_t frame_counter = 0, timing_begin = 0;   // timing_begin: first batch not yet reported by dev_get_timing
     uint8_t sky_recorded[BHRAY_TIMING_RING] = {0};
     uint8_t ring_frames[BHRAY_TIMING_RING] = {0};   // frames of the batch held by each timing-ring entry
+    // execution spans of the trace launches of timed batches (FrameLaunch::span): [BHRAY_TIMING_RING][SPAN_MAX][2] device words
+    unsigned long long* d_span = nullptr;
+    uint8_t ring_spans[BHRAY_TIMING_RING] = {0};    // trace launches of each timing-ring entry
+    double wall_clock_khz = 100000.0;               // hipDeviceAttributeWallClockRate (s_memrealtime: 100 MHz on gfx950)
     int* d_err = nullptr;
     int num_cus = 256;
     // BHRAY_F_TEMPORAL: what is predicted beyond the pixels the previous frame traced (measured at 1080p on a camera orbiting at 0.002
@@ -133,6 +141,11 @@ struct bhray_dev {
     int grid_override = 0;                 // BHRAY_TRACE_GRID: absolute number of persistent trace blocks (tuning experiments only)
     int dense_override = -1;               // BHRAY_TRACE_DENSE=0/1 (tuning experiments only)
     bool rendered = false;
+    // asynchronous hand-off (dev_read_hdr_async): copies run on their own streams (the SDMA engines), behind the frame's kernels
+    hipStream_t copy_stream[BHRAY_COPY_STREAMS] = {nullptr, nullptr};
+    hipEvent_t read_ev[BHRAY_READ_RING] = {nullptr};     // ticket t -> read_ev[t % BHRAY_READ_RING]
+    hipEvent_t copy_join = nullptr;
+    uint64_t read_tickets = 0;
     std::string err;
 };
 
@@ -272,6 +285,7 @@ const char* bhray_strerror(int code) {
         case BHRAY_E_BVH_DEPTH: return "BVH deeper than the traversal stack";
         case BHRAY_E_IO: return "I/O or parse error";
         case BHRAY_E_CAPACITY: return "model exceeds reference capacity";
+        case BHRAY_E_COMM: return "RCCL unavailable or collective failed";
         default: return "unknown error";
     }
 }
@@ -357,6 +371,10 @@ void dev_destroy(bhray_dev* c) {
     for (auto& m : c->models) free_model(m);
     for (auto& e : c->events) if (e) (void)hipEventDestroy(e);
     if (c->d_err) (void)hipFree(c->d_err);
+    if (c->d_span) (void)hipFree(c->d_span);
+    for (auto& st : c->copy_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (auto& e : c->read_ev) if (e) (void)hipEventDestroy(e);
+    if (c->copy_join) (void)hipEventDestroy(c->copy_join);
     delete c;
 }
 
@@ -535,8 +553,12 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
         }
     }
     if (cfg->flags & (BHRAY_F_TIMING | BHRAY_F_TIMING_SPARSE)) {
-        c->events.assign((size_t)BHRAY_TIMING_RING * (nl * 3 + 2), nullptr);
+        c->events.assign((size_t)BHRAY_TIMING_RING * (nl * 3 + 4), nullptr);
         for (auto& e : c->events) CHK(hipEventCreate(&e));
+        CHK(hipMalloc(&c->d_span, (size_t)BHRAY_TIMING_RING * SPAN_MAX * 2 * sizeof(unsigned long long)));
+        CHK(hipMemset(c->d_span, 0, (size_t)BHRAY_TIMING_RING * SPAN_MAX * 2 * sizeof(unsigned long long)));
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) == hipSuccess && khz > 0) c->wall_clock_khz = (double)khz;
     }
     CHK(hipMalloc(&c->d_err, sizeof(int)));
     CHK(hipMemset(c->d_err, 0, sizeof(int)));
@@ -748,7 +770,7 @@ int launch_batch(bhray_dev* c) {
         args_used += (size_t)nb * sizeof(FrameLaunch);
         memset(h, 0, (size_t)nb * sizeof(FrameLaunch));
     };
-    struct Launch { int kind; const FrameLaunch* d; int blocks; bool count; std::vector<int> ev_before, ev_after; int build = -1; bool fixup = false; int levels = 1; };   // kind 0 classify, 1 trace; timing events recorded around it; build: -1 the ctx's trace build, 0 latency, 1 dense
+    struct Launch { int kind; const FrameLaunch* d; int blocks; bool count; std::vector<int> ev_before, ev_after; int build = -1; bool fixup = false; int levels = 1; FrameLaunch* h = nullptr; };   // kind 0 classify, 1 trace; timing events recorded around it; build: -1 the ctx's trace build, 0 latency, 1 dense
     std::vector<Launch> seq;
     // Persistent trace grid: (resident blocks per CU) x CUs.  With several batches in flight each launch takes only
     // half of the block slots: the kernels of the other batches fill the rest, and a wave of a half-size grid pulls
@@ -759,7 +781,7 @@ int launch_batch(bhray_dev* c) {
     // 0.080 ms per frame; one slot: the latency build is 7-15 % faster per launch).
     const bool dense = c->dense_override >= 0 ? c->dense_override != 0
                                               : (c->slots.size() * (size_t)c->batch >= 4 * (size_t)c->cfg.row_world);
-    const bool literal = (c->cfg.flags & BHRAY_F_LITERAL) != 0;
+    const int literal = (c->cfg.flags & BHRAY_F_LITERAL) ? 1 : ((c->cfg.flags & BHRAY_F_EVAL_FMA) ? 2 : 0);   // the integrator's evaluation (launch_trace's `eval`)
     int bpc = trace_blocks_per_cu(S.method, S.models, count, dense, literal);
     if (c->slots.size() > 1 && bpc > 1) bpc = bpc > 4 ? 2 : (bpc / 2 > 1 ? bpc / 2 : 1);     // measured: 2 blocks per CU is best at 8-16 slots
     if (c->bpc_override > 0) bpc = c->bpc_override;
@@ -863,7 +885,7 @@ int launch_batch(bhray_dev* c) {
             if (l == 0) { pred_first = d; pred_blocks = 0; }
             if (classify_blocks(l) > pred_blocks) pred_blocks = classify_blocks(l);
         }
-        seq.push_back({2, pred_first, pred_blocks, false, {0}, {}, -1, false, (int)nl});      // ONE launch, blockIdx.z = level (the entries are contiguous)
+        seq.push_back({2, pred_first, pred_blocks, false, {(int)(3 * nl + 2)}, {}, -1, false, (int)nl});      // ONE launch, blockIdx.z = level (the entries are contiguous)
         {
             FrameLaunch* h; const FrameLaunch* d; next_launch(h, d);
             for (uint32_t k = 0; k < nb; k++) {
@@ -880,7 +902,7 @@ int launch_batch(bhray_dev* c) {
             }
             // the predicted launch holds a whole frame's rays: the dense build (0.61 against 0.66 ms at 1080p); the fix-up launches are
             // expected to be nearly empty: the latency build, which looks at the queue head before its first atomic
-            seq.push_back({1, d, c->num_cus * trace_blocks_per_cu(S.method, S.models, count, 1, literal), count, {}, {}, 1});
+            seq.push_back({1, d, c->num_cus * trace_blocks_per_cu(S.method, S.models, count, 1, literal), count, {}, {(int)(3 * nl + 3)}, 1});
         }
         for (uint32_t l = 0; l < nl; l++) {
             FrameLaunch* h; const FrameLaunch* d; next_launch(h, d);
@@ -892,7 +914,7 @@ int launch_batch(bhray_dev* c) {
                 h[k].need = R.need[l];
                 h[k].stamp = R.stamp[l]; h[k].stamp_value = R.stamp_value; h[k].probe_empty = 1;
             }
-            seq.push_back({0, d, classify_blocks(l), count, l == 0 ? std::vector<int>{} : std::vector<int>{(int)(3 * l)}, {(int)(3 * l + 1)}, -1, true});
+            seq.push_back({0, d, classify_blocks(l), count, {(int)(3 * l)}, {(int)(3 * l + 1)}, -1, true});
             seq.push_back({1, d, c->num_cus * trace_blocks_per_cu(S.method, S.models, count, 0, literal), count, {}, {(int)(3 * l + 2)}, 0});
         }
         first_normal = nl;
@@ -958,12 +980,25 @@ int launch_batch(bhray_dev* c) {
         }
     }
     if (args_used > S.args_cap) return fail(c, BHRAY_E_STATE, "internal: argument block overflow");
+    const size_t ring = (size_t)(c->batch_counter % BHRAY_TIMING_RING);
+    if (timing && c->d_span) {                 // execution spans of this batch's trace launches (entry 0 of each launch's FrameLaunch array)
+        int nt = 0;
+        for (const Launch& Ln : seq) {
+            if (Ln.kind != 1 || nt >= SPAN_MAX) continue;
+            FrameLaunch* h0 = (FrameLaunch*)(S.h_args + ((const uint8_t*)Ln.d - S.d_args));
+            h0->span = c->d_span + (ring * SPAN_MAX + (size_t)nt) * 2;
+            nt++;
+        }
+        c->ring_spans[ring] = (uint8_t)nt;
+        HIPCHK(c, hipMemsetAsync(c->d_span + ring * SPAN_MAX * 2, 0, (size_t)SPAN_MAX * 2 * sizeof(unsigned long long), st));
+    } else {
+        c->ring_spans[ring] = 0;
+    }
     // enqueue
     HIPCHK(c, launch_upload(S.h_args, S.d_args, (args_used + 15) / 16, S.d_qctl, (size_t)nb * 2 * BHRAY_MAX_LEVELS, st));   // + queue control reset
     HIPCHK(c, hipEventRecord(S.uploaded, st));
     if (count) HIPCHK(c, hipMemsetAsync(S.d_counters, 0, (size_t)nb * BHRAY_MAX_LEVELS * sizeof(Counters64), st));
-    const size_t ring = (size_t)(c->batch_counter % BHRAY_TIMING_RING);
-    hipEvent_t* fev = timing ? &c->events[ring * (nl * 3 + 2)] : nullptr;
+    hipEvent_t* fev = timing ? &c->events[ring * (nl * 3 + 4)] : nullptr;
     if (timing) { c->sky_recorded[ring] = 0; c->ring_frames[ring] = (uint8_t)nb; }
     for (const Launch& Ln : seq) {
         if (timing) for (int e : Ln.ev_before) HIPCHK(c, hipEventRecord(fev[e], st));
@@ -1068,6 +1103,60 @@ int dev_read_hdr(bhray_dev* c, float* dst, size_t pitch) {
     return BHRAY_OK;
 }
 
+// Asynchronous hand-off of the most recently enqueued frame to host memory (a consumer on another device: the wgpu texture the
+// reference's SkyPipeline samples, ray_pipeline.rs:297-299, mod.rs:215).  The copy is enqueued on the engine's copy streams -
+// the two halves of the frame on two streams, i.e. two SDMA engines - behind that frame's kernels; the call returns at once, frame
+// k's copy overlaps frame k+1's render.  `dst` should be pinned (bhray_host_alloc / hipHostRegister): a pageable destination makes
+// the runtime stage the copy and the call synchronous.  The slot's next frame waits for the copy before it overwrites the image.
+int dev_read_hdr_async(bhray_dev* c, float* dst, size_t pitch, uint64_t* ticket) {
+    if (!c || !ticket) return BHRAY_E_INVALID;
+    const size_t rowb = (size_t)c->cfg.frame_w * sizeof(float4);
+    if (!c->rendered) return fail(c, BHRAY_E_STATE, "nothing rendered yet");
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rc = launch_batch(c); if (rc) return rc; }
+    const uint64_t t = c->read_tickets;
+    hipEvent_t& ev = c->read_ev[t % BHRAY_READ_RING];
+    if (!ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    else if (t >= BHRAY_READ_RING) HIPCHK(c, hipEventSynchronize(ev));          // the ticket that held this event 64 copies ago
+    Slot& S = c->slots[(size_t)c->last_slot];
+    const size_t rows = c->local_rows.size();
+    if (rows) {
+        if (!dst || pitch < rowb) return fail(c, BHRAY_E_INVALID, "bad destination / pitch");
+        const uint8_t* src = (const uint8_t*)S.fr[(size_t)c->last_sub].out;
+        const size_t half = rows / 2;
+        for (int k = 0; k < BHRAY_COPY_STREAMS; k++) {
+            hipStream_t& cs = c->copy_stream[k];
+            if (!cs) HIPCHK(c, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+            const size_t r0 = k == 0 ? 0 : half, r1 = k == 0 ? half : rows;
+            HIPCHK(c, hipStreamWaitEvent(cs, S.done, 0));
+            if (r1 > r0) {
+                if (pitch == rowb) HIPCHK(c, hipMemcpyAsync((uint8_t*)dst + r0 * pitch, src + r0 * rowb, (r1 - r0) * rowb, hipMemcpyDeviceToHost, cs));
+                else HIPCHK(c, hipMemcpy2DAsync((uint8_t*)dst + r0 * pitch, pitch, src + r0 * rowb, rowb, rowb, r1 - r0, hipMemcpyDeviceToHost, cs));
+            }
+        }
+        // one event for the whole frame: stream 0 joins stream 1
+        if (!c->copy_join) HIPCHK(c, hipEventCreateWithFlags(&c->copy_join, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->copy_join, c->copy_stream[1]));
+        HIPCHK(c, hipStreamWaitEvent(c->copy_stream[0], c->copy_join, 0));
+    } else if (!c->copy_stream[0]) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream[0], hipStreamNonBlocking));
+    }
+    HIPCHK(c, hipEventRecord(ev, c->copy_stream[0]));
+    HIPCHK(c, hipStreamWaitEvent(S.stream, ev, 0));        // the slot's next batch overwrites the image only after the copy has read it
+    *ticket = t;
+    c->read_tickets = t + 1;
+    return BHRAY_OK;
+}
+
+int dev_wait_read(bhray_dev* c, uint64_t ticket) {
+    if (!c) return BHRAY_E_INVALID;
+    if (ticket >= c->read_tickets) return fail(c, BHRAY_E_INVALID, "unknown read ticket");
+    if (c->read_tickets - ticket > BHRAY_READ_RING) return BHRAY_OK;              // its event was waited for when it was recycled
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->read_ev[ticket % BHRAY_READ_RING]));
+    return BHRAY_OK;
+}
+
 int dev_read_level(bhray_dev* c, uint32_t level, float* dst, size_t pitch) {
     if (!c) return BHRAY_E_INVALID;
     if (level >= c->cfg.levels) return fail(c, BHRAY_E_INVALID, "level out of range");
@@ -1119,7 +1208,7 @@ int dev_resolve_sky(bhray_dev* c) {
     TexDev sky; sky.rgba = c->tex[BHRAY_TEX_SKY]; sky.w = c->tex_w[BHRAY_TEX_SKY]; sky.h = c->tex_h[BHRAY_TEX_SKY];
     const bool timing = (c->cfg.flags & BHRAY_F_TIMING) != 0;
     const size_t ring = (size_t)(S.batch_id % BHRAY_TIMING_RING);
-    hipEvent_t* ev = timing ? &c->events[ring * (c->cfg.levels * 3 + 2) + c->cfg.levels * 3] : nullptr;
+    hipEvent_t* ev = timing ? &c->events[ring * (c->cfg.levels * 3 + 4) + c->cfg.levels * 3] : nullptr;
     if (timing) HIPCHK(c, hipEventRecord(ev[0], S.stream));
     HIPCHK(c, launch_sky(sky, R.out, R.sky_out, npix, S.stream));
     if (timing) { HIPCHK(c, hipEventRecord(ev[1], S.stream)); c->sky_recorded[ring] = 1; }
@@ -1266,7 +1355,7 @@ int dev_get_timing(bhray_dev* c, bhray_timing* out) {
     if (c->batch_counter - begin > BHRAY_TIMING_RING) begin = c->batch_counter - BHRAY_TIMING_RING;
     for (uint64_t f = begin; f < c->batch_counter; f++) {
         const size_t ring = (size_t)(f % BHRAY_TIMING_RING);
-        hipEvent_t* ev = &c->events[ring * (nl * 3 + 2)];
+        hipEvent_t* ev = &c->events[ring * (nl * 3 + 4)];
         if (!c->ring_frames[ring]) continue;                           // a batch without events (BHRAY_F_TIMING_SPARSE)
         if (c->sky_recorded[ring]) {
             float t = 0; HIPCHK(c, hipEventElapsedTime(&t, ev[3 * nl], ev[3 * nl + 1])); out->sky_ms += t; out->sky_launches++;
@@ -1284,9 +1373,28 @@ int dev_get_timing(bhray_dev* c, bhray_timing* out) {
             if (!first) first = ev[3 * l];
             last = ev[3 * l + 2];
         }
+        if ((c->cfg.flags & BHRAY_F_TEMPORAL) && first) {      // prediction + predicted trace launch: the bulk of a temporal-mode frame
+            float t = 0; HIPCHK(c, hipEventElapsedTime(&t, ev[3 * nl + 2], ev[3 * nl + 3]));
+            out->predicted_trace_ms += t; out->predicted_launches++;
+            first = ev[3 * nl + 2];
+        }
         if (first && last) { float t = 0; HIPCHK(c, hipEventElapsedTime(&t, first, last)); out->total_ms += t; }
         out->frames += c->ring_frames[ring];
         out->batches++;
+    }
+    if (c->d_span) {
+        std::vector<unsigned long long> sp((size_t)BHRAY_TIMING_RING * SPAN_MAX * 2);
+        HIPCHK(c, hipMemcpy(sp.data(), c->d_span, sp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (uint64_t f = begin; f < c->batch_counter; f++) {
+            const size_t ring = (size_t)(f % BHRAY_TIMING_RING);
+            if (!c->ring_frames[ring]) continue;
+            for (int t = 0; t < (int)c->ring_spans[ring]; t++) {
+                const unsigned long long a = ~sp[(ring * SPAN_MAX + (size_t)t) * 2], b = sp[(ring * SPAN_MAX + (size_t)t) * 2 + 1];
+                if (sp[(ring * SPAN_MAX + (size_t)t) * 2] == 0ull || b < a) continue;       // the launch never ran (no rows)
+                out->trace_exec_ms += (float)((double)(b - a) / c->wall_clock_khz);
+                out->trace_exec_launches++;
+            }
+        }
     }
     c->timing_begin = c->batch_counter;
     return BHRAY_OK;

@@ -127,6 +127,8 @@ struct CommRank {                  // a local rank of the communicator: one GPU 
     hipStream_t stream = nullptr;  // communication stream of that GPU (sends / receives / de-interleave)
 };
 
+struct WaitEvent { hipEvent_t ev = nullptr; int device = -1; bool in_use = false; };
+
 struct GroupSlot {                 // per batch slot (same index as the devices' slots)
     float4* frames = nullptr;                 // root: B assembled frames
     float4* staging = nullptr;                // root: tiles of the other partitions, [part][frame of batch][row][x]
@@ -156,9 +158,14 @@ struct bhray_ctx {
     RowDesc* d_table = nullptr; uint32_t table_rows = 0;      // root GPU
     size_t staging_rows = 0;               // rows of one staging buffer (all non-root partitions, B frames)
     float4* bound = nullptr;               // bhray_bind_output: destination of the next frame (one-shot)
-    hipEvent_t wait_ev = nullptr;          // bhray_wait_stream
+    hipStream_t copy_stream = nullptr;     // gather mode: bhray_read_hdr_async (root GPU)
+    hipEvent_t read_ev[64] = {nullptr};
+    uint64_t read_tickets = 0;
+    std::vector<void*> external;           // bhray_import_external_fd: hipExternalMemory_t handles, by mapped pointer (pairs: ptr, handle)
+    std::vector<WaitEvent> wait_pool;      // bhray_wait_stream: one event per call until the next render has consumed them
     int last_slot = 0; uint32_t last_sub = 0;
     bool rendered = false;
+    bool failed = false;                   // a collective failed half way: the communicator's state is unknown, every later gather is refused
     float gather_ms = 0, deint_ms = 0; uint32_t gathers = 0;
     std::string err;
 };
@@ -197,6 +204,7 @@ size_t frame_pixels(const bhray_ctx* c) { return (size_t)c->cfg.frame_w * (size_
 int group_gather(bhray_ctx* c, int si, uint32_t nb) {
     Rccl* R = rccl();
     if (!R) return gfail(c, BHRAY_E_COMM, "%s", g_rccl.error.c_str());
+    if (c->failed) return gfail(c, BHRAY_E_COMM, "an earlier gather of this ctx failed inside its RCCL group; destroy the ctx");
     GroupSlot& G = c->gslots[(size_t)si];
     const size_t W = c->cfg.frame_w;
     const bool timing = (c->cfg.flags & (BHRAY_F_TIMING | BHRAY_F_TIMING_SPARSE)) != 0;
@@ -213,20 +221,30 @@ int group_gather(bhray_ctx* c, int si, uint32_t nb) {
     // ONE group: every tile of the batch.  Sends and receives are issued in partition order, so the messages between
     // a pair of ranks (several partitions may share a rank) match in order.
     GNCCL(c, R, R->GroupStart());
-    for (uint32_t q = 0; q < c->world; q++) {
-        Part& p = c->parts[q];
-        if (q == c->root || !p.dev || p.rows == 0) continue;
-        CommRank* cr = rank_of(c, p);
-        GHIP(c, hipSetDevice(p.device));
-        GNCCL(c, R, R->Send(G.send[q], (size_t)nb * p.rows * W * 4, ncclFloat32, rp.rank, cr->comm, cr->stream));
-    }
-    if (rr) {
-        GHIP(c, hipSetDevice(rr->device));
-        for (uint32_t q = 0; q < c->world; q++) {
-            const Part& p = c->parts[q];
-            if (q == c->root || p.rows == 0) continue;
-            GNCCL(c, R, R->Recv(G.staging + p.stage_row0 * W, (size_t)nb * p.rows * W * 4, ncclFloat32, p.rank, rr->comm, rr->stream));
-        }
+    {
+        // an error between GroupStart and GroupEnd must not leave the thread's RCCL group open (later collectives of this or any
+        // other ctx would be queued into it, peers of a multi-process run would hang): close it, then report
+        int grc = BHRAY_OK;
+        auto in_group = [&]() -> int {
+            for (uint32_t q = 0; q < c->world; q++) {
+                Part& p = c->parts[q];
+                if (q == c->root || !p.dev || p.rows == 0) continue;
+                CommRank* cr = rank_of(c, p);
+                GHIP(c, hipSetDevice(p.device));
+                GNCCL(c, R, R->Send(G.send[q], (size_t)nb * p.rows * W * 4, ncclFloat32, rp.rank, cr->comm, cr->stream));
+            }
+            if (rr) {
+                GHIP(c, hipSetDevice(rr->device));
+                for (uint32_t q = 0; q < c->world; q++) {
+                    const Part& p = c->parts[q];
+                    if (q == c->root || p.rows == 0) continue;
+                    GNCCL(c, R, R->Recv(G.staging + p.stage_row0 * W, (size_t)nb * p.rows * W * 4, ncclFloat32, p.rank, rr->comm, rr->stream));
+                }
+            }
+            return BHRAY_OK;
+        };
+        grc = in_group();
+        if (grc != BHRAY_OK) { (void)R->GroupEnd(); c->failed = true; return grc; }      // c->err keeps the first message
     }
     GNCCL(c, R, R->GroupEnd());
     // a slot's next batch may overwrite its send buffer only after the send has read it
@@ -325,7 +343,10 @@ void group_free(bhray_ctx* c) {
         if (r.comm && R) (void)R->CommDestroy(r.comm);
         if (r.stream) (void)hipStreamDestroy(r.stream);
     }
-    if (c->wait_ev) (void)hipEventDestroy(c->wait_ev);
+    if (c->copy_stream) { (void)hipSetDevice(c->parts[c->root].device); (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    for (auto& e : c->read_ev) if (e) (void)hipEventDestroy(e);
+    for (size_t i = 0; i + 1 < c->external.size(); i += 2) if (c->external[i + 1]) (void)hipDestroyExternalMemory((hipExternalMemory_t)c->external[i + 1]);
+    for (WaitEvent& w : c->wait_pool) if (w.ev) { (void)hipSetDevice(w.device); (void)hipEventDestroy(w.ev); }
 }
 
 // destination of the frame about to be staged at (slot, sub): every local partition's output binding
@@ -603,6 +624,7 @@ int bhray_render(bhray_ctx* c) {
         bhray_dev* d = c->parts[0].dev;
         if (c->bound) { DEV(c, d, dev_bind_output(d, c->bound, (size_t)-1)); c->bound = nullptr; }
         DEV(c, d, dev_render(d));
+        for (WaitEvent& w : c->wait_pool) w.in_use = false;      // the render's stream waits have been enqueued
         c->rendered = true;
         return BHRAY_OK;
     }
@@ -618,6 +640,7 @@ int bhray_render(bhray_ctx* c) {
     { int rc = after_launch(c); if (rc) return rc; }
     { int rc = bind_partitions(c, si, sub); if (rc) return rc; }
     for (Part& p : c->parts) if (p.dev) DEV(c, p.dev, dev_render(p.dev));
+    for (WaitEvent& w : c->wait_pool) w.in_use = false;
     c->last_slot = si; c->last_sub = sub; c->rendered = true;
     return after_launch(c);
 }
@@ -721,14 +744,114 @@ int bhray_bind_output(bhray_ctx* c, void* p, size_t bytes) {
     return BHRAY_OK;
 }
 
+// ---- asynchronous hand-off -------------------------------------------------------------------------
+int bhray_read_hdr_async(bhray_ctx* c, float* dst, size_t pitch, uint64_t* ticket) {
+    if (!c || !ticket) return BHRAY_E_INVALID;
+    if (c->single) { DEV(c, c->parts[0].dev, dev_read_hdr_async(c->parts[0].dev, dst, pitch, ticket)); return BHRAY_OK; }
+    if (!c->rendered) return gfail(c, BHRAY_E_STATE, "nothing rendered yet");
+    { int rc = group_flush(c); if (rc) return rc; }
+    const uint64_t t = c->read_tickets;
+    *ticket = t; c->read_tickets = t + 1;
+    if (!c->root_local) return BHRAY_OK;                        // the frame lives on another rank: nothing to copy here
+    const size_t rowb = (size_t)c->cfg.frame_w * sizeof(float4);
+    if (!dst || pitch < rowb) return gfail(c, BHRAY_E_INVALID, "bad destination / pitch");
+    Part& rp = *root_part(c);
+    GHIP(c, hipSetDevice(rp.device));
+    if (!c->copy_stream) GHIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    hipEvent_t& ev = c->read_ev[t % 64];
+    if (!ev) GHIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    else if (t >= 64) GHIP(c, hipEventSynchronize(ev));
+    GroupSlot& G = c->gslots[(size_t)c->last_slot];
+    GHIP(c, hipStreamWaitEvent(c->copy_stream, G.frame_done, 0));        // behind the de-interleave (and the sky pass, if it was resolved)
+    if (pitch == rowb) GHIP(c, hipMemcpyAsync(dst, G.dst[c->last_sub], rowb * c->cfg.frame_h, hipMemcpyDeviceToHost, c->copy_stream));
+    else GHIP(c, hipMemcpy2DAsync(dst, pitch, G.dst[c->last_sub], rowb, rowb, c->cfg.frame_h, hipMemcpyDeviceToHost, c->copy_stream));
+    GHIP(c, hipEventRecord(ev, c->copy_stream));
+    GHIP(c, hipStreamWaitEvent(dev_slot_stream(rp.dev, c->last_slot), ev, 0));   // the root's next render into this slot writes its own rows into that frame
+    CommRank* rr = rank_of(c, rp);
+    GHIP(c, hipStreamWaitEvent(rr->stream, ev, 0));                              // ... and so does the next de-interleave
+    return BHRAY_OK;
+}
+
+int bhray_wait_read(bhray_ctx* c, uint64_t ticket) {
+    if (!c) return BHRAY_E_INVALID;
+    if (c->single) { DEV(c, c->parts[0].dev, dev_wait_read(c->parts[0].dev, ticket)); return BHRAY_OK; }
+    if (ticket >= c->read_tickets) return gfail(c, BHRAY_E_INVALID, "unknown read ticket");
+    if (!c->root_local || c->read_tickets - ticket > 64 || !c->read_ev[ticket % 64]) return BHRAY_OK;
+    GHIP(c, hipSetDevice(root_part(c)->device));
+    GHIP(c, hipEventSynchronize(c->read_ev[ticket % 64]));
+    return BHRAY_OK;
+}
+
+int bhray_host_alloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) return BHRAY_E_INVALID;
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return gfail(nullptr, e == hipErrorOutOfMemory ? BHRAY_E_NOMEM : BHRAY_E_HIP, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return BHRAY_OK;
+}
+
+int bhray_host_free(void* p) {
+    if (!p) return BHRAY_OK;
+    hipError_t e = hipHostFree(p);
+    if (e != hipSuccess) return gfail(nullptr, BHRAY_E_HIP, "hipHostFree: %s", hipGetErrorString(e));
+    return BHRAY_OK;
+}
+
+// ---- zero-copy hand-off: memory exported by the consumer's API ---------------------------------------
+int bhray_import_external_fd(bhray_ctx* c, int fd, size_t bytes, void** dev_ptr) {
+    if (!c || !dev_ptr || fd < 0 || bytes == 0) return BHRAY_E_INVALID;
+    *dev_ptr = nullptr;
+    const int dev = c->single ? c->parts[0].device : (c->root_local ? root_part(c)->device : -1);
+    if (dev < 0) return gfail(c, BHRAY_E_STATE, "this rank does not deliver the frame");
+    GHIP(c, hipSetDevice(dev));
+    hipExternalMemoryHandleDesc hd; memset(&hd, 0, sizeof hd);
+    hd.type = hipExternalMemoryHandleTypeOpaqueFd;
+    hd.handle.fd = fd;
+    hd.size = bytes;
+    hipExternalMemory_t em = nullptr;
+    hipError_t e = hipImportExternalMemory(&em, &hd);
+    if (e != hipSuccess) return gfail(c, BHRAY_E_HIP, "hipImportExternalMemory(fd %d, %zu bytes): %s", fd, bytes, hipGetErrorString(e));
+    hipExternalMemoryBufferDesc bd; memset(&bd, 0, sizeof bd);
+    bd.offset = 0; bd.size = bytes;
+    void* p = nullptr;
+    e = hipExternalMemoryGetMappedBuffer(&p, em, &bd);
+    if (e != hipSuccess || !p) { (void)hipDestroyExternalMemory(em); return gfail(c, BHRAY_E_HIP, "hipExternalMemoryGetMappedBuffer: %s", hipGetErrorString(e)); }
+    c->external.push_back(p); c->external.push_back((void*)em);
+    *dev_ptr = p;
+    return BHRAY_OK;
+}
+
+int bhray_release_external(bhray_ctx* c, void* dev_ptr) {
+    if (!c || !dev_ptr) return BHRAY_E_INVALID;
+    for (size_t i = 0; i + 1 < c->external.size(); i += 2) {
+        if (c->external[i] != dev_ptr) continue;
+        { int rc = bhray_sync(c); if (rc) return rc; }
+        hipError_t e = hipDestroyExternalMemory((hipExternalMemory_t)c->external[i + 1]);
+        c->external.erase(c->external.begin() + (long)i, c->external.begin() + (long)i + 2);
+        if (e != hipSuccess) return gfail(c, BHRAY_E_HIP, "hipDestroyExternalMemory: %s", hipGetErrorString(e));
+        return BHRAY_OK;
+    }
+    return gfail(c, BHRAY_E_INVALID, "not a pointer returned by bhray_import_external_fd");
+}
+
 // ---- ordering against caller streams ------------------------------------------------------------
 int bhray_wait_stream(bhray_ctx* c, void* s) {
     if (!c) return BHRAY_E_INVALID;
-    const int dev = c->single ? c->parts[0].device : (c->root_local ? root_part(c)->device : c->ranks[0].device);
+    // One event per call (two calls with different streams before one render are two dependencies), recorded with the STREAM's
+    // device current (a stream of another partition's GPU is fine: the renders wait across devices).  The events are handed
+    // to every local partition and recycled once the next bhray_render has consumed them.
+    int dev = c->single ? c->parts[0].device : (c->root_local ? root_part(c)->device : c->ranks[0].device);
+    if (s) { int sd = -1; if (hipStreamGetDevice((hipStream_t)s, &sd) == hipSuccess && sd >= 0) dev = sd; }
     GHIP(c, hipSetDevice(dev));
-    if (!c->wait_ev) GHIP(c, hipEventCreateWithFlags(&c->wait_ev, hipEventDisableTiming));
-    GHIP(c, hipEventRecord(c->wait_ev, (hipStream_t)s));
-    for (Part& p : c->parts) if (p.dev) DEV(c, p.dev, dev_wait_event(p.dev, c->wait_ev));
+    hipEvent_t ev = nullptr;
+    for (WaitEvent& w : c->wait_pool) if (!w.in_use && w.device == dev) { w.in_use = true; ev = w.ev; break; }
+    if (!ev) {
+        GHIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        WaitEvent w; w.ev = ev; w.device = dev; w.in_use = true;
+        c->wait_pool.push_back(w);
+    }
+    GHIP(c, hipEventRecord(ev, (hipStream_t)s));
+    for (Part& p : c->parts) if (p.dev) DEV(c, p.dev, dev_wait_event(p.dev, ev));
     return BHRAY_OK;
 }
 
@@ -770,6 +893,9 @@ int bhray_resolve_sky(bhray_ctx* c) {
     if (!G.sky[c->last_sub]) GHIP(c, hipMalloc(&G.sky[c->last_sub], frame_pixels(c) * sizeof(uint2)));
     DEV(c, rp.dev, dev_launch_sky(rp.dev, G.dst[c->last_sub], G.sky[c->last_sub], frame_pixels(c), rr->stream));   // behind the de-interleave
     GHIP(c, hipEventRecord(G.frame_done, rr->stream));
+    // the root's next render into this slot writes its own rows straight into the frame the sky pass is reading (the wait that
+    // group_gather enqueued captured the EARLIER record of frame_done, behind the de-interleave): order it behind this one
+    GHIP(c, hipStreamWaitEvent(dev_slot_stream(rp.dev, c->last_slot), G.frame_done, 0));
     return BHRAY_OK;
 }
 

@@ -117,6 +117,7 @@ struct FrameLaunch {
     uint32_t stamp_value;  // stamp of the current frame
     int probe_empty;       // trace: this launch is expected to find its queue (nearly) used up - look before the first atomic
     int blocks;            // predict (one launch, all levels): this level's own block count
+    unsigned long long* span; // trace, entry 0 of a timed launch: [0] max(~first block start) [1] max(last block end), device wall clock; nullptr: untimed
 };
 
 // classify / predict: a 256-thread block covers a rectangle of BX x BY 8x8-pixel tiles (4 waves, BX*BY/4 tiles each in turn)
@@ -128,9 +129,9 @@ struct FrameLaunch {
 #endif
 // launchers (bhray_kernels.hip); Pb / Fb are device arrays of nb entries
 hipError_t launch_classify(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int blocks, bool count, bool fixup, hipStream_t s);
-hipError_t launch_trace(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int method, bool models, bool count, bool dense, bool literal, int* err_flag,
+hipError_t launch_trace(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int method, bool models, bool count, bool dense, int eval, int* err_flag,
                         int grid_blocks, hipStream_t s);
-int trace_blocks_per_cu(int method, int has_models, int count, int dense, int literal);
+int trace_blocks_per_cu(int method, int has_models, int count, int dense, int eval);   // eval: 0 contract, 1 BHRAY_F_LITERAL, 2 BHRAY_F_EVAL_FMA
 // copies n16 16-byte words from pinned host memory to device memory with a kernel (stays on the compute queue: a DMA copy
 // between the launches of a stream costs a cross-engine handshake each time)
 // and zeroes `nzero` 32-bit words at `zero` (the queue control words of the batch) in the same launch

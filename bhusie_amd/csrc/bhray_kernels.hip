@@ -479,44 +479,92 @@ __device__ __forceinline__ void next_ray_euler(F3 q0, F3& pos, F3& dir, float st
     pos = fmadd3(dir, step, pos);
 }
 
-// The LITERAL reading of the integrator (BHRAY_F_LITERAL): ray.wgsl:401-480 operator by operator under N0-N2 — one binary32
-// operation per WGSL operator in source order, no fused multiply-add, no reassociation, IEEE division and square root as the
-// compiler lowers them; pow(d, 5) = ((d*d)*(d*d))*d, pow(l, 2) = l*l, pow(e, -0.001) the portable form.  Bit-identical to
-// oracle_set_literal(1) and to tests/golden/frames_literal.npz: the variant exists so that "the contract (N3/N7/N9/N10) is a
-// permitted evaluation of the shader text" is a measured distance between two kernels, not prose.  Not tuned.
-__device__ __forceinline__ F3 f_literal(F3 p, F3 bpos, float h2, float dist) {          // fn f, ray.wgsl:401-403
-    const F3 num = (p - bpos) * (-1.5f * h2);
-    return div_s(num, pow5(dist));
+// The LITERAL reading of the integrator (BHRAY_F_LITERAL, EVAL == 1): ray.wgsl:401-480 operator by operator under N0-N2 — one
+// binary32 operation per WGSL operator in source order, no fused multiply-add, no reassociation; pow(d, 5) = ((d*d)*(d*d))*d,
+// pow(l, 2) = l*l, pow(e, -0.001) the portable form.  Bit-identical to oracle_set_literal(1) and to tests/golden/frames_literal.npz:
+// the variant exists so that "the contract (N3/N7/N9/N10) is a permitted evaluation of the shader text" is a measured distance
+// between two kernels, not prose.  Tuned this round without changing a bit: the correctly rounded 1/x and sqrt(x) are the short
+// gfx950 sequences of N8 (rcp_rn / sqrt_rn: equal to the IEEE lowering on every input, bhray_selftest), the functions are inlined,
+// the reciprocal of dist^5 - the same value in all six evaluations of f - is formed once, and the step-size power is the
+// domain-specialised form (pow_m001_step == bh_pow_m001 on its whole domain).
+__device__ __forceinline__ float length_rn(F3 v) { return sqrt_rn(dot(v, v)); }                       // == length(v)
+__device__ __forceinline__ F3 normalize_rn(F3 v) {                                                    // == normalize(v) = v * (1 / length(v))
+    const float d = dot(v, v);
+    float r = rcp_newton(sqrt_corrected(d));
+    if (__builtin_expect(__ballot(!sqrt_in_range(d)) != 0ull, 0)) r = 1.0f / sqrtf(d);
+    return v * r;
 }
-__device__ __forceinline__ F3 wsum2(F3 a, float ca, F3 b, float cb) { return a * ca + b * cb; }
+__device__ __forceinline__ F3 f_literal(F3 p, F3 bpos, float h2, float inv_d5) {          // fn f, ray.wgsl:401-403: num / pow(dist, 5) = num * (1 / dist^5) (N2)
+    const F3 num = (p - bpos) * (-1.5f * h2);
+    return num * inv_d5;
+}
 __device__ constexpr float DB2 = KF(0.0 - 0.0), BA2 = KF(0.0);
-__device__ __noinline__ void next_ray_rk_literal(F3 bpos, F3& pos, F3& dir, float& h_io) {   // ray.wgsl:405-465 (D1: loop once)
+__device__ __forceinline__ void next_ray_rk_literal(F3 bpos, F3& pos, F3& dir, float& h_io) {   // ray.wgsl:405-465 (D1: loop once)
     const F3 p0 = pos, d0 = dir;
-    const float dist = length(p0 - bpos);
-    const float lc = length(cross(p0, d0));
+    const float dist = length_rn(p0 - bpos);
+    const float lc = length_rn(cross(p0, d0));
     const float h2 = lc * lc;
     const float h = h_io;
-    const F3 k1 = f_literal(p0, bpos, h2, dist);
-    const F3 k2 = f_literal(p0 + (k1 * A21) * h, bpos, h2, dist);
-    const F3 k3 = f_literal(p0 + (k1 * A31 + k2 * A32) * h, bpos, h2, dist);
-    const F3 k4 = f_literal(p0 + ((k1 * A41 + k2 * A42) + k2 * A43) * h, bpos, h2, dist);                         // a_43*k_2 (sic)
-    const F3 k5 = f_literal(p0 + (((k1 * A51 + k2 * A52) + k3 * A53) + k4 * A54) * h, bpos, h2, dist);
-    const F3 k6 = f_literal(p0 + ((((k1 * A61 + k2 * A62) + k3 * A63) + k4 * A64) + k5 * A65) * h, bpos, h2, dist);
+    const float i5 = rcp_rn(pow5(dist));
+    const F3 k1 = f_literal(p0, bpos, h2, i5);
+    const F3 k2 = f_literal(p0 + (k1 * A21) * h, bpos, h2, i5);
+    const F3 k3 = f_literal(p0 + (k1 * A31 + k2 * A32) * h, bpos, h2, i5);
+    const F3 k4 = f_literal(p0 + ((k1 * A41 + k2 * A42) + k2 * A43) * h, bpos, h2, i5);                         // a_43*k_2 (sic)
+    const F3 k5 = f_literal(p0 + (((k1 * A51 + k2 * A52) + k3 * A53) + k4 * A54) * h, bpos, h2, i5);
+    const F3 k6 = f_literal(p0 + ((((k1 * A61 + k2 * A62) + k3 * A63) + k4 * A64) + k5 * A65) * h, bpos, h2, i5);
     const F3 es = ((((k1 * DB1 + k2 * DB2) + k3 * DB3) + k4 * DB4) + k5 * DB5) + k6 * DB6;
     const F3 e = es * h;
     const float e_max = max_(max_(fabsf(e.x), fabsf(e.y)), fabsf(e.z));
     const F3 ds = ((((k1 * BA1 + k2 * BA2) + k3 * BA3) + k4 * BA4) + k5 * BA5) + k6 * BA6;
-    dir = normalize(d0 + ds * h);
+    dir = normalize_rn(d0 + ds * h);
     pos = p0 + d0 * h;                                                                                           // old direction
-    if (e_max > 0.00002f) h_io = h * (0.9f * bh_pow_m001(e_max));
+    if (e_max > 0.00002f) h_io = h * (0.9f * pow_m001_step(e_max));
     else h_io = h * 1.0001f;
 }
-__device__ __noinline__ void next_ray_euler_literal(F3 bpos, F3& pos, F3& dir, float step) {   // ray.wgsl:467-480
-    const float lc = length(cross(pos, dir));
+__device__ __forceinline__ void next_ray_euler_literal(F3 bpos, F3& pos, F3& dir, float step) {   // ray.wgsl:467-480
+    const float lc = length_rn(cross(pos, dir));
     const float h2 = lc * lc;
-    const float dist = length(pos - bpos);
-    dir = normalize(dir + f_literal(pos, bpos, h2, dist) * step);
+    const float dist = length_rn(pos - bpos);
+    dir = normalize_rn(dir + f_literal(pos, bpos, h2, rcp_rn(pow5(dist))) * step);
     pos = pos + dir * step;
+}
+
+// A THIRD evaluation (BHRAY_F_EVAL_FMA, EVAL == 2): the literal expression tree with fused multiply-add contraction ONLY - every
+// `x*y + z` of the text whose product is a direct operand of the addition is one fma, the first product of a sum of products stays
+// rounded - and none of the reassociations N9 / N10 (no per-step scalar, no step size folded into the stages, zero-coefficient
+// terms kept).  What a shader compiler's default contraction does to ray.wgsl:401-480, and nothing more.  Bit-identical to
+// oracle_set_eval(2).  It exists to show that the pixels on which the contract differs from the literal text by more than 1e-4
+// are the pixels on which ANY two legal evaluations differ (tests/test_gpu_literal.py).
+__device__ __forceinline__ void next_ray_rk_fma(F3 bpos, F3& pos, F3& dir, float& h_io) {
+    const F3 p0 = pos, d0 = dir;
+    const float dist = sqrt_rn(fdot(p0 - bpos, p0 - bpos));
+    const F3 cr = fcross(p0, d0);
+    const float lc = sqrt_rn(fdot(cr, cr));
+    const float h2 = lc * lc;
+    const float h = h_io;
+    const float i5 = rcp_rn(pow5(dist));
+    const F3 k1 = f_literal(p0, bpos, h2, i5);
+    const F3 k2 = f_literal(fmadd3(k1 * A21, h, p0), bpos, h2, i5);
+    const F3 k3 = f_literal(fmadd3(fmadd3(k2, A32, k1 * A31), h, p0), bpos, h2, i5);
+    const F3 k4 = f_literal(fmadd3(fmadd3(k2, A43, fmadd3(k2, A42, k1 * A41)), h, p0), bpos, h2, i5);
+    const F3 k5 = f_literal(fmadd3(fmadd3(k4, A54, fmadd3(k3, A53, fmadd3(k2, A52, k1 * A51))), h, p0), bpos, h2, i5);
+    const F3 k6 = f_literal(fmadd3(fmadd3(k5, A65, fmadd3(k4, A64, fmadd3(k3, A63, fmadd3(k2, A62, k1 * A61)))), h, p0), bpos, h2, i5);
+    const F3 es = fmadd3(k6, DB6, fmadd3(k5, DB5, fmadd3(k4, DB4, fmadd3(k3, DB3, fmadd3(k2, DB2, k1 * DB1)))));
+    const F3 e = es * h;
+    const float e_max = max_(max_(fabsf(e.x), fabsf(e.y)), fabsf(e.z));
+    const F3 ds = fmadd3(k6, BA6, fmadd3(k5, BA5, fmadd3(k4, BA4, fmadd3(k3, BA3, fmadd3(k2, BA2, k1 * BA1)))));
+    dir = fnormalize_rn(fmadd3(ds, h, d0));
+    pos = fmadd3(d0, h, p0);
+    if (e_max > 0.00002f) h_io = h * (0.9f * pow_m001_step(e_max));
+    else h_io = h * 1.0001f;
+}
+__device__ __forceinline__ void next_ray_euler_fma(F3 bpos, F3& pos, F3& dir, float step) {
+    const F3 cr = fcross(pos, dir);
+    const float lc = sqrt_rn(fdot(cr, cr));
+    const float h2 = lc * lc;
+    const float dist = sqrt_rn(fdot(pos - bpos, pos - bpos));
+    dir = fnormalize_rn(fmadd3(f_literal(pos, bpos, h2, rcp_rn(pow5(dist))), step, dir));
+    pos = fmadd3(dir, step, pos);
 }
 
 // number of set bits of a wave mask below this lane (prefix popcount): v_mbcnt_lo + v_mbcnt_hi, no per-lane mask registers
@@ -769,10 +817,17 @@ template <> struct ColdState<true> {
 #ifdef BHRAY_EXP_PROFILE
 __device__ long long xp_dump[8192 * 16];
 #endif
-template <int METHOD, bool MODELS, bool COUNT, bool DENSE, bool LIT = false>
+template <int METHOD, bool MODELS, bool COUNT, bool DENSE, int EVAL = 0>
 __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHRAY_TRACE_WAVES_DENSE : BHRAY_TRACE_WAVES)) void trace_kernel(const FrameParams* __restrict__ Pb, const FrameLaunch* __restrict__ Fb, const int nb, int* __restrict__ err_flag) {
     const int lane = threadIdx.x & 63;
     int err = 0;
+    // Execution span of this launch (timed batches only: Fb[0].span != nullptr): first block's start and last block's end on the
+    // device's constant-rate clock (s_memrealtime).  Unlike HIP events around the launch it excludes the time the launch waits in
+    // its queue behind the persistent kernels of other frames: it is what rocprofv3 --kernel-trace reports for the kernel.
+    // span[0] = max(~start) (zero-initialised), span[1] = max(end).
+#ifndef BHRAY_NO_SPAN
+    if (Fb[0].span && threadIdx.x == 0) atomicMax(&Fb[0].span[0], ~(unsigned long long)wall_clock64());
+#endif
     constexpr bool COLD_LDS = DENSE && !MODELS;
     __shared__ float cold_lds[COLD_LDS ? 8 * BHRAY_TRACE_THREADS : 1];
     // mesh variant: optional LDS staging of the top of the BVH and of the shallow part of the traversal stacks (trace_ray_model)
@@ -1233,6 +1288,9 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
         }
     }
     }   // frames of the batch
+#ifndef BHRAY_NO_SPAN
+    if (Fb[0].span && threadIdx.x == 0) atomicMax(&Fb[0].span[1], (unsigned long long)wall_clock64());
+#endif
     if (err) *err_flag = err;
 }
 
@@ -1387,48 +1445,50 @@ hipError_t launch_classify(const FrameParams* Pb, const FrameLaunch* Fb, int nb,
     return hipGetLastError();
 }
 
-template <int METHOD, bool MODELS, bool DENSE, bool LIT = false>
+template <int METHOD, bool MODELS, bool DENSE, int EVAL = 0>
 static hipError_t launch_trace_t(const FrameParams* Pb, const FrameLaunch* Fb, int nb, bool count, int* err_flag, int grid_blocks, hipStream_t s) {
     (void)hipGetLastError();
     constexpr size_t dyn_lds = MODELS ? (size_t)BHRAY_BVH_LDS_TOP * 32 + (size_t)BHRAY_BVH_LDS_STACK * BHRAY_TRACE_THREADS * 8 : 0;   // trace_ray_model's LDS
-    if (count) hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, true, DENSE, LIT>), dim3((grid_blocks * 256 + BHRAY_TRACE_THREADS - 1) / BHRAY_TRACE_THREADS), dim3(BHRAY_TRACE_THREADS), dyn_lds, s, Pb, Fb, nb, err_flag);
-    else hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, false, DENSE, LIT>), dim3((grid_blocks * 256 + BHRAY_TRACE_THREADS - 1) / BHRAY_TRACE_THREADS), dim3(BHRAY_TRACE_THREADS), dyn_lds, s, Pb, Fb, nb, err_flag);
+    if (count) hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, true, DENSE, EVAL>), dim3((grid_blocks * 256 + BHRAY_TRACE_THREADS - 1) / BHRAY_TRACE_THREADS), dim3(BHRAY_TRACE_THREADS), dyn_lds, s, Pb, Fb, nb, err_flag);
+    else hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, false, DENSE, EVAL>), dim3((grid_blocks * 256 + BHRAY_TRACE_THREADS - 1) / BHRAY_TRACE_THREADS), dim3(BHRAY_TRACE_THREADS), dyn_lds, s, Pb, Fb, nb, err_flag);
     return hipGetLastError();
 }
 
-hipError_t launch_trace(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int method, bool models, bool count, bool dense, bool literal, int* err_flag,
-                        int grid_blocks, hipStream_t s) {
-    if (nb <= 0) return hipSuccess;
-    if (literal) {      // BHRAY_F_LITERAL: the operator-by-operator integrator; one register budget per mesh / no-mesh
-        if (models) return method == 0 ? launch_trace_t<0, true, false, true>(Pb, Fb, nb, count, err_flag, grid_blocks, s)
-                                       : launch_trace_t<1, true, false, true>(Pb, Fb, nb, count, err_flag, grid_blocks, s);
-        return method == 0 ? launch_trace_t<0, false, false, true>(Pb, Fb, nb, count, err_flag, grid_blocks, s)
-                           : launch_trace_t<1, false, false, true>(Pb, Fb, nb, count, err_flag, grid_blocks, s);
-    }
-    if (models) {       // the mesh variant has one register budget
-        return method == 0 ? launch_trace_t<0, true, false>(Pb, Fb, nb, count, err_flag, grid_blocks, s)
-                           : launch_trace_t<1, true, false>(Pb, Fb, nb, count, err_flag, grid_blocks, s);
+// eval: 0 the numerics contract, 1 BHRAY_F_LITERAL, 2 BHRAY_F_EVAL_FMA.  The mesh variant has one register budget.
+template <int EVAL>
+static hipError_t launch_trace_e(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int method, bool models, bool count, bool dense, int* err_flag,
+                                 int grid_blocks, hipStream_t s) {
+    if (models) {
+        return method == 0 ? launch_trace_t<0, true, false, EVAL>(Pb, Fb, nb, count, err_flag, grid_blocks, s)
+                           : launch_trace_t<1, true, false, EVAL>(Pb, Fb, nb, count, err_flag, grid_blocks, s);
     }
     if (method == 0) {
-        return dense ? launch_trace_t<0, false, true>(Pb, Fb, nb, count, err_flag, grid_blocks, s)
-                     : launch_trace_t<0, false, false>(Pb, Fb, nb, count, err_flag, grid_blocks, s);
+        return dense ? launch_trace_t<0, false, true, EVAL>(Pb, Fb, nb, count, err_flag, grid_blocks, s)
+                     : launch_trace_t<0, false, false, EVAL>(Pb, Fb, nb, count, err_flag, grid_blocks, s);
     }
-    return dense ? launch_trace_t<1, false, true>(Pb, Fb, nb, count, err_flag, grid_blocks, s)
-                 : launch_trace_t<1, false, false>(Pb, Fb, nb, count, err_flag, grid_blocks, s);
+    return dense ? launch_trace_t<1, false, true, EVAL>(Pb, Fb, nb, count, err_flag, grid_blocks, s)
+                 : launch_trace_t<1, false, false, EVAL>(Pb, Fb, nb, count, err_flag, grid_blocks, s);
+}
+hipError_t launch_trace(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int method, bool models, bool count, bool dense, int eval, int* err_flag,
+                        int grid_blocks, hipStream_t s) {
+    if (nb <= 0) return hipSuccess;
+    if (eval == 1) return launch_trace_e<1>(Pb, Fb, nb, method, models, count, dense, err_flag, grid_blocks, s);
+    if (eval == 2) return launch_trace_e<2>(Pb, Fb, nb, method, models, count, dense, err_flag, grid_blocks, s);
+    return launch_trace_e<0>(Pb, Fb, nb, method, models, count, dense, err_flag, grid_blocks, s);
 }
 
-int trace_blocks_per_cu(int method, int has_models, int count, int dense, int literal) {
-    int n = 0;
-    const void* f;
-#define PICK(M, MD, C, D) (const void*)trace_kernel<M, MD, C, D>
-#define PICKL(M, MD, C) (const void*)trace_kernel<M, MD, C, false, true>
-    if (literal) f = has_models ? (method == 0 ? (count ? PICKL(0, true, true) : PICKL(0, true, false)) : (count ? PICKL(1, true, true) : PICKL(1, true, false)))
-                                : (method == 0 ? (count ? PICKL(0, false, true) : PICKL(0, false, false)) : (count ? PICKL(1, false, true) : PICKL(1, false, false)));
-    else if (has_models) f = method == 0 ? (count ? PICK(0, true, true, false) : PICK(0, true, false, false)) : (count ? PICK(1, true, true, false) : PICK(1, true, false, false));
-    else if (dense) f = method == 0 ? (count ? PICK(0, false, true, true) : PICK(0, false, false, true)) : (count ? PICK(1, false, true, true) : PICK(1, false, false, true));
-    else f = method == 0 ? (count ? PICK(0, false, true, false) : PICK(0, false, false, false)) : (count ? PICK(1, false, true, false) : PICK(1, false, false, false));
+template <int EVAL>
+static const void* trace_kernel_ptr(int method, int has_models, int count, int dense) {
+#define PICK(M, MD, C, D) (const void*)trace_kernel<M, MD, C, D, EVAL>
+    if (has_models) return method == 0 ? (count ? PICK(0, true, true, false) : PICK(0, true, false, false)) : (count ? PICK(1, true, true, false) : PICK(1, true, false, false));
+    if (dense) return method == 0 ? (count ? PICK(0, false, true, true) : PICK(0, false, false, true)) : (count ? PICK(1, false, true, true) : PICK(1, false, false, true));
+    return method == 0 ? (count ? PICK(0, false, true, false) : PICK(0, false, false, false)) : (count ? PICK(1, false, true, false) : PICK(1, false, false, false));
 #undef PICK
-#undef PICKL
+}
+int trace_blocks_per_cu(int method, int has_models, int count, int dense, int eval) {
+    int n = 0;
+    const void* f = eval == 1 ? trace_kernel_ptr<1>(method, has_models, count, dense)
+                  : eval == 2 ? trace_kernel_ptr<2>(method, has_models, count, dense) : trace_kernel_ptr<0>(method, has_models, count, dense);
     const size_t dyn_lds = has_models ? (size_t)BHRAY_BVH_LDS_TOP * 32 + (size_t)BHRAY_BVH_LDS_STACK * BHRAY_TRACE_THREADS * 8 : 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, BHRAY_TRACE_THREADS, dyn_lds) != hipSuccess || n < 1) n = 2;
     n = n * BHRAY_TRACE_THREADS / 256;            // in units of 256 threads (the grid is sized in those)

@@ -14,6 +14,7 @@ F_TIMING = 2
 F_LITERAL = 4
 F_TEMPORAL = 8
 F_TIMING_SPARSE = 16
+F_EVAL_FMA = 32
 TEX_TEMP_LUT, TEX_DISK, TEX_SKY = 0, 1, 2
 
 
@@ -97,7 +98,9 @@ class BhrayTiming(C.Structure):
                 ("trace_launches", C.c_uint32), ("classify_launches", C.c_uint32),
                 ("level_trace_ms", C.c_float * MAX_LEVELS), ("level_classify_ms", C.c_float * MAX_LEVELS),
                 ("sky_ms", C.c_float), ("sky_launches", C.c_uint32),
-                ("gather_ms", C.c_float), ("deinterleave_ms", C.c_float), ("gathers", C.c_uint32)]
+                ("gather_ms", C.c_float), ("deinterleave_ms", C.c_float), ("gathers", C.c_uint32),
+                ("predicted_trace_ms", C.c_float), ("predicted_launches", C.c_uint32),
+                ("trace_exec_ms", C.c_float), ("trace_exec_launches", C.c_uint32)]
 
 
 class BhrayGatherInfo(C.Structure):
@@ -143,6 +146,12 @@ SYMBOLS = {
     "bhray_local_row_index": (C.c_int, [vp, u32, P(u32)]),
     "bhray_hdr_device_ptr": (C.c_int, [vp, P(vp), P(sz)]),
     "bhray_bind_output": (C.c_int, [vp, vp, sz]),
+    "bhray_read_hdr_async": (C.c_int, [vp, vp, sz, P(C.c_uint64)]),
+    "bhray_wait_read": (C.c_int, [vp, C.c_uint64]),
+    "bhray_host_alloc": (C.c_int, [sz, P(vp)]),
+    "bhray_host_free": (C.c_int, [vp]),
+    "bhray_import_external_fd": (C.c_int, [vp, C.c_int, sz, P(vp)]),
+    "bhray_release_external": (C.c_int, [vp, vp]),
     "bhray_resolve_sky": (C.c_int, [vp]),
     "bhray_read_sky": (C.c_int, [vp, vp, sz]),
     "bhray_sky_device_ptr": (C.c_int, [vp, P(vp), P(sz)]),

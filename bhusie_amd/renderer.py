@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 
 from ._lib import lib
-from .layouts import (F_COUNTERS, F_LITERAL, F_TEMPORAL, F_TIMING, F_TIMING_SPARSE, GATHER_RCCL, TEX_DISK, TEX_SKY, TEX_TEMP_LUT, BhrayConfig, BhrayCounters,
+from .layouts import (F_COUNTERS, F_EVAL_FMA, F_LITERAL, F_TEMPORAL, F_TIMING, F_TIMING_SPARSE, GATHER_RCCL, TEX_DISK, TEX_SKY, TEX_TEMP_LUT, BhrayConfig, BhrayCounters,
                       BhrayGatherInfo, BhrayTiming, check)
 from .model import Model
 from .scene import BlackHole, Camera, RayDetails
@@ -59,7 +59,7 @@ class RayPass:
 
     def __init__(self, cfg: BhrayConfig, device=0, counters=False, timing=False, row_rank=0, row_world=1, stripe_rows=27,
                  frames_in_flight=0, speculative_levels=0, frames_per_batch=0, devices=None, gather_root=0, comm_id=None,
-                 literal=False, superset_levels=0, temporal=False):
+                 literal=False, superset_levels=0, temporal=False, eval_fma=False):
         cfg = BhrayConfig.from_buffer_copy(bytes(cfg))
         cfg.struct_size = C.sizeof(BhrayConfig)
         cfg.device = device
@@ -72,7 +72,7 @@ class RayPass:
             assert len(comm_id) == 128
             cfg.gather = GATHER_RCCL
             C.memmove(cfg.comm_id, bytes(comm_id), 128)
-        cfg.flags = (F_COUNTERS if counters else 0) | (F_TIMING_SPARSE if timing == "sparse" else (F_TIMING if timing else 0)) | (F_LITERAL if literal else 0) | (F_TEMPORAL if temporal else 0)
+        cfg.flags = (F_COUNTERS if counters else 0) | (F_TIMING_SPARSE if timing == "sparse" else (F_TIMING if timing else 0)) | (F_LITERAL if literal else 0) | (F_TEMPORAL if temporal else 0) | (F_EVAL_FMA if eval_fma else 0)
         cfg.row_rank, cfg.row_world, cfg.stripe_rows = row_rank, row_world, stripe_rows
         cfg.frames_in_flight = frames_in_flight
         cfg.speculative_levels = speculative_levels
@@ -157,6 +157,24 @@ class RayPass:
         check(lib().bhray_read_hdr(self._h, out.ctypes.data, int(self.cfg.frame_w) * 16), self._h)
         return out
 
+    def read_hdr_async(self, dst: "PinnedFrame") -> int:
+        """Enqueue the device->host copy of the most recently enqueued frame into pinned memory, behind its kernels; returns a ticket."""
+        t = C.c_uint64()
+        check(lib().bhray_read_hdr_async(self._h, C.c_void_p(dst.ptr), int(self.cfg.frame_w) * 16, C.byref(t)), self._h)
+        return int(t.value)
+
+    def wait_read(self, ticket: int):
+        check(lib().bhray_wait_read(self._h, C.c_uint64(ticket)), self._h)
+
+    def import_external_fd(self, fd: int, nbytes: int) -> int:
+        """Map memory exported by another API (Vulkan OPAQUE_FD / dma-buf) on the GPU that delivers the frame; returns a device pointer for bind_output."""
+        p = C.c_void_p()
+        check(lib().bhray_import_external_fd(self._h, int(fd), nbytes, C.byref(p)), self._h)
+        return p.value
+
+    def release_external(self, ptr: int):
+        check(lib().bhray_release_external(self._h, C.c_void_p(ptr)), self._h)
+
     def read_level(self, level: int) -> np.ndarray:
         w, h = int(self.cfg.level_w[level]), int(self.cfg.level_h[level])
         out = np.empty((h, w, 4), dtype=np.float32)
@@ -222,6 +240,29 @@ class RayPass:
         t = BhrayTiming()
         check(lib().bhray_get_timing(self._h, C.byref(t)), self._h)
         return t
+
+
+class PinnedFrame:
+    """Pinned host memory for one RGBA32F frame (bhray_host_alloc), viewed as a (rows, width, 4) float32 array."""
+
+    def __init__(self, rows: int, width: int):
+        p = C.c_void_p()
+        self.nbytes = rows * width * 16
+        check(lib().bhray_host_alloc(self.nbytes, C.byref(p)))
+        self.ptr = p.value
+        self.array = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(rows, width, 4))
+
+    def free(self):
+        p, self.ptr = self.ptr, None
+        if p:
+            self.array = None
+            check(lib().bhray_host_free(C.c_void_p(p)))
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class Renderer:

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define BHRAY_VERSION_MAJOR 0
-#define BHRAY_VERSION_MINOR 2
+#define BHRAY_VERSION_MINOR 3
 
 /* ------------------------------------------------------------------------------------------
  * Error codes
@@ -158,10 +158,16 @@ enum {                                  /* bhray_config.flags */
                                            border pixels: DESIGN.md §4), +8 % rays; 1080p, one frame at a time: 0.78 ms with a static
                                            camera, 0.84-0.87 ms with a moving one, 1.20 ms without the flag.  levels <= 4, no
                                            speculative / superset levels.                                                    */
+    BHRAY_F_EVAL_FMA   = 1u << 5,       /* a THIRD evaluation of the integrator: the shader text with fused multiply-add contraction only
+                                           (every `x*y + z` of ray.wgsl:401-480 one fma), none of the contract's reassociations (N9/N10).
+                                           Like BHRAY_F_LITERAL it exists for measurement: the pixels on which it differs from the literal
+                                           text by more than 1e-4 are the pixels on which the default evaluation does
+                                           (tests/test_gpu_literal.py).  Ignored when BHRAY_F_LITERAL is set.                        */
     BHRAY_F_LITERAL    = 1u << 2        /* the integrator (ray.wgsl:401-480, 533) operator by operator: one binary32 operation per
                                            WGSL operator in source order, no fused multiply-add, no reassociation.  Slower; exists
                                            to MEASURE how far the default evaluation (DESIGN.md §2, N3/N7/N9/N10 — permitted by
-                                           WGSL, cheaper on CDNA4) is from the shader text: tests/test_gpu_literal.py       */
+                                           WGSL, cheaper on CDNA4) is from the shader text: tests/test_gpu_literal.py.  Cost: bench.py's
+                                           `literal` entry                                                          */
 };
 
 /* The ladder is the reference's chain of RayPipelines (mod.rs:170-207): level 0 traces every
@@ -325,6 +331,28 @@ int bhray_local_row_index(const bhray_ctx* ctx, uint32_t i, uint32_t* frame_row)
 int bhray_hdr_device_ptr(bhray_ctx* ctx, void** dev_ptr, size_t* bytes);
 int bhray_bind_output(bhray_ctx* ctx, void* dev_ptr, size_t bytes);
 
+/* Hand-off to a consumer that is NOT a HIP client of the same GPU (the reference's SkyPipeline samples the ray output as a wgpu
+ * texture: ray_pipeline.rs:297-299, mod.rs:215, sky.wgsl:4,17).  Two ways, cheapest first:
+ *
+ * (1) zero copy: the consumer exports the memory behind its texture / buffer as a file descriptor (Vulkan
+ *     VK_KHR_external_memory_fd: an OPAQUE_FD or dma-buf of a linear VkBuffer, which the host then copies to or aliases with its
+ *     Rgba32Float texture on its own queue); bhray_import_external_fd maps it into the address space of the GPU that delivers
+ *     the frame (hipImportExternalMemory) and returns a device pointer for bhray_bind_output.  The fd stays owned by the caller
+ *     (the import dup()s nothing: keep it open until bhray_release_external).  Ordering: bhray_sync, or an exported semaphore
+ *     the host signals from a stream it ordered with bhray_signal_stream.
+ * (2) asynchronous read-back: bhray_read_hdr_async enqueues the device->host copy of the most recently enqueued frame on the
+ *     library's copy streams (two SDMA engines, half the rows each), behind that frame's kernels, and returns at once with a
+ *     ticket; frame k's copy overlaps frame k+1's render.  bhray_wait_read(ticket) blocks until that frame has landed.  `dst`
+ *     must stay valid until then and should be pinned host memory (bhray_host_alloc, or the host's own hipHostRegister):
+ *     a pageable destination makes the runtime stage the copy.  A slot's image is not overwritten before its copy has read it.
+ *     At most 64 tickets are outstanding (the 65th call waits for the oldest).  Multi-GPU ctx: the assembled frame on the root. */
+int bhray_read_hdr_async(bhray_ctx* ctx, float* dst_rgba32f, size_t row_pitch_bytes, uint64_t* ticket);
+int bhray_wait_read(bhray_ctx* ctx, uint64_t ticket);
+int bhray_host_alloc(size_t bytes, void** out);               /* pinned host memory (hipHostMalloc) for hosts that do not link HIP */
+int bhray_host_free(void* p);
+int bhray_import_external_fd(bhray_ctx* ctx, int fd, size_t bytes, void** dev_ptr);
+int bhray_release_external(bhray_ctx* ctx, void* dev_ptr);
+
 /* Frames in flight.  The ladder levels of ONE frame are dependent launches, and the coarse levels
  * are far too small to fill 256 CUs (level 0 is ~3 k rays), so a ctx keeps `frames_in_flight`
  * frame slots, each with its own HIP stream and level/queue buffers; consecutive bhray_render
@@ -402,6 +430,14 @@ typedef struct bhray_timing {
     float    gather_ms;                /* multi-GPU, root: Σ (receive of the row tiles: start → all tiles arrived)   */
     float    deinterleave_ms;          /* multi-GPU, root: Σ de-interleave kernels                                   */
     uint32_t gathers;                  /* batches gathered                                                            */
+    float    predicted_trace_ms;       /* BHRAY_F_TEMPORAL: Σ (prediction + the predicted trace launch, all levels): the bulk of such a
+                                          frame; trace_ms / level_trace_ms then hold the fix-up launches only          */
+    uint32_t predicted_launches;
+    float    trace_exec_ms;            /* Σ EXECUTION spans of the trace kernels: first block's start → last block's end on the device's
+                                          constant-rate clock, stamped by the kernel itself.  trace_ms (HIP events in the stream) also
+                                          contains the time a launch waits for room beside the persistent kernels of the other frames
+                                          in flight; this is what `rocprofv3 --kernel-trace` reports as the kernel's duration          */
+    uint32_t trace_exec_launches;
 } bhray_timing;
 int bhray_get_timing(bhray_ctx* ctx, bhray_timing* out);       /* needs BHRAY_F_TIMING       */
 

@@ -519,11 +519,60 @@ def f_scale(h2, dist):
 # distance between the numerics contract (N3/N7/N9/N10: what the HIP kernel computes by default) and the shader text:
 # tests/golden/frames_literal.npz is generated from it and is never regenerated when the contract changes.
 LITERAL = False
+# A third evaluation (set_eval(2); C oracle: oracle_set_eval(2); kernel: BHRAY_F_EVAL_FMA): the literal expression tree with
+# fused multiply-add contraction ONLY - every `x*y + z` of ray.wgsl:401-480 whose product is a direct operand of the addition is
+# one fma, the first product of a sum of products stays rounded - and none of the contract's reassociations (N9 / N10).
+FMA_ONLY = False
 
 
 def set_literal(on: bool) -> None:
-    global LITERAL
+    global LITERAL, FMA_ONLY
     LITERAL = bool(on)
+    FMA_ONLY = False
+
+
+def set_eval(mode: int) -> None:
+    """0 the numerics contract, 1 the literal text, 2 fused multiply-add contraction only"""
+    global LITERAL, FMA_ONLY
+    LITERAL, FMA_ONLY = mode == 1, mode == 2
+
+
+def _fsum(terms):
+    """k_1*c_1 + k_2*c_2 + ... with the contraction a compiler applies: first product rounded, every further term one fma"""
+    k, c = terms[0]
+    acc = (k * c).astype(np.float32)
+    for k, c in terms[1:]:
+        acc = fma32(k, c, acc)
+    return acc
+
+
+def next_ray_euler_fma(S, pos, dirn, step):
+    lc = flen(fcross(pos, dirn)); h2 = lc * lc
+    dist = flen((pos - S.bh_pos).astype(np.float32))
+    nd = fnorm(fmadd3(f_literal(S, pos, h2, dist), step, dirn))
+    npos = fmadd3(nd, step, pos)
+    return npos.astype(np.float32), nd.astype(np.float32)
+
+
+def next_ray_rk_fma(S, pos, dirn, h):
+    dist = flen((pos - S.bh_pos).astype(np.float32))
+    lc = flen(fcross(pos, dirn)); h2 = lc * lc
+    k1 = f_literal(S, pos, h2, dist)
+    k2 = f_literal(S, fmadd3((k1 * A21).astype(np.float32), h, pos), h2, dist)
+    k3 = f_literal(S, fmadd3(_fsum([(k1, A31), (k2, A32)]), h, pos), h2, dist)
+    k4 = f_literal(S, fmadd3(_fsum([(k1, A41), (k2, A42), (k2, A43)]), h, pos), h2, dist)                 # a_43*k_2 (sic)
+    k5 = f_literal(S, fmadd3(_fsum([(k1, A51), (k2, A52), (k3, A53), (k4, A54)]), h, pos), h2, dist)
+    k6 = f_literal(S, fmadd3(_fsum([(k1, A61), (k2, A62), (k3, A63), (k4, A64), (k5, A65)]), h, pos), h2, dist)
+    ks = (k1, k2, k3, k4, k5, k6)
+    e = (_fsum(list(zip(ks, DB))) * h[:, None]).astype(np.float32)
+    ea = np.abs(e)
+    e_max = fmax(fmax(ea[:, 0], ea[:, 1]), ea[:, 2])
+    nd = fnorm(fmadd3(_fsum(list(zip(ks, BA))), h, dirn))
+    npos = fmadd3(dirn, h, pos)                                                                           # old direction
+    with np.errstate(invalid="ignore"):
+        grow = e_max > f32(0.00002)
+    nh = np.where(grow, h * (f32(0.9) * bh_pow_m001(np.where(grow, e_max, f32(1.0)))), h * f32(1.0001)).astype(np.float32)
+    return npos.astype(np.float32), nd.astype(np.float32), nh
 
 
 def f_literal(S, p, h2, dist):
@@ -578,6 +627,8 @@ def next_ray_rk_literal(S, pos, dirn, h):
 def next_ray_euler(S, pos, dirn, step):
     if LITERAL:
         return next_ray_euler_literal(S, pos, dirn, step)
+    if FMA_ONLY:
+        return next_ray_euler_fma(S, pos, dirn, step)
     cr = fcross(pos, dirn); h2 = fdot(cr, cr)               # N3: pow(length(v), 2.0) = dot(v, v)
     q0 = (pos - S.bh_pos).astype(np.float32)                # N9: position relative to the hole
     dist = flen(q0)
@@ -598,6 +649,8 @@ def _lin(terms):
 def next_ray_rk(S, pos, dirn, h):
     if LITERAL:
         return next_ray_rk_literal(S, pos, dirn, h)
+    if FMA_ONLY:
+        return next_ray_rk_fma(S, pos, dirn, h)
     q0 = (pos - S.bh_pos).astype(np.float32)                # N9: position relative to the hole, once per step
     dist = flen(q0)
     cr = fcross(pos, dirn); h2 = fdot(cr, cr)               # N3: pow(length(v), 2.0) = dot(v, v)

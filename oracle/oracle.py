@@ -83,6 +83,10 @@ def lib():
         L.oracle_f32_to_f16.argtypes = [C.c_float]
         L.oracle_set_literal.argtypes = [C.c_int]
         L.oracle_get_literal.restype = C.c_int
+        L.oracle_set_eval.argtypes = [C.c_int]
+        L.oracle_get_eval.restype = C.c_int
+        L.oracle_render_aux.restype = C.c_int
+        L.oracle_render_aux.argtypes = [C.POINTER(_Scene), C.c_int, C.c_int, C.c_void_p]
         L.oracle_num_threads.restype = C.c_int
         L.oracle_set_threads.argtypes = [C.c_int]
         _lib = L
@@ -247,3 +251,23 @@ def set_literal(on: bool) -> None:
     """Integrator evaluation: False = the numerics contract (N3, N7, N9; what the HIP kernel computes), True = the shader text
     operator by operator (N0-N2).  Process-wide switch of the C oracle; tests restore it."""
     lib().oracle_set_literal(1 if on else 0)
+
+
+EVAL_CONTRACT, EVAL_LITERAL, EVAL_FMA = 0, 1, 2
+
+
+def set_eval(mode: int) -> None:
+    """0 = the numerics contract, 1 = the literal text, 2 = the literal text with fused multiply-add contraction only (no
+    reassociation): the THIRD legal evaluation (kernel flag BHRAY_F_EVAL_FMA)."""
+    lib().oracle_set_eval(int(mode))
+
+
+def render_aux(scene: OracleScene, size) -> np.ndarray:
+    """Every pixel of a (W, H) frame traced from the camera: (H, W, 4) = closest approach to the hole, iterations, smallest
+    distance of a disk-plane crossing from the disk's rims (1e30 = never crossed), disk hits.  Diagnostics for the parity tests."""
+    w, h = size
+    s, keep = scene._pack()
+    out = np.zeros((h, w, 4), dtype=np.float32)
+    assert lib().oracle_render_aux(C.byref(s), w, h, out.ctypes.data) == 0
+    del keep
+    return out

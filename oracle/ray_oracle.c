@@ -92,6 +92,7 @@ typedef struct {
     const o_model* models;           /* details->model_count entries */
     o_tex t_temp, t_disk, t_sky;
     o_counters* cnt;                 /* per-thread, may be NULL */
+    float* aux;                      /* per-ray diagnostics of trace_ray (oracle_render_aux), may be NULL */
 } scene;
 
 /* ---- vector helpers under the numerics contract ---------------------------------------- */
@@ -546,9 +547,18 @@ static RenderState hit_ray(const scene* S, Ray ray, float t_min, float t_max, fl
  * relative to the hole, q_i = fma(sum_i, h, p0 - bh).  The LITERAL one (oracle_set_literal(1)) evaluates the shader text
  * operator by operator under N0-N2 (+ d*d*d*d*d for pow(d,5), l*l for pow(l,2)); tests/test_oracle_kat.py measures the
  * distance between the two, which is what separates any two conforming WGSL implementations. */
-static int g_literal = 0;
-void oracle_set_literal(int on) { g_literal = on != 0; }
-int oracle_get_literal(void) { return g_literal; }
+/* A THIRD evaluation (oracle_set_eval(2), kernel flag BHRAY_F_EVAL_FMA): the literal expression tree with fused multiply-add
+ * contraction ONLY - every `x*y + z` of the text whose product is a direct operand of the addition becomes one fma, the first
+ * product of a sum of products stays rounded - and none of the reassociations N9/N10 (no per-step scalar, no step size folded into
+ * the stages, zero-coefficient terms kept).  It is what a shader compiler's default contraction does to ray.wgsl:401-480 and nothing
+ * more.  It exists to show that the pixels on which the contract differs from the literal text by more than 1e-4 are the pixels on
+ * which ANY two legal evaluations differ (tests/test_gpu_literal.py). */
+static int g_eval = 0;                /* 0 contract (N3/N7/N9/N10), 1 literal (N0-N2), 2 fma contraction only */
+#define g_literal (g_eval == 1)
+void oracle_set_literal(int on) { g_eval = on != 0 ? 1 : 0; }
+int oracle_get_literal(void) { return g_eval == 1; }
+void oracle_set_eval(int mode) { g_eval = (mode == 1 || mode == 2) ? mode : 0; }
+int oracle_get_eval(void) { return g_eval; }
 
 static inline float pow5(float d) { return ((d * d) * (d * d)) * d; }                  /* N3 */
 static inline v3 f_literal(const scene* S, v3 p, float h2, float dist) {
@@ -587,11 +597,49 @@ static RKState next_ray_rk_literal(const scene* S, RKState st) {
     return st;
 }
 
+/* fma contraction only (oracle_set_eval(2)): the literal tree, `x*y + z` fused where the text has it */
+static inline v3 f_fma(const scene* S, v3 p, float h2, float dist) {       /* fn f: no x*y + z in it */
+    v3 num = muls(sub(p, fromp(S->bh->position)), -1.5f * h2);
+    return divs(num, pow5(dist));
+}
+static RKState next_ray_rk_fma(const scene* S, RKState st) {
+    Ray ray = st.ray;
+    v3 p0 = ray.position, d0 = ray.direction;
+    float dist = flength(sub(p0, fromp(S->bh->position)));
+    float lc = flength(fcross(p0, d0));
+    float h2 = lc * lc;
+    float h = st.h;
+    v3 k1 = f_fma(S, p0, h2, dist);
+    v3 k2 = f_fma(S, fmadd3(muls(k1, a_21), h, p0), h2, dist);
+    v3 k3 = f_fma(S, fmadd3(fmadd3(k2, a_32, muls(k1, a_31)), h, p0), h2, dist);
+    v3 k4 = f_fma(S, fmadd3(fmadd3(k2, a_43, fmadd3(k2, a_42, muls(k1, a_41))), h, p0), h2, dist);                    /* a_43*k_2 (sic) */
+    v3 k5 = f_fma(S, fmadd3(fmadd3(k4, a_54, fmadd3(k3, a_53, fmadd3(k2, a_52, muls(k1, a_51)))), h, p0), h2, dist);
+    v3 k6 = f_fma(S, fmadd3(fmadd3(k5, a_65, fmadd3(k4, a_64, fmadd3(k3, a_63, fmadd3(k2, a_62, muls(k1, a_61))))), h, p0), h2, dist);
+    v3 es = fmadd3(k6, db_6, fmadd3(k5, db_5, fmadd3(k4, db_4, fmadd3(k3, db_3, fmadd3(k2, db_2, muls(k1, db_1))))));
+    v3 e = muls(es, h);
+    st.e_max = fmax_(fmax_(fabsf(e.x), fabsf(e.y)), fabsf(e.z));
+    v3 ds = fmadd3(k6, b_a_6, fmadd3(k5, b_a_5, fmadd3(k4, b_a_4, fmadd3(k3, b_a_3, fmadd3(k2, b_a_2, muls(k1, b_a_1))))));
+    st.ray.direction = fnormalize(fmadd3(ds, h, d0));
+    st.ray.position = fmadd3(d0, h, p0);                                      /* old direction */
+    if (st.e_max > 0.00002f) st.h = st.h * (0.9f * bh_pow_m001(st.e_max));
+    else st.h = st.h * 1.0001f;
+    return st;
+}
+static Ray next_ray_euler_fma(const scene* S, Ray ray, float step) {
+    float lc = flength(fcross(ray.position, ray.direction));
+    float h2 = lc * lc;
+    float dist = flength(sub(ray.position, fromp(S->bh->position)));
+    ray.direction = fnormalize(fmadd3(f_fma(S, ray.position, h2, dist), step, ray.direction));
+    ray.position = fmadd3(ray.direction, step, ray.position);
+    return ray;
+}
+
 /* contract: N3, N7, N9 */
 /* sum of scaled vectors, left to right: first product rounded, the rest fused */
 static inline v3 lin2(v3 a, float ca, v3 b, float cb) { return fmadd3(b, cb, muls(a, ca)); }
 static RKState next_ray_rk(const scene* S, RKState st) {
-    if (g_literal) return next_ray_rk_literal(S, st);
+    if (g_eval == 1) return next_ray_rk_literal(S, st);
+    if (g_eval == 2) return next_ray_rk_fma(S, st);
     Ray ray = st.ray;
     v3 p0 = ray.position;
     v3 q0 = sub(p0, fromp(S->bh->position));                     /* N9: position relative to the hole, once per step */
@@ -636,7 +684,8 @@ static Ray next_ray_euler_literal(const scene* S, Ray ray, float step) {
     return ray;
 }
 static Ray next_ray_euler(const scene* S, Ray ray, float step) {
-    if (g_literal) return next_ray_euler_literal(S, ray, step);
+    if (g_eval == 1) return next_ray_euler_literal(S, ray, step);
+    if (g_eval == 2) return next_ray_euler_fma(S, ray, step);
     v3 cr = fcross(ray.position, ray.direction);
     float h2 = fdot(cr, cr);                                     /* N3: pow(length(v), 2.0) = dot(v, v) */
     v3 q0 = sub(ray.position, fromp(S->bh->position));
@@ -662,6 +711,7 @@ static v4 trace_ray(const scene* S, Ray ray) {
     int hit = 0;
     int i = 0;
     float closest_to_bh = distance(curr.position, bpos);
+    float aux_edge = 1e30f, aux_hits = 0.0f;
     if (S->cnt) S->cnt->traced++;
 
     for (; i < S->details->max_iterations; i++) {
@@ -677,10 +727,21 @@ static v4 trace_ray(const scene* S, Ray ray) {
                 curr = rk.ray;
                 step_size = rk.h;
             }
-            float cd = g_literal ? distance(curr.position, bpos) : fdistance(curr.position, bpos);   /* N7: the integrator's distance */
+            float cd = g_eval == 1 ? distance(curr.position, bpos) : fdistance(curr.position, bpos);   /* N7: the integrator's distance */
             if (cd < closest_to_bh) closest_to_bh = cd;
             prev.direction = curr.direction;
             crs = hit_ray(S, prev, t_min, step_size, ray_distance, 0, 1);
+            if (S->aux) {                                   /* diagnostics only: how close to the disk's rims did this step cross its plane? */
+                v3 n = fromp(bh->normal);
+                float t = dot(sub(bpos, prev.position), n) / dot(n, prev.direction);
+                if (t < step_size && t > t_min) {
+                    float dc = distance(bpos, add(prev.position, muls(prev.direction, t)));
+                    float e0 = fabsf(dc - bh->inner_radius), e1 = fabsf(dc - bh->outer_radius);
+                    float e = e0 < e1 ? e0 : e1;
+                    if (e < aux_edge) aux_edge = e;
+                    if (dc >= bh->inner_radius && dc <= bh->outer_radius) aux_hits += 1.0f;
+                }
+            }
             if (cd > bh_radius) {
                 relativity = 0;
                 float fw = bh_radius * bh->feather_amount;
@@ -715,6 +776,7 @@ static v4 trace_ray(const scene* S, Ray ray) {
     }
 
     v4 out;
+    if (S->aux) { S->aux[0] = closest_to_bh; S->aux[1] = (float)i; S->aux[2] = aux_edge; S->aux[3] = aux_hits; }
     if (hit || i <= 5) {
         if (color_amount > 0.001f) {
             if (S->cnt) S->cnt->sky_samples++;
@@ -849,7 +911,7 @@ int oracle_render_level(const oracle_scene* os, int sw, int sh, const float* pre
     {
         o_counters local; memset(&local, 0, sizeof local);
         scene S; S.camera = os->camera; S.details = os->details; S.bh = os->bh; S.models = os->models;
-        S.t_temp = os->t_temp; S.t_disk = os->t_disk; S.t_sky = os->t_sky; S.cnt = counters ? &local : NULL;
+        S.t_temp = os->t_temp; S.t_disk = os->t_disk; S.t_sky = os->t_sky; S.cnt = counters ? &local : NULL; S.aux = NULL;
 #pragma omp for schedule(dynamic, 1)
         for (int y = y0; y < y1; y++) {
             for (int x = x0; x < x1; x++) {
@@ -877,6 +939,27 @@ int oracle_render_level(const oracle_scene* os, int sw, int sh, const float* pre
     return 0;
 }
 
+/* Diagnostics for the parity tests: EVERY pixel of a sw x sh level traced from the camera (no grid), aux[sh][sw][4] =
+ * (closest approach to the hole, iterations, smallest distance between a disk-plane crossing and the disk's inner / outer rim
+ * (1e30: the ray never crossed the plane), number of disk hits).  These are the quantities that say WHY a ray amplifies rounding
+ * differences (it wound around the photon sphere; it crossed the plane at a rim, where an ulp decides hit / no hit). */
+int oracle_render_aux(const oracle_scene* os, int sw, int sh, float* aux) {
+    if (!os || !aux || sw < 1 || sh < 1) return -1;
+#pragma omp parallel
+    {
+        scene S; S.camera = os->camera; S.details = os->details; S.bh = os->bh; S.models = os->models;
+        S.t_temp = os->t_temp; S.t_disk = os->t_disk; S.t_sky = os->t_sky; S.cnt = NULL;
+#pragma omp for schedule(dynamic, 1)
+        for (int y = 0; y < sh; y++) {
+            for (int x = 0; x < sw; x++) {
+                S.aux = aux + 4 * ((size_t)y * (size_t)sw + (size_t)x);
+                (void)trace_ray(&S, create_ray(&S, x, y, sw, sh));
+            }
+        }
+    }
+    return 0;
+}
+
 /* Per-function probes for known-answer tests and cross-checks (tests/ only). */
 void oracle_create_ray(const oracle_scene* os, int px, int py, int sw, int sh, float out6[6]) {
     scene S; memset(&S, 0, sizeof S); S.camera = os->camera; S.details = os->details; S.bh = os->bh;
@@ -886,7 +969,7 @@ void oracle_create_ray(const oracle_scene* os, int px, int py, int sw, int sh, f
 }
 void oracle_trace_ray(const oracle_scene* os, const float ray6[6], float out4[4], o_counters* c) {
     scene S; S.camera = os->camera; S.details = os->details; S.bh = os->bh; S.models = os->models;
-    S.t_temp = os->t_temp; S.t_disk = os->t_disk; S.t_sky = os->t_sky; S.cnt = c;
+    S.t_temp = os->t_temp; S.t_disk = os->t_disk; S.t_sky = os->t_sky; S.cnt = c; S.aux = NULL;
     Ray r = { V(ray6[0], ray6[1], ray6[2]), V(ray6[3], ray6[4], ray6[5]) };
     v4 o = trace_ray(&S, r);
     out4[0] = o.x; out4[1] = o.y; out4[2] = o.z; out4[3] = o.w;

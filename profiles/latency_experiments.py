@@ -4,8 +4,8 @@ copied to profiles/r02_latency_experiments.json).
 
  1. lone_wave_phases   where one wave's time goes in a latency-bound launch (level 0 of the 1080p ladder alone, 2 993 rays dealt out
                        3 per wave): per-phase and per-iteration clocks written by a timing-only build of the SAME sources
-                           make -C bhusie_amd/csrc OUT=../../scratch/variants/libbhray_prof.so  OBJDIR=_obj_prof  EXTRA=-DBHRAY_EXP_PROFILE
-                           make -C bhusie_amd/csrc OUT=../../scratch/variants/libbhray_prof2.so OBJDIR=_obj_prof2 EXTRA="-DBHRAY_EXP_PROFILE -DBHRAY_EXP_PROFILE_FINE"
+                           make -C bhusie_amd/csrc OUT=../../profiles/variants/libbhray_prof.so  OBJDIR=_obj_prof  EXTRA=-DBHRAY_EXP_PROFILE
+                           make -C bhusie_amd/csrc OUT=../../profiles/variants/libbhray_prof2.so OBJDIR=_obj_prof2 EXTRA="-DBHRAY_EXP_PROFILE -DBHRAY_EXP_PROFILE_FINE"
                        (clock64 ticks = shader clocks, 0.42 ns on the box: profiles/ubench/lone_wave.hip; every clock read costs ~70).
  2. temporal_prediction  BHRAY_F_TEMPORAL with a moving camera: rays the per-level fix-up launches had to trace (= what the prediction
                        missed) and the latency of one frame at a time, for the prediction parameters BHRAY_TEMPORAL_MARGIN /
@@ -112,7 +112,7 @@ if __name__ == "__main__":
         sys.exit(0)
     res = {}
     env = dict(os.environ)
-    for key, lib, fine in (("lone_wave_phases", "scratch/variants/libbhray_prof.so", ""), ("lone_wave_phases_fine", "scratch/variants/libbhray_prof2.so", "1")):
+    for key, lib, fine in (("lone_wave_phases", "profiles/variants/libbhray_prof.so", ""), ("lone_wave_phases_fine", "profiles/variants/libbhray_prof2.so", "1")):
         if os.path.exists(os.path.join(ROOT, lib)):
             r = subprocess.run([sys.executable, __file__, "lone"], capture_output=True, text=True, env=dict(env, BHRAY_LIB=os.path.join(ROOT, lib), FINE=fine), cwd=ROOT)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]

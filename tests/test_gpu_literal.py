@@ -1,4 +1,4 @@
-"""-m gpu: how far is the HIP path from the LITERAL text of ray.wgsl?
+"""-m gpu: how far is the HIP path from the LITERAL text of ray.wgsl - and is that distance a property of the kernel or of the problem?
 
 The default kernels implement the numerics contract of DESIGN.md §2 (fused multiply-add, reassociation and small-integer powers
 in the integrator: N3/N7/N9/N10 — evaluations WGSL permits).  Every other -m gpu test compares them with the oracle under the
@@ -11,6 +11,14 @@ SAME contract.  This file pins the distance to the shader text itself, three way
     bounded median, and >= 99.7 % of the pixels inside the 1e-4 bar of BASELINE.json's north_star.  The remainder are the chaotic
     rays (photon sphere, disk edge) on which any two conforming evaluations disagree; their maximum is recorded, not bounded.
  3. The default kernels against the literal KERNEL (GPU vs GPU): the same statistics without any CPU code in the loop.
+ 4. A THIRD legal evaluation (BHRAY_F_EVAL_FMA: the text with fused multiply-add contraction only, no reassociation), pinned like
+    the literal one (frozen NumPy-written fixtures, the C oracle's eval mode 2), and the literal kernel with ONE INPUT CHANGED BY ONE
+    ULP (the camera's z).  The pixels beyond 1e-4 of contract-vs-literal, fma-vs-literal and literal'-vs-literal are the same
+    population: same size (within a small factor), mostly the same pixels.  Not even the literal evaluation is within 1e-4 of itself
+    when an input moves by an ulp, so no bound tighter than "the same population as a one-ulp perturbation" can be asked of ANY
+    implementation that is not bit-identical to the text.  Most of that population is the metric, not the ray: a direction pixel is a
+    unit vector carrying ~1e-6 of accumulated rounding (245 steps), which is > 1e-4 RELATIVE in any channel that is near zero;
+    measured against the vector's norm the direction-pixel population shrinks 20-fold, the whole population 4-5-fold (recorded, bounded).
 """
 import json
 import os
@@ -89,14 +97,40 @@ def test_literal_kernel_equals_literal_oracle_at_1918x1081(method):
     assert rp.counters() == cnt.as_dict()
 
 
+def _per_channel(got, want):
+    """max over channels of |got - want| / max(|want|, 1e-3): the metric of BASELINE.json's north_star ("1e-4 relative per channel")"""
+    with np.errstate(invalid="ignore"):
+        return (np.abs(got - want) / np.maximum(np.abs(want), T.ABS_FLOOR)).max(axis=-1)
+
+
+def _per_pixel(got, want):
+    """error relative to the PIXEL's magnitude: direction pixels ||dv|| / ||v||, colour pixels max|dc| / max(max|c|, 1e-3)"""
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ang = np.linalg.norm((got - want)[..., :3], axis=-1) / np.linalg.norm(want[..., :3], axis=-1)
+        col = np.abs(got - want)[..., :3].max(axis=-1) / np.maximum(np.abs(want[..., :3]).max(axis=-1), T.ABS_FLOOR)
+    return np.where(want[..., 3] == 0, ang, col)
+
+
 def _distance(got, want):
     same = got[..., 3] == want[..., 3]
+    e = _per_channel(got, want)
+    p = _per_pixel(got, want)
+    ok = same & np.isfinite(e)
+    ev, pv = e[ok], p[ok & np.isfinite(p)]
+    return {"pixels": int(same.size), "class_differences": int((~same).sum()), "median_rel_err": float(np.median(ev)),
+            "p99_rel_err": float(np.quantile(ev, 0.99)), "fraction_within_1e-4": float((ev <= 1e-4).mean()),
+            "pixels_beyond_1e-4": int((ev > 1e-4).sum()), "max_rel_err": float(ev.max()),
+            "per_pixel_norm": {"pixels_beyond_1e-4": int((pv > 1e-4).sum()), "fraction_within_1e-4": float((pv <= 1e-4).mean()),
+                               "median": float(np.median(pv)), "max": float(pv.max())}}
+
+
+def _beyond(got, want):
+    """pixel masks: beyond 1e-4 per channel / per pixel norm (class differences count as beyond)"""
+    same = got[..., 3] == want[..., 3]
     with np.errstate(invalid="ignore"):
-        e = (np.abs(got - want) / np.maximum(np.abs(want), T.ABS_FLOOR))[same].max(axis=-1)
-    e = e[np.isfinite(e)]
-    return {"pixels": int(same.size), "class_differences": int((~same).sum()), "median_rel_err": float(np.median(e)),
-            "p99_rel_err": float(np.quantile(e, 0.99)), "fraction_within_1e-4": float((e <= 1e-4).mean()),
-            "pixels_beyond_1e-4": int((e > 1e-4).sum()), "max_rel_err": float(e.max())}
+        a = ~same | (_per_channel(got, want) > 1e-4)
+        b = ~same | (_per_pixel(got, want) > 1e-4)
+    return a, b
 
 
 def _record(entry):
@@ -109,7 +143,8 @@ def _record(entry):
 @pytest.mark.parametrize("method", [1, 0])
 def test_default_kernels_vs_the_literal_reading_at_the_bench_frame(method):
     """configs[1], 1920x1080 with the adaptive grid: the contract kernels against (a) the literal C oracle, (b) the literal
-    kernel.  Bounds: 0 class differences, median < 1e-6, >= 99.7 % of the pixels within 1e-4; the maximum is recorded."""
+    kernel.  Bounds: 0 class differences, median < 1e-6; the fraction within 1e-4 is recorded and bounded RELATIVE to what a
+    one-ulp change of one input does to the literal evaluation itself (test_the_outliers_are_the_problems_not_the_kernels)."""
     tex = T.textures(small=False)
     u = T.uniforms(integration_method=method)
     cfg = B.ladder_for_frame((1920, 1080), 3, 4)
@@ -129,4 +164,86 @@ def test_default_kernels_vs_the_literal_reading_at_the_bench_frame(method):
         _record(d)
         assert d["class_differences"] == 0, d
         assert d["median_rel_err"] < 1e-6, d
-        assert d["fraction_within_1e-4"] >= 0.997, d
+        assert d["fraction_within_1e-4"] >= 0.995, d                    # 0.9973 measured; the meaningful bound is the relative one below
+        assert d["per_pixel_norm"]["fraction_within_1e-4"] >= 0.999, d  # 0.9994 measured
+
+
+FMA_CASES = ["euler_l0", "rk_l0", "rk_ladder", "rk_outside"]
+
+
+@pytest.mark.parametrize("name", FMA_CASES)
+def test_fma_kernel_reproduces_the_frozen_fma_fixtures(name):
+    g = np.load(os.path.join(GOLD, "frames_fma.npz"))
+    tex = (g["t_temp"], g["t_disk"], g["t_sky"])
+    u = (g[f"{name}.camera"].tobytes(), g[f"{name}.black_hole"].tobytes(), g[f"{name}.details"].tobytes())
+    sizes = [tuple(int(v) for v in s) for s in g[f"{name}.sizes"]]
+    cfg = B.ladder_from_base(sizes[0], 3, len(sizes))
+    rp = _gpu(cfg, u, tex, eval_fma=True, counters=True)
+    n = 0
+    for l in range(len(sizes)):
+        n += _same_to_the_bit_where_specified(rp.read_level(l), g[f"{name}.level{l}"], f"fma {name} level {l}")
+    assert n > 0
+    traced, steps, copied, interp, sky = (int(v) for v in g[f"{name}.stats"])
+    c = rp.counters()
+    assert (c["traced"], c["steps"], c["copied"], c["interpolated"], c["sky_samples"]) == (traced, steps, copied, interp, sky)
+    if name in ("rk_l0", "euler_l0"):                       # a third evaluation: neither the contract nor the literal one
+        assert not np.array_equal(_gpu(cfg, u, tex).read_hdr(), rp.read_hdr())
+        assert not np.array_equal(_gpu(cfg, u, tex, literal=True).read_hdr(), rp.read_hdr())
+
+
+@pytest.mark.parametrize("method", [1, 0])
+def test_fma_kernel_equals_fma_oracle_at_1918x1081(method):
+    tex = T.textures(small=False)
+    u = T.uniforms(integration_method=method)
+    cfg = B.ladder_from_base((72, 41), 3, 4)
+    rp = _gpu(cfg, u, tex, eval_fma=True, counters=True)
+    cnt = O.Counters()
+    O.set_eval(O.EVAL_FMA)
+    try:
+        want = O.render_ladder(T.oracle_scene(*u, tex), cfg.sizes(), cnt)
+    finally:
+        O.set_eval(O.EVAL_CONTRACT)
+    for l in range(4):
+        _same_to_the_bit_where_specified(rp.read_level(l), want[l], f"fma level {l} method {method}")
+    assert rp.counters() == cnt.as_dict()
+
+
+@pytest.mark.parametrize("method", [1, 0])
+def test_the_outliers_are_the_problems_not_the_kernels(method):
+    """Bench frame, every evaluation on the GPU.  A = pixels where the CONTRACT kernels differ from the literal kernel by more than
+    1e-4, B = the same for the FMA-only kernel, P = the same for the LITERAL kernel with the camera's z moved by ONE ULP.
+    Claims (each asserted with a factor-of-two margin, all recorded):
+      * |A| and |B| are within 3x of |P|: rounding the operations differently costs what moving one input by one ulp costs;
+      * A and B are mostly the same pixels (>= 70 % of the smaller set);
+      * measured against the pixel's norm instead of per channel, every population shrinks by more than 3x (direction pixels alone: 20x; the per-channel
+        metric divides ~1e-6 of absolute error by channels that are near zero) and stays below 0.1 % of the frame."""
+    tex = T.textures(small=False)
+    cfg = B.ladder_for_frame((1920, 1080), 3, 4)
+    u = T.uniforms(integration_method=method)
+    z1 = float(np.nextafter(np.float32(-19.0), np.float32(0.0)))
+    up = T.uniforms(camera=B.Camera(position=(0.0, 0.0, z1)), integration_method=method)
+    lit = _gpu(cfg, u, tex, literal=True).read_hdr()
+    con = _gpu(cfg, u, tex).read_hdr()
+    fma = _gpu(cfg, u, tex, eval_fma=True).read_hdr()
+    per = _gpu(cfg, up, tex, literal=True).read_hdr()
+    A, An = _beyond(con, lit)
+    Bm, Bn = _beyond(fma, lit)
+    P, Pn = _beyond(per, lit)
+    C_, Cn = _beyond(fma, con)
+    n = A.size
+    entry = {"config": "1920x1080 " + ("adaptive RK" if method else "Euler"), "population_test": True, "pixels": int(n),
+             "per_channel_beyond_1e-4": {"contract_vs_literal": int(A.sum()), "fma_vs_literal": int(Bm.sum()),
+                                         "literal_camera_z_plus_1ulp_vs_literal": int(P.sum()), "fma_vs_contract": int(C_.sum()),
+                                         "contract_and_fma": int((A & Bm).sum()), "contract_and_perturbed": int((A & P).sum())},
+             "per_pixel_norm_beyond_1e-4": {"contract_vs_literal": int(An.sum()), "fma_vs_literal": int(Bn.sum()),
+                                            "literal_camera_z_plus_1ulp_vs_literal": int(Pn.sum()), "fma_vs_contract": int(Cn.sum()),
+                                            "contract_and_fma": int((An & Bn).sum()), "contract_and_perturbed": int((An & Pn).sum())},
+             "class_differences": {"contract": int((con[..., 3] != lit[..., 3]).sum()), "fma": int((fma[..., 3] != lit[..., 3]).sum()),
+                                   "perturbed": int((per[..., 3] != lit[..., 3]).sum())}}
+    _record(entry)
+    assert entry["class_differences"]["contract"] == 0 and entry["class_differences"]["fma"] == 0
+    assert P.sum() > 0, "a one-ulp change of the camera position must move some pixel by more than 1e-4 - else the bar would be attainable"
+    assert A.sum() <= 3 * P.sum() and Bm.sum() <= 3 * P.sum(), entry
+    assert (A & Bm).sum() >= 0.7 * min(A.sum(), Bm.sum()), entry
+    assert An.sum() * 3 <= A.sum() and Bn.sum() * 3 <= Bm.sum(), entry
+    assert An.sum() <= 1e-3 * n and Bn.sum() <= 1e-3 * n and An.sum() <= 3 * max(1, Pn.sum()) + 0.0002 * n, entry
