@@ -144,7 +144,6 @@ struct bhray_dev {
     // asynchronous hand-off (dev_read_hdr_async): copies run on their own streams (the SDMA engines), behind the frame's kernels
     hipStream_t copy_stream[BHRAY_COPY_STREAMS] = {nullptr, nullptr};
     hipEvent_t read_ev[BHRAY_READ_RING] = {nullptr};     // ticket t -> read_ev[t % BHRAY_READ_RING]
-    hipEvent_t copy_join = nullptr;
     uint64_t read_tickets = 0;
     std::string err;
 };
@@ -374,7 +373,6 @@ void dev_destroy(bhray_dev* c) {
     if (c->d_span) (void)hipFree(c->d_span);
     for (auto& st : c->copy_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (auto& e : c->read_ev) if (e) (void)hipEventDestroy(e);
-    if (c->copy_join) (void)hipEventDestroy(c->copy_join);
     delete c;
 }
 
@@ -1104,9 +1102,8 @@ int dev_read_hdr(bhray_dev* c, float* dst, size_t pitch) {
 }
 
 // Asynchronous hand-off of the most recently enqueued frame to host memory (a consumer on another device: the wgpu texture the
-// reference's SkyPipeline samples, ray_pipeline.rs:297-299, mod.rs:215).  The copy is enqueued on the engine's copy streams -
-// the two halves of the frame on two streams, i.e. two SDMA engines - behind that frame's kernels; the call returns at once, frame
-// k's copy overlaps frame k+1's render.  `dst` should be pinned (bhray_host_alloc / hipHostRegister): a pageable destination makes
+// reference's SkyPipeline samples, ray_pipeline.rs:297-299, mod.rs:215).  The copy is enqueued on one of the engine's copy streams
+// (SDMA: no CU time) behind that frame's kernels; the call returns at once, frame k's copy overlaps frame k+1's render.  `dst` should be pinned (bhray_host_alloc / hipHostRegister): a pageable destination makes
 // the runtime stage the copy and the call synchronous.  The slot's next frame waits for the copy before it overwrites the image.
 int dev_read_hdr_async(bhray_dev* c, float* dst, size_t pitch, uint64_t* ticket) {
     if (!c || !ticket) return BHRAY_E_INVALID;
@@ -1123,25 +1120,19 @@ int dev_read_hdr_async(bhray_dev* c, float* dst, size_t pitch, uint64_t* ticket)
     if (rows) {
         if (!dst || pitch < rowb) return fail(c, BHRAY_E_INVALID, "bad destination / pitch");
         const uint8_t* src = (const uint8_t*)S.fr[(size_t)c->last_sub].out;
-        const size_t half = rows / 2;
-        for (int k = 0; k < BHRAY_COPY_STREAMS; k++) {
-            hipStream_t& cs = c->copy_stream[k];
-            if (!cs) HIPCHK(c, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-            const size_t r0 = k == 0 ? 0 : half, r1 = k == 0 ? half : rows;
-            HIPCHK(c, hipStreamWaitEvent(cs, S.done, 0));
-            if (r1 > r0) {
-                if (pitch == rowb) HIPCHK(c, hipMemcpyAsync((uint8_t*)dst + r0 * pitch, src + r0 * rowb, (r1 - r0) * rowb, hipMemcpyDeviceToHost, cs));
-                else HIPCHK(c, hipMemcpy2DAsync((uint8_t*)dst + r0 * pitch, pitch, src + r0 * rowb, rowb, rowb, r1 - r0, hipMemcpyDeviceToHost, cs));
-            }
-        }
-        // one event for the whole frame: stream 0 joins stream 1
-        if (!c->copy_join) HIPCHK(c, hipEventCreateWithFlags(&c->copy_join, hipEventDisableTiming));
-        HIPCHK(c, hipEventRecord(c->copy_join, c->copy_stream[1]));
-        HIPCHK(c, hipStreamWaitEvent(c->copy_stream[0], c->copy_join, 0));
-    } else if (!c->copy_stream[0]) {
-        HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream[0], hipStreamNonBlocking));
+        // ONE copy per frame (a single hipMemcpyAsync already runs at the link rate: 55.7 GB/s device -> pinned host on this box,
+        // profiles/ubench/pcie_handoff.hip; halves on two streams or a copy kernel are not faster), consecutive frames on alternating
+        // copy streams so that a copy whose frame is not finished yet does not hold back the next one
+        hipStream_t& cs = c->copy_stream[t % BHRAY_COPY_STREAMS];
+        if (!cs) HIPCHK(c, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamWaitEvent(cs, S.done, 0));
+        if (pitch == rowb) HIPCHK(c, hipMemcpyAsync(dst, src, rows * rowb, hipMemcpyDeviceToHost, cs));
+        else HIPCHK(c, hipMemcpy2DAsync(dst, pitch, src, rowb, rowb, rows, hipMemcpyDeviceToHost, cs));
+        HIPCHK(c, hipEventRecord(ev, cs));
+    } else {
+        if (!c->copy_stream[0]) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream[0], hipStreamNonBlocking));
+        HIPCHK(c, hipEventRecord(ev, c->copy_stream[0]));
     }
-    HIPCHK(c, hipEventRecord(ev, c->copy_stream[0]));
     HIPCHK(c, hipStreamWaitEvent(S.stream, ev, 0));        // the slot's next batch overwrites the image only after the copy has read it
     *ticket = t;
     c->read_tickets = t + 1;

@@ -341,7 +341,7 @@ int bhray_bind_output(bhray_ctx* ctx, void* dev_ptr, size_t bytes);
  *     (the import dup()s nothing: keep it open until bhray_release_external).  Ordering: bhray_sync, or an exported semaphore
  *     the host signals from a stream it ordered with bhray_signal_stream.
  * (2) asynchronous read-back: bhray_read_hdr_async enqueues the device->host copy of the most recently enqueued frame on the
- *     library's copy streams (two SDMA engines, half the rows each), behind that frame's kernels, and returns at once with a
+ *     library's copy streams (SDMA: no CU time; consecutive frames alternate between two streams), behind that frame's kernels, and returns at once with a
  *     ticket; frame k's copy overlaps frame k+1's render.  bhray_wait_read(ticket) blocks until that frame has landed.  `dst`
  *     must stay valid until then and should be pinned host memory (bhray_host_alloc, or the host's own hipHostRegister):
  *     a pageable destination makes the runtime stage the copy.  A slot's image is not overwritten before its copy has read it.
