@@ -61,6 +61,10 @@ struct FrameRes {
     float4* out = nullptr;              // where this frame is written (own_out or a bound buffer)
     uint2* sky_out = nullptr;           // RGBA16F image of the sky resolve pass (allocated on first use)
     uint64_t frame_id = 0;              // frame_counter value of the frame held here
+    // fused ladder: per-frame tile state and queues (bhray_internal.h)
+    FusedCtl* fz_ctl = nullptr; uint32_t* fz_deps = nullptr; uint32_t* fz_pending = nullptr; unsigned long long* fz_cq = nullptr;
+    std::vector<unsigned long long*> fz_rq;
+    uint32_t fz_stamp = 0;
 };
 
 // One batch in flight: a HIP stream, the frames of the batch (frames_per_batch of them) and the argument block of its
@@ -81,6 +85,18 @@ struct Slot {
     uint8_t* d_args = nullptr;
     size_t args_cap = 0;
     uint64_t batch_id = 0;              // batch_counter value of the batch this slot holds
+};
+
+// Fused ladder (BHRAY_F_FUSED): the tile graph of the ctx's geometry - which coarse tile columns / rows every tile column / row reads,
+// and the transposed lists (who depends on a coarse tile column / row).  Separable: a tile's dependencies are (its column's) x (its row's).
+struct FusedTables {
+    bool on = false;
+    uint32_t tile_base[BHRAY_MAX_SPEC_LEVELS] = {0}, tiles_x[BHRAY_MAX_SPEC_LEVELS] = {0}, tiles_y[BHRAY_MAX_SPEC_LEVELS] = {0};
+    uint32_t total_tiles = 0, n_initial = 0, init_end[BHRAY_MAX_SPEC_LEVELS] = {0};
+    int32_t* d_row_index[BHRAY_MAX_SPEC_LEVELS] = {nullptr};
+    uint8_t* d_xdep[BHRAY_MAX_SPEC_LEVELS] = {nullptr}; uint8_t* d_ydep[BHRAY_MAX_SPEC_LEVELS] = {nullptr};
+    uint32_t* d_nx_off[BHRAY_MAX_SPEC_LEVELS] = {nullptr}; uint16_t* d_nx_list[BHRAY_MAX_SPEC_LEVELS] = {nullptr};
+    uint32_t* d_ny_off[BHRAY_MAX_SPEC_LEVELS] = {nullptr}; uint16_t* d_ny_list[BHRAY_MAX_SPEC_LEVELS] = {nullptr};
 };
 
 struct ModelStore {
@@ -114,6 +130,7 @@ struct bhray_dev {
     uint8_t* tex[3] = {nullptr, nullptr, nullptr};
     int tex_w[3] = {0, 0, 0}, tex_h[3] = {0, 0, 0};
     ModelStore models[BHRAY_MAX_MODELS];
+    FusedTables fz;
     bhray_camera_uniform cam{};
     bhray_black_hole_uniform bh{};
     bhray_details det{};
@@ -353,6 +370,11 @@ void dev_destroy(bhray_dev* c) {
             for (auto p : R.stamp) if (p) (void)hipFree(p);
             if (R.own_out) (void)hipFree(R.own_out);
             if (R.sky_out) (void)hipFree(R.sky_out);
+            if (R.fz_ctl) (void)hipFree(R.fz_ctl);
+            if (R.fz_deps) (void)hipFree(R.fz_deps);
+            if (R.fz_pending) (void)hipFree(R.fz_pending);
+            if (R.fz_cq) (void)hipFree(R.fz_cq);
+            for (auto q : R.fz_rq) if (q) (void)hipFree(q);
         }
         if (S.d_qctl) (void)hipFree(S.d_qctl);
         if (S.d_counters) (void)hipFree(S.d_counters);
@@ -365,6 +387,10 @@ void dev_destroy(bhray_dev* c) {
     for (Level& L : c->levels) {
         if (L.d_rows) (void)hipFree(L.d_rows);
         if (L.d_rowmap) (void)hipFree(L.d_rowmap);
+    }
+    for (int l = 0; l < BHRAY_MAX_SPEC_LEVELS; l++) {
+        void* ps[] = {c->fz.d_row_index[l], c->fz.d_xdep[l], c->fz.d_ydep[l], c->fz.d_nx_off[l], c->fz.d_nx_list[l], c->fz.d_ny_off[l], c->fz.d_ny_list[l]};
+        for (void* q : ps) if (q) (void)hipFree(q);
     }
     for (auto& t : c->tex) if (t) (void)hipFree(t);
     for (auto& m : c->models) free_model(m);
@@ -398,6 +424,8 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
         return fail(nullptr, BHRAY_E_INVALID, "superset_levels must be 0 or 2..%d and leave at least one coarser level (beyond the speculative ones)", BHRAY_MAX_SPEC_LEVELS);
     if ((cfg->flags & BHRAY_F_TEMPORAL) && (cfg->levels > BHRAY_MAX_SPEC_LEVELS || cfg->speculative_levels || cfg->superset_levels))
         return fail(nullptr, BHRAY_E_INVALID, "BHRAY_F_TEMPORAL needs levels <= %d and no speculative / superset levels", BHRAY_MAX_SPEC_LEVELS);
+    if ((cfg->flags & BHRAY_F_FUSED) && (cfg->levels > BHRAY_MAX_SPEC_LEVELS || cfg->superset_levels || (cfg->flags & BHRAY_F_TEMPORAL)))
+        return fail(nullptr, BHRAY_E_INVALID, "BHRAY_F_FUSED needs levels <= %d and neither superset levels nor BHRAY_F_TEMPORAL", BHRAY_MAX_SPEC_LEVELS);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(nullptr, BHRAY_E_NO_DEVICE, "no HIP device visible (libbhray has no CPU path)");
@@ -469,6 +497,68 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
             CHK(hipMemcpy(L.d_rowmap, map.data(), (size_t)L.h * sizeof(int32_t), hipMemcpyHostToDevice));
         }
     }
+    if ((cfg->flags & BHRAY_F_FUSED) && !c->levels[nl - 1].rows.empty()) {
+        FusedTables& Z = c->fz;
+        Z.on = true;
+        const uint32_t nall = cfg->speculative_levels ? cfg->speculative_levels : 1;      // all-traced levels
+        std::vector<std::vector<int32_t>> row_index(nl);
+        uint32_t base = 0;
+        for (uint32_t l = 0; l < nl; l++) {
+            const Level& L = c->levels[l];
+            const bool last = l == nl - 1;
+            const int X0 = last ? (int)cfg->crop_x : 0, X1 = last ? (int)(cfg->crop_x + cfg->frame_w) : L.w;
+            Z.tile_base[l] = base; Z.tiles_x[l] = (uint32_t)((X1 - X0 + 7) / 8); Z.tiles_y[l] = (uint32_t)((L.rows.size() + 7) / 8);
+            base += Z.tiles_x[l] * Z.tiles_y[l];
+            if (l < nall) { Z.n_initial += Z.tiles_x[l] * Z.tiles_y[l]; }
+            Z.init_end[l] = Z.n_initial;
+            row_index[l].assign((size_t)L.h, -1);
+            for (size_t j = 0; j < L.rows.size(); j++) row_index[l][(size_t)L.rows[j]] = (int32_t)j;
+            CHK(hipMalloc(&Z.d_row_index[l], (size_t)L.h * sizeof(int32_t)));
+            CHK(hipMemcpy(Z.d_row_index[l], row_index[l].data(), (size_t)L.h * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        Z.total_tiles = base;
+        for (uint32_t l = 1; l < nl; l++) {
+            const Level& L = c->levels[l]; const Level& Pv = c->levels[l - 1];
+            const bool last = l == nl - 1;
+            const int X0 = last ? (int)cfg->crop_x : 0, X1 = last ? (int)(cfg->crop_x + cfg->frame_w) : L.w;
+            const int sfx = (L.w - 1) / (Pv.w - 1), sfy = (L.h - 1) / (Pv.h - 1);                  // ray.wgsl:185
+            const float rx = (float)Pv.w / (float)(L.w + (sfx - 1)), ry = (float)Pv.h / (float)(L.h + (sfy - 1));   // ray.wgsl:187 - as level_params
+            auto clampi = [](int v, int n) { return v < 0 ? 0 : (v > n - 1 ? n - 1 : v); };
+            std::vector<std::vector<uint16_t>> xs(Z.tiles_x[l]), ys(Z.tiles_y[l]);
+            auto add = [](std::vector<uint16_t>& v, int t) { for (uint16_t e : v) if (e == (uint16_t)t) return; v.push_back((uint16_t)t); };
+            for (int x = X0; x < X1; x++) {
+                const float tl = floorf((float)x * rx);
+                add(xs[(size_t)((x - X0) >> 3)], clampi((int)tl, Pv.w) >> 3);
+                add(xs[(size_t)((x - X0) >> 3)], clampi((int)(tl + 1.0f), Pv.w) >> 3);
+            }
+            for (size_t j = 0; j < L.rows.size(); j++) {
+                const float tl = floorf((float)L.rows[j] * ry);
+                const int ja = row_index[l - 1][(size_t)clampi((int)tl, Pv.h)], jb = row_index[l - 1][(size_t)clampi((int)(tl + 1.0f), Pv.h)];
+                if (ja < 0 || jb < 0) { int rc_ = fail(nullptr, BHRAY_E_STATE, "internal: fused ladder: level %u row %d reads a coarse row this partition does not compute", l, L.rows[j]); dev_destroy(c); return rc_; }
+                add(ys[j >> 3], ja >> 3); add(ys[j >> 3], jb >> 3);
+            }
+            std::vector<uint8_t> xd(xs.size()), yd(ys.size());
+            for (size_t t = 0; t < xs.size(); t++) xd[t] = (uint8_t)xs[t].size();
+            for (size_t t = 0; t < ys.size(); t++) yd[t] = (uint8_t)ys[t].size();
+            CHK(hipMalloc(&Z.d_xdep[l], xd.size())); CHK(hipMemcpy(Z.d_xdep[l], xd.data(), xd.size(), hipMemcpyHostToDevice));
+            CHK(hipMalloc(&Z.d_ydep[l], yd.size())); CHK(hipMemcpy(Z.d_ydep[l], yd.data(), yd.size(), hipMemcpyHostToDevice));
+            // transposed: dependents of every coarse tile column / row (CSR), stored with the COARSE level l-1
+            auto transpose = [&](const std::vector<std::vector<uint16_t>>& sets, uint32_t ncoarse, uint32_t*& d_off, uint16_t*& d_list) -> hipError_t {
+                std::vector<uint32_t> off(ncoarse + 1, 0);
+                for (const auto& v : sets) for (uint16_t e : v) off[(size_t)e + 1]++;
+                for (uint32_t i = 0; i < ncoarse; i++) off[i + 1] += off[i];
+                std::vector<uint16_t> list(off[ncoarse] ? off[ncoarse] : 1);
+                std::vector<uint32_t> fill(off.begin(), off.end() - 1);
+                for (size_t t = 0; t < sets.size(); t++) for (uint16_t e : sets[t]) list[fill[e]++] = (uint16_t)t;
+                hipError_t e_ = hipMalloc(&d_off, off.size() * sizeof(uint32_t)); if (e_ != hipSuccess) return e_;
+                e_ = hipMemcpy(d_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice); if (e_ != hipSuccess) return e_;
+                e_ = hipMalloc(&d_list, list.size() * sizeof(uint16_t)); if (e_ != hipSuccess) return e_;
+                return hipMemcpy(d_list, list.data(), list.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+            };
+            CHK(transpose(xs, Z.tiles_x[l - 1], Z.d_nx_off[l - 1], Z.d_nx_list[l - 1]));
+            CHK(transpose(ys, Z.tiles_y[l - 1], Z.d_ny_off[l - 1], Z.d_ny_list[l - 1]));
+        }
+    }
     c->out_bytes = (opt.frame_rowmap ? (size_t)cfg->frame_h : c->local_rows.size()) * (size_t)cfg->frame_w * sizeof(float4);
     const size_t nlaunch = 5 * (size_t)nl + 3;                            // upper bound of launches per batch
     // Streams beyond the hardware queues ROCm maps them onto (GPU_MAX_HW_QUEUES, default 4; two are left to the null stream and a
@@ -488,7 +578,7 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
         CHK(hipMemset(S.d_qctl, 0, B * 2 * BHRAY_MAX_LEVELS * sizeof(uint32_t)));
         CHK(hipMalloc(&S.d_counters, B * BHRAY_MAX_LEVELS * sizeof(Counters64)));
         CHK(hipMemset(S.d_counters, 0, B * BHRAY_MAX_LEVELS * sizeof(Counters64)));
-        S.args_cap = (B * (sizeof(FrameParams) + nlaunch * sizeof(FrameLaunch)) + 15) & ~(size_t)15;
+        S.args_cap = (B * (sizeof(FrameParams) + nlaunch * sizeof(FrameLaunch) + sizeof(FusedFrame) + 16) + 15) & ~(size_t)15;
         CHK(hipHostMalloc((void**)&S.h_args, S.args_cap, hipHostMallocDefault));
         CHK(hipMalloc(&S.d_args, S.args_cap));
         S.fr.resize(B);
@@ -542,6 +632,19 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
                 size_t cap = 0;
                 for (uint32_t l = nl - cfg->superset_levels; l < nl; l++) cap += c->levels[l].queue_cap;
                 if (cap) CHK(hipMalloc(&R.super_queue, cap * sizeof(uint32_t)));
+            }
+            if (c->fz.on) {
+                const FusedTables& Z = c->fz;
+                CHK(hipMalloc(&R.fz_ctl, sizeof(FusedCtl))); CHK(hipMemset(R.fz_ctl, 0, sizeof(FusedCtl)));
+                CHK(hipMalloc(&R.fz_deps, (size_t)Z.total_tiles * sizeof(uint32_t)));
+                CHK(hipMalloc(&R.fz_pending, (size_t)Z.total_tiles * sizeof(uint32_t)));
+                const size_t ncq = (size_t)Z.total_tiles + Z.n_initial + 64;
+                CHK(hipMalloc(&R.fz_cq, ncq * sizeof(unsigned long long))); CHK(hipMemset(R.fz_cq, 0, ncq * sizeof(unsigned long long)));
+                R.fz_rq.assign(nl, nullptr);
+                for (uint32_t l = 0; l < nl; l++) {
+                    const size_t cap = c->levels[l].queue_cap + 64;
+                    CHK(hipMalloc(&R.fz_rq[l], cap * sizeof(unsigned long long))); CHK(hipMemset(R.fz_rq[l], 0, cap * sizeof(unsigned long long)));
+                }
             }
             if (c->out_bytes && !opt.external_out) {
                 CHK(hipMalloc(&R.own_out, c->out_bytes));
@@ -813,7 +916,52 @@ int launch_batch(bhray_dev* c) {
     const uint32_t ns = c->cfg.speculative_levels;
     uint32_t first_normal = 0;
     const bool any_rows = !c->levels[nl - 1].rows.empty();    // a partition without rows has nothing to launch (then no level has rows)
-    if (ns && any_rows) {
+    const bool fused = c->fz.on && any_rows;
+    if (fused) {
+        // ONE launch for the whole ladder of the batch's frames (bhray_internal.h: fused ladder): the tile state is reset, then the
+        // persistent kernel classifies tiles and traces rays as their dependencies resolve.
+        const FusedTables& Z = c->fz;
+        FrameLaunch* h; const FrameLaunch* d; next_launch(h, d);
+        args_used = (args_used + 15) & ~(size_t)15;
+        FusedFrame* hz = (FusedFrame*)(S.h_args + args_used); const FusedFrame* dz = (const FusedFrame*)(S.d_args + args_used);
+        args_used += (size_t)nb * sizeof(FusedFrame);
+        if (args_used > S.args_cap) return fail(c, BHRAY_E_STATE, "internal: argument block overflow");
+        const uint32_t nall = ns ? ns : 1;
+        for (uint32_t k = 0; k < nb; k++) {
+            FrameRes& R = S.fr[k];
+            if (++R.fz_stamp == 0) R.fz_stamp = 1;                 // queue entries of this launch carry this tag (0 = never written)
+            FusedFrame& F = hz[k];
+            memset(&F, 0, sizeof F);
+            F.nl = (int)nl; F.ns = (int)ns; F.stamp = R.fz_stamp; F.n_initial = Z.n_initial; F.total_tiles = Z.total_tiles;
+            F.n_items = Z.n_initial + (Z.total_tiles - Z.tiles_x[0] * Z.tiles_y[0]);
+            for (uint32_t l = 0; l < BHRAY_MAX_SPEC_LEVELS; l++) F.init_end[l] = l < nl ? Z.init_end[l] : Z.n_initial;
+            F.ctl = R.fz_ctl; F.deps = R.fz_deps; F.pending = R.fz_pending; F.cq = R.fz_cq;
+            for (uint32_t l = 0; l < nl; l++) {
+                FusedLevel& V = F.lv[l];
+                level_params(R, l, V.L);
+                V.L.tag = (int)l;
+                V.all_traced = l < nall ? 1 : 0;
+                if (V.all_traced && l > 0) V.L.spec = R.spec_out[l];
+                V.row_index = Z.d_row_index[l];
+                V.tile_base = Z.tile_base[l]; V.tiles_x = Z.tiles_x[l]; V.tiles_y = Z.tiles_y[l];
+                V.xdep = Z.d_xdep[l]; V.ydep = Z.d_ydep[l];
+                V.nx_off = Z.d_nx_off[l]; V.nx_list = Z.d_nx_list[l]; V.ny_off = Z.d_ny_off[l]; V.ny_list = Z.d_ny_list[l];
+                V.rq = R.fz_rq[l]; V.rq_cap = (uint32_t)(c->levels[l].queue_cap + 64);
+                V.counters = count ? R.d_counters + l : nullptr;
+                if (V.all_traced && l > 0) { V.ray_out = R.spec_out[l]; V.ray_pitch = V.L.w; V.ray_x0 = 0; V.ray_rowmap = nullptr; }
+                else { V.ray_out = V.L.out; V.ray_pitch = V.L.out_pitch; V.ray_x0 = V.L.out_x0; V.ray_rowmap = V.L.rowmap; }
+            }
+            level_params(R, 0, h[k].L);
+            h[k].queue = R.queue[0]; h[k].qctl = R.d_qctl; h[k].counters = count ? R.d_counters : nullptr;
+            h[k].fz = dz + k;
+        }
+        seq.push_back({3, d, (int)Z.total_tiles, false, {0, 1}, {}});
+        std::vector<int> after = {2};
+        for (uint32_t l = 1; l < nl; l++) { after.push_back((int)(3 * l)); after.push_back((int)(3 * l + 1)); after.push_back((int)(3 * l + 2)); }
+        int fb_ = c->bpc_override > 0 ? c->bpc_override : fused_blocks_per_cu(S.method, S.models, count, literal);
+        seq.push_back({4, d, (c->grid_override > 0 ? c->grid_override : c->num_cus * fb_), count, {}, after});
+    }
+    if (ns && any_rows && !fused) {
         // (1) every needed pixel of levels 0..ns-1 into ONE level-tagged queue, (2) one trace launch over it,
         // (3) classify levels 1..ns-1 against the traced images.  Queue control words of level 0 serve the merged queue.
         for (uint32_t l = 0; l < ns; l++) {
@@ -855,7 +1003,7 @@ int launch_batch(bhray_dev* c) {
         first_normal = ns;
     }
     const bool temporal = (c->cfg.flags & BHRAY_F_TEMPORAL) != 0;
-    if (temporal && any_rows) {
+    if (temporal && any_rows && !fused) {
         // Temporal speculation: ONE launch traces, for every level, the pixels the previous frame held in this slot position had
         // to trace (its exact classification recorded them); then the ladder runs as usual, except that a pixel that needs tracing
         // and was delivered by the predicted launch (stamp) is not traced again.  With a perfect prediction the per-level trace
@@ -919,7 +1067,7 @@ int launch_batch(bhray_dev* c) {
     }
     const uint32_t nu = temporal ? 0 : c->cfg.superset_levels;
     const uint32_t u0 = nu ? nl - nu : nl;                     // first level of the superset group
-    for (uint32_t l = first_normal; l < u0 && any_rows; l++) {
+    for (uint32_t l = first_normal; l < u0 && any_rows && !fused; l++) {
         FrameLaunch* h; const FrameLaunch* d; next_launch(h, d);
         for (uint32_t k = 0; k < nb; k++) {
             const FrameRes& R = S.fr[k];
@@ -929,7 +1077,7 @@ int launch_batch(bhray_dev* c) {
         seq.push_back({0, d, classify_blocks(l), count, {(int)(3 * l)}, {(int)(3 * l + 1)}});
         seq.push_back({1, d, grid, count, {}, {(int)(3 * l + 2)}});
     }
-    if (nu && any_rows) {
+    if (nu && any_rows && !fused) {
         // Superset speculation over the last nu levels: ONE trace launch instead of nu dependent ones.
         //  (1) tentative classification of levels u0..nl-1 in order: a pixel whose coarser inputs are known is classified exactly,
         //      a pixel with an input that is itself queued (PENDING) is queued conservatively -> one level-tagged queue;
@@ -982,7 +1130,7 @@ int launch_batch(bhray_dev* c) {
     if (timing && c->d_span) {                 // execution spans of this batch's trace launches (entry 0 of each launch's FrameLaunch array)
         int nt = 0;
         for (const Launch& Ln : seq) {
-            if (Ln.kind != 1 || nt >= SPAN_MAX) continue;
+            if ((Ln.kind != 1 && Ln.kind != 4) || nt >= SPAN_MAX) continue;
             FrameLaunch* h0 = (FrameLaunch*)(S.h_args + ((const uint8_t*)Ln.d - S.d_args));
             h0->span = c->d_span + (ring * SPAN_MAX + (size_t)nt) * 2;
             nt++;
@@ -1000,7 +1148,9 @@ int launch_batch(bhray_dev* c) {
     if (timing) { c->sky_recorded[ring] = 0; c->ring_frames[ring] = (uint8_t)nb; }
     for (const Launch& Ln : seq) {
         if (timing) for (int e : Ln.ev_before) HIPCHK(c, hipEventRecord(fev[e], st));
-        if (Ln.kind == 2) HIPCHK(c, launch_predict(dP, Ln.d, (int)nb, Ln.levels, Ln.blocks, st));
+        if (Ln.kind == 3) HIPCHK(c, launch_fused_reset(Ln.d, (int)nb, Ln.blocks, st));
+        else if (Ln.kind == 4) HIPCHK(c, launch_fused(dP, Ln.d, (int)nb, S.method, S.models, Ln.count, literal, c->d_err, Ln.blocks, st));
+        else if (Ln.kind == 2) HIPCHK(c, launch_predict(dP, Ln.d, (int)nb, Ln.levels, Ln.blocks, st));
         else if (Ln.kind == 0) HIPCHK(c, launch_classify(dP, Ln.d, (int)nb, Ln.blocks, Ln.count, Ln.fixup, st));
         else HIPCHK(c, launch_trace(dP, Ln.d, (int)nb, S.method, S.models, Ln.count, Ln.build < 0 ? dense : Ln.build != 0, literal, c->d_err, Ln.blocks, st));
         if (timing) for (int e : Ln.ev_after) HIPCHK(c, hipEventRecord(fev[e], st));
@@ -1357,6 +1507,7 @@ int dev_get_timing(bhray_dev* c, bhray_timing* out) {
             float a = 0, b = 0;
             HIPCHK(c, hipEventElapsedTime(&a, ev[3 * l], ev[3 * l + 1]));
             HIPCHK(c, hipEventElapsedTime(&b, ev[3 * l + 1], ev[3 * l + 2]));
+            if (c->fz.on && l > 0) { if (!first) first = ev[3 * l]; last = ev[3 * l + 2]; continue; }      // fused ladder: one launch, booked as level 0's
             const bool spec_classified = (c->cfg.speculative_levels && l >= 1 && l < c->cfg.speculative_levels) ||
                                          (c->cfg.superset_levels && l > nl - c->cfg.superset_levels);               // no trace launch of its own
             out->classify_ms += a; out->level_classify_ms[l] += a; out->classify_launches++;

@@ -748,7 +748,8 @@ __global__ __launch_bounds__(BHRAY_CLASSIFY_THREADS) void classify_kernel(const 
 // ------------------------------------------------------------------------------------------
 // trace: ray.wgsl:269-285 + 482-596
 // ------------------------------------------------------------------------------------------
-enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, M_SHADE_FLAT = 5 };   // M_SHADE_x: a disk hit waits for its shading, then continues in mode x
+enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, M_SHADE_FLAT = 5,
+             M_WAIT = -1 };   // fused ladder: the lane holds a slot of a ray queue whose entry has not been published yet (cold pix = slot, it = level)   // M_SHADE_x: a disk hit waits for its shading, then continues in mode x
 #ifndef BHRAY_THIN_WAVES
 #define BHRAY_THIN_WAVES 1024    // latency build: a short queue is dealt out evenly over this many waves (MI355X: 256 CUs x 4 SIMDs); 0 = off
 #endif
@@ -781,6 +782,182 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #ifndef BHRAY_MAILBOX_T
 #define BHRAY_MAILBOX_T 0        // drain merging (measured, off: DESIGN.md §4): a wave with this many live rays or fewer parks them; 0 disables
 #endif
+
+// ------------------------------------------------------------------------------------------
+// fused ladder (BHRAY_F_FUSED; structures and protocol: bhray_internal.h)
+// ------------------------------------------------------------------------------------------
+// Every word another workgroup reads or writes is an 8-byte (or 4-byte) agent-scope atomic on BOTH sides: such accesses bypass the
+// per-CU L1 and are coherent between the XCDs' L2s (MI355X_MICROARCH.md: "8-B agent atomics both sides"); no fences are needed.
+#define BHRAY_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+__device__ __forceinline__ unsigned long long ld_u64_agent(const unsigned long long* p) { return __hip_atomic_load(p, BHRAY_RLX_AGENT); }
+__device__ __forceinline__ void st_u64_agent(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, BHRAY_RLX_AGENT); }
+__device__ __forceinline__ uint32_t ld_u32_agent(const uint32_t* p) { return __hip_atomic_load(p, BHRAY_RLX_AGENT); }
+__device__ __forceinline__ void st_u32_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, BHRAY_RLX_AGENT); }
+__device__ __forceinline__ float4 ld_px_agent(const float4* p) {
+    const unsigned long long a = ld_u64_agent(reinterpret_cast<const unsigned long long*>(p));
+    const unsigned long long b = ld_u64_agent(reinterpret_cast<const unsigned long long*>(p) + 1);
+    return make_float4(u2f((uint32_t)a), u2f((uint32_t)(a >> 32)), u2f((uint32_t)b), u2f((uint32_t)(b >> 32)));
+}
+__device__ __forceinline__ void st_px_agent(float4* p, float4 v) {
+    st_u64_agent(reinterpret_cast<unsigned long long*>(p), (unsigned long long)f2u(v.x) | ((unsigned long long)f2u(v.y) << 32));
+    st_u64_agent(reinterpret_cast<unsigned long long*>(p) + 1, (unsigned long long)f2u(v.z) | ((unsigned long long)f2u(v.w) << 32));
+}
+// every vector memory operation of this wave has completed (write-through stores included): what must precede the publication of a
+// counter / queue entry that tells another workgroup the data is there.  Inline asm: the compiler may drop a builtin wait.
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+    return (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
+}
+__device__ __forceinline__ void drain_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Takes up to `want` items of the half-open range [*head, *tail) - ONE lane calls.  `tail` only grows; a CAS bounded by it never
+// reserves an item no producer has reserved (an unbounded atomicAdd would leave lanes waiting for entries that never come).
+__device__ __forceinline__ uint32_t take_bounded(uint32_t* head, const uint32_t* tail, uint32_t want, uint32_t& first) {
+    uint32_t h = ld_u32_agent(head);
+    for (;;) {
+        const uint32_t t = ld_u32_agent(tail);
+        if (h >= t) return 0u;
+        const uint32_t n = want < t - h ? want : t - h;
+        const uint32_t seen = atomicCAS(head, h, h + n);
+        if (seen == h) { first = h; return n; }
+        h = seen;
+    }
+}
+// lanes with `ready` publish tile `ft` as a classify item (wave-uniform call)
+__device__ __forceinline__ void fused_push_tiles(const FusedFrame& Z, bool ready, uint32_t ft, int lane) {
+    const unsigned long long m = __ballot(ready);
+    if (m == 0ull) return;
+    const int leader = (int)__builtin_ctzll(m);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&Z.ctl->cq_tail, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader);
+    if (ready) st_u64_agent(&Z.cq[base + lanes_below(m)], ((unsigned long long)Z.stamp << 32) | ft);
+}
+// Tile `tile` (a global tile id of level l) is FINAL: every pixel of it has been stored.  Its dependents at level l+1 lose one
+// dependency each (the lanes take one dependent each); those that have none left become classify items.  Wave-uniform call.
+__device__ __forceinline__ void fused_tile_final(const FusedFrame& Z, int l, uint32_t tile, int lane) {
+    const FusedLevel& V = Z.lv[l];
+    if (l + 1 < Z.nl) {
+        const FusedLevel& W = Z.lv[l + 1];
+        const uint32_t t = tile - V.tile_base, tx = t % V.tiles_x, ty = t / V.tiles_x;
+        const uint32_t x0 = V.nx_off[tx], nx = V.nx_off[tx + 1] - x0, y0 = V.ny_off[ty], ny = V.ny_off[ty + 1] - y0;
+        const uint32_t n = nx * ny;
+        for (uint32_t k0 = 0; k0 < n; k0 += 64u) {
+            const uint32_t k = k0 + (uint32_t)lane;
+            bool ready = false; uint32_t ft = 0;
+            if (k < n) {
+                ft = W.tile_base + (uint32_t)V.ny_list[y0 + k / nx] * W.tiles_x + (uint32_t)V.nx_list[x0 + k % nx];
+                ready = atomicSub(&Z.deps[ft], 1u) == 1u;
+            }
+            fused_push_tiles(Z, ready, ft, lane);
+        }
+    }
+    if (lane == 0 && atomicSub(&Z.ctl->tiles_left, 1u) == 1u) st_u32_agent(&Z.ctl->done, 1u);
+}
+// The rays a tile queued have all stored their pixels (pending reached 0).  Level 0 and the levels that are classified normally: the
+// tile is final.  A speculative level >= 1: its traced values are complete, which was the tile's own dependency for its classification.
+__device__ __forceinline__ void fused_rays_done(const FusedFrame& Z, int l, uint32_t tile, int lane) {
+    if (Z.lv[l].all_traced && l > 0) {
+        bool ready = false;
+        if (lane == 0) ready = atomicSub(&Z.deps[tile], 1u) == 1u;
+        fused_push_tiles(Z, ready, tile, lane);
+    } else {
+        fused_tile_final(Z, l, tile, lane);
+    }
+}
+// publishes the rays of one tile (lanes with `want`) in level l's ray queue; returns their number (wave-uniform call)
+__device__ __forceinline__ uint32_t fused_push_rays(const FusedFrame& Z, int l, uint32_t tile, bool want, uint32_t pix, int lane) {
+    const unsigned long long m = __ballot(want);
+    const uint32_t cnt = (uint32_t)__popcll(m);
+    if (cnt == 0u) return 0u;
+    // the tile's pixel stores have completed (caller: drain_vm) and its pending count is in place BEFORE any ray can be taken
+    uint32_t base = 0;
+    if (lane == 0) {
+        st_u32_agent(&Z.pending[tile], cnt);
+        drain_vm();
+        base = atomicAdd(&Z.ctl->rq[l].reserve, cnt);
+    }
+    base = (uint32_t)__shfl((int)base, 0);
+    if (want) st_u64_agent(&Z.lv[l].rq[base + lanes_below(m)], ((unsigned long long)Z.stamp << 32) | pix);
+    return cnt;
+}
+// One work item of the tile ring: `enqueue_all` - every pixel of a tile of an all-traced level becomes a ray; otherwise the
+// classification of ray.wgsl:167-243 for the tile's 64 pixels (one lane each), exactly as classify_kernel decides (same operations on
+// the same values), with the coarser level read through agent-scope loads.  Wave-uniform call by a wave that holds no rays.
+template <bool COUNT>
+__device__ __forceinline__ void fused_process_tile(const FrameParams& P, const FusedFrame& Z, int l, uint32_t tile, bool enqueue_all, int lane) {
+    const FusedLevel& V = Z.lv[l];
+    const LevelParams& L = V.L;
+    const uint32_t t = tile - V.tile_base, tx = t % V.tiles_x, ty = t / V.tiles_x;
+    const int x = L.x0 + (int)tx * 8 + (lane & 7), j = (int)ty * 8 + (lane >> 3);
+    const bool valid = x < L.x1 && j < L.nrows;
+    const int y = valid ? L.rows[j] : 0;
+    const bool last = l == Z.nl - 1;
+    bool need_trace = false;
+    int kind = -1;
+    if (valid) {
+        if (enqueue_all) {
+            need_trace = true; kind = 2;
+        } else {
+            const float ppx = (float)x * L.rx, ppy = (float)y * L.ry;
+            const float tlx = floorf(ppx), tly = floorf(ppy);
+            auto ldp = [&](int cx, int cy) {
+                cx = cx < 0 ? 0 : (cx > L.pw - 1 ? L.pw - 1 : cx);
+                cy = cy < 0 ? 0 : (cy > L.ph - 1 ? L.ph - 1 : cy);
+                return ld_px_agent(L.prev + ((size_t)cy * (size_t)L.pw + (size_t)cx));
+            };
+            auto store = [&](float4 v) {
+                float4* dst = L.out + out_index(L, x, y);
+                if (last) *dst = v; else st_px_agent(dst, v);
+            };
+            const float4 c_tl = ldp((int)tlx, (int)tly);
+            if (fabsf(tlx - ppx) < 0.001f && fabsf(tly - ppy) < 0.001f) {
+                store(c_tl); kind = 0;
+            } else {
+                const float4 c_bl = ldp((int)tlx, (int)(tly + 1.0f));
+                const float4 c_tr = ldp((int)(tlx + 1.0f), (int)tly);
+                const float4 c_br = ldp((int)(tlx + 1.0f), (int)(tly + 1.0f));
+                const bool alphas0 = c_tl.w == 0.0f && c_tr.w == 0.0f && c_bl.w == 0.0f && c_br.w == 0.0f;
+                bool interp = false;
+                if (alphas0) {
+                    const float cs = P.acos_cstar;
+                    interp = cosine_below_threshold(angle_cosine(c_bl, c_tl), cs) && cosine_below_threshold(angle_cosine(c_br, c_tr), cs) &&
+                             cosine_below_threshold(angle_cosine(c_tl, c_tr), cs) && cosine_below_threshold(angle_cosine(c_bl, c_br), cs);
+                }
+                if (interp) {
+                    const float tx_ = ppx - tlx, ty_ = ppy - tly;
+                    const F3 top = mix3(f3(c_tl.x, c_tl.y, c_tl.z), f3(c_tr.x, c_tr.y, c_tr.z), tx_);
+                    const F3 bot = mix3(f3(c_bl.x, c_bl.y, c_bl.z), f3(c_br.x, c_br.y, c_br.z), tx_);
+                    const F3 p = mix3(top, bot, ty_);
+                    store(make_float4(p.x, p.y, p.z, 0.0f)); kind = 1;
+                } else {
+                    need_trace = true; kind = 2;
+                    if (L.spec) {                    // a speculative level: the traced value exists (its rays were this tile's own dependency)
+                        store(ld_px_agent(L.spec + ((size_t)y * (size_t)L.w + (size_t)x)));
+                        need_trace = false;
+                    }
+                }
+            }
+        }
+    }
+    if (COUNT && !enqueue_all && V.counters) {
+        const unsigned long long nv = __popcll(__ballot(valid)), nc = __popcll(__ballot(kind == 0)), ni = __popcll(__ballot(kind == 1));
+        if (lane == 0) { atomicAdd(&V.counters->v[0], nv); atomicAdd(&V.counters->v[1], nc); atomicAdd(&V.counters->v[2], ni); }
+    }
+    if (COUNT && enqueue_all && l == 0 && Z.ns == 0 && V.counters) {     // level 0's pixels are all traced pixels: counted as the classify kernel counts them (it does not in speculative mode)
+        const unsigned long long nv = __popcll(__ballot(valid));
+        if (lane == 0) atomicAdd(&V.counters->v[0], nv);
+    }
+    drain_vm();                                      // this wave's pixel stores are complete before anything announces them
+    const uint32_t pix = ((uint32_t)l << 30) | ((uint32_t)y << 15) | (uint32_t)x;
+    const uint32_t cnt = fused_push_rays(Z, l, tile, need_trace, pix, lane);
+    // this level's ray queue closes when its last tile has been processed: every producer's reservation precedes its own decrement,
+    // so the reserve counter read by whoever brings the count to zero is final
+    if (lane == 0 && (enqueue_all || !V.all_traced) && atomicSub(&Z.ctl->rq[l].unprocessed, 1u) == 1u) st_u32_agent(&Z.ctl->rq[l].final, ld_u32_agent(&Z.ctl->rq[l].reserve) + 1u);
+    if (cnt == 0u) {
+        if (enqueue_all) fused_rays_done(Z, l, tile, lane);       // (a tile without a valid pixel cannot exist; kept total)
+        else fused_tile_final(Z, l, tile, lane);
+    }
+}
 
 // Cold per-lane ray state: values the integrator step loop reads or writes only on its rare paths (sphere exit, an actual hit)
 // or not at all (the pixel id) — 8 words per lane.  The dense build (6 waves per SIMD = 80 VGPRs) keeps them in LDS, one word
@@ -817,7 +994,7 @@ template <> struct ColdState<true> {
 #ifdef BHRAY_EXP_PROFILE
 __device__ long long xp_dump[8192 * 16];
 #endif
-template <int METHOD, bool MODELS, bool COUNT, bool DENSE, int EVAL = 0>
+template <int METHOD, bool MODELS, bool COUNT, bool DENSE, int EVAL = 0, bool FUSED = false>
 __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHRAY_TRACE_WAVES_DENSE : BHRAY_TRACE_WAVES)) void trace_kernel(const FrameParams* __restrict__ Pb, const FrameLaunch* __restrict__ Fb, const int nb, int* __restrict__ err_flag) {
     const int lane = threadIdx.x & 63;
     int err = 0;
@@ -865,9 +1042,61 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
         __syncthreads();
     }
     // the frames of the batch, starting with this block's own: a block whose frame has run dry helps with the others
-    for (int fi = 0; fi < nb; fi++) {
+    // FUSED, tile work.  ONE wave of every block (a different SIMD from block to block) is a CLASSIFIER: it serves the tile ring of one
+    // frame of the batch - a ticket per item (one unconditional atomicAdd), then it waits for THAT item and processes it: enqueue-all
+    // items of the all-traced levels first (ring positions below n_initial are implicit), then classify items as tile dependencies
+    // resolve.  The number of classifiers is fixed, so however far their tickets run ahead of what has been published, the other
+    // waves are there to trace the rays the items wait for; and an item on the critical path is served the moment it is published,
+    // by a wave that does nothing else.  When the ring's known total (n_items) is handed out the classifier becomes a tracer.
+    if (FUSED) {
+        const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform, and the compiler must know it
+        if (wave_in_block == (blockIdx.x & (BHRAY_TRACE_THREADS / 64 - 1))) {
+            const int fb = (int)(blockIdx.x % (unsigned)nb);
+            const FrameParams& P = Pb[fb];
+            const FusedFrame& Z = *Fb[fb].fz;
+            for (;;) {
+                uint32_t tk = 0;
+                if (lane == 0) tk = atomicAdd(&Z.ctl->cq_head, 1u);
+                tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+                if (tk >= Z.n_items) break;
+                uint32_t tile; int l = 0; bool enqueue_all;
+                if (tk < Z.n_initial) {
+#pragma unroll
+                    for (int q = 0; q < BHRAY_MAX_SPEC_LEVELS - 1; q++) if (q + 1 < Z.nl && tk >= Z.init_end[q]) l = q + 1;
+                    tile = Z.lv[l].tile_base + (tk - (l > 0 ? Z.init_end[l - 1] : 0u));
+                    enqueue_all = true;
+                } else {
+                    unsigned long long e = 0;
+                    int polls = 0;
+                    bool bad = false;
+                    for (;;) {                                   // the item this ticket stands for: published when its tile's last dependency resolves
+                        e = uniform_u64(ld_u64_agent(&Z.cq[tk]));   // (one address for the whole wave: keep the loop's exit wave-uniform for the compiler too)
+                        if ((uint32_t)(e >> 32) == Z.stamp) break;
+                        polls++;
+                        if (polls < 8) __builtin_amdgcn_s_sleep(4); else if (polls < 64) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(64);
+                        if (polls > (1 << 21)) { bad = true; break; }
+                    }
+                    if (bad) { err = BHRAY_E_STATE; break; }
+                    tile = (uint32_t)e;
+#pragma unroll
+                    for (int q = 1; q < BHRAY_MAX_SPEC_LEVELS; q++) if (q < Z.nl && tile >= Z.lv[q].tile_base) l = q;
+                    enqueue_all = false;
+                }
+                fused_process_tile<COUNT>(P, Z, l, tile, enqueue_all, lane);
+            }
+        }
+    }
+    // FUSED: a wave keeps cycling over the batch's frames until it has seen every one of them complete (FusedCtl::done); it leaves a
+    // frame in which it holds no ray and finds no work, and comes back later
+    uint32_t fused_done_mask = 0u;
+    int fused_idle = 0;                           // consecutive polls that found nothing (back-off; survives the hop to another frame)
+    for (int fi = 0; FUSED || fi < nb; fi++) {
     const int fb = (int)((blockIdx.x + (unsigned)fi) % (unsigned)nb);
     const bool last_frame = fi == nb - 1;
+    if (FUSED) {
+        if (fused_done_mask == (nb >= 32 ? 0xffffffffu : ((1u << nb) - 1u))) break;
+        if (fused_done_mask & (1u << fb)) continue;
+    }
     const FrameParams& P = Pb[fb];
     const FrameLaunch& F = Fb[fb];
     const LevelParams& L = F.L;
@@ -916,6 +1145,8 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
     // step loop, taken or not - the latency build keeps it in a VGPR; the dense build has no VGPR to spare (80: 6 waves per SIMD).
     typename std::conditional<COLD_LDS, bool, int>::type hit = 0;
     bool exhausted = false;
+    int fused_wait_round = 0;   // FUSED: this wave's outstanding ticket of the tile ring
+    uint32_t fused_tile = 0; int fused_lv = 0; bool fused_fin = false;      // FUSED: the tile the ray that has just finished belongs to
     int flat_round = 0;
     unsigned long long cnt[13];           // [0..9] = bhray_counters' frame counters, [10] wave steps (lane 0), [11] rays adopted, [12] longest ray
     if (COUNT) { for (int k = 0; k < 13; k++) cnt[k] = 0; }
@@ -935,7 +1166,87 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
         const bool xp_refill = __any(mode == M_EMPTY);
 #endif
         // ---- refill finished lanes from the queue (wave ballot + prefix popcount)
-        {
+        if (FUSED) {
+            const FusedFrame& Z = *F.fz;
+            // Rays are handed out by TICKETS: one unconditional atomicAdd on the level's head for a few slots (a compare-and-swap bounded by
+            // the producers' counter turns into a storm of failing atomics when a thousand idle waves see the same new entries).  Waves
+            // that saw the same entries may take slots beyond what has been published; such a lane waits on ITS OWN slot (M_WAIT) - an
+            // address nobody else polls - while the wave's other rays keep stepping, and gives the slot up when the level has closed
+            // (every tile of it processed: rq.final) below its index, or when the slot lies beyond the level's pixel count.
+            const auto start_ray = [&](uint32_t pix) {      // create_ray, ray.wgsl:269-285 (right/up/fwd_ff hoisted to the host, bit-identical) - the plain refill's text
+                cold.set_pix(pix);
+                const int px = (int)(pix & 0x7fffu), py = (int)((pix >> 15) & 0x7fffu), lv = (int)(pix >> 30);
+                const int lw = Z.lv[lv].L.w, lh = Z.lv[lv].L.h;
+                const int sm = (lw - 1) < (lh - 1) ? (lw - 1) : (lh - 1);
+                const float increment = 1.0f / (float)sm;
+                const float posx = (2.0f * ((float)px - (float)(lw - 1) * 0.5f)) * increment;
+                const float posy = (2.0f * ((float)py - (float)(lh - 1) * 0.5f)) * increment;
+                const F3 cam = ld3(P.cam);
+                const F3 rdir = normalize((ld3(P.right) * posx + ld3(P.up) * posy) + ld3(P.fwd_ff));
+                cold.set_rdir(rdir);
+                cpos = cam; cdir = rdir; ppos = cam; pdir = rdir;
+                rkpos = cam; rkdir = rdir; rkh = P.step_size;
+                cold.set_color(f3(0, 0, 0)); amount = 1.0f; closest = H.ray_distance;
+                dist_c = P.ray_distance_f; cpos_dist = P.ray_distance_f; qrel = cam - bpos;
+                it = 0; hit = 0;
+                mode = P.relativity0 ? M_REL : M_FLAT;
+                if (COUNT) cnt[3]++;
+            };
+            const unsigned long long need = __ballot(mode == M_EMPTY);
+            // (a) slots for the empty lanes, coarsest level first (the coarse levels are the critical path).  A short queue is dealt out a
+            //     few rays per wave: a phase lasts as long as its longest ray, and what that ray pays per step is what its WAVE executes
+            if (need != 0ull && (__popcll(need) >= BHRAY_REFILL_MIN || !__any(mode == M_REL))) {
+                uint32_t first = 0, got = 0; int l = 0;
+                const int src = (int)__builtin_ctzll(need);
+                if (lane == src) {
+                    const uint32_t n = (uint32_t)__popcll(need);
+                    const uint32_t waves = gridDim.x * (BHRAY_TRACE_THREADS / 64);
+                    for (int q = 0; q < BHRAY_MAX_SPEC_LEVELS; q++) {
+                        if (q >= Z.nl) break;
+                        const uint32_t r = ld_u32_agent(&Z.ctl->rq[q].reserve), h = ld_u32_agent(&Z.ctl->rq[q].head);
+                        const int avail = (int)(r - h);
+                        if (avail <= 0) continue;
+                        uint32_t cap = ((uint32_t)avail + waves - 1u) / waves;
+                        cap = cap < 4u ? 4u : cap;
+                        got = n < cap ? n : cap;
+                        first = atomicAdd(&Z.ctl->rq[q].head, got);
+                        l = q;
+                        break;
+                    }
+                }
+                got = (uint32_t)__shfl((int)got, src); first = (uint32_t)__shfl((int)first, src); l = __shfl(l, src);
+                if (got != 0u) {
+                    fused_idle = 0;
+                    const uint32_t rank = lanes_below(need);
+                    if (mode == M_EMPTY && rank < got && first + rank < Z.lv[l].rq_cap) { mode = M_WAIT; cold.set_pix(first + rank); it = l; }
+                }
+            }
+            // (b) lanes that hold a slot look at it
+            if (__any(mode == M_WAIT)) {
+                if (mode == M_WAIT) {
+                    const uint32_t idx = cold.pix();
+                    const int lw_ = it;
+                    const unsigned long long e = ld_u64_agent(&Z.lv[lw_].rq[idx]);
+                    if ((uint32_t)(e >> 32) == Z.stamp) {
+                        start_ray((uint32_t)e);
+                    } else if ((fused_wait_round & 7) == 0) {                            // (the closing word is one address for everybody: look rarely)
+                        const uint32_t f = ld_u32_agent(&Z.ctl->rq[lw_].final);
+                        if (f != 0u && idx >= f - 1u) { mode = M_EMPTY; it = 0; }     // the level closed below this slot: nothing will come
+                    }
+                }
+                fused_wait_round++;
+                if (fused_wait_round > (1 << 22)) { err = BHRAY_E_STATE; if (mode == M_WAIT) { mode = M_EMPTY; it = 0; } }     // a slot that never fills: a bug, not a hang
+                if (!__any(mode > M_EMPTY)) __builtin_amdgcn_s_sleep(32);             // only waiting lanes: do not spin at full speed
+            }
+            if (!__any(mode != M_EMPTY)) {                       // this wave holds no ray, waits for none
+                if (__builtin_amdgcn_readfirstlane((int)ld_u32_agent(&Z.ctl->done)) != 0) { fused_done_mask |= 1u << fb; break; }
+                fused_idle++;
+                if (nb > 1 && fused_idle > 8) break;            // look at the batch's other frames; this one is revisited
+                if (fused_idle < 4) __builtin_amdgcn_s_sleep(8); else if (fused_idle < 16) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(127);
+                if (fused_idle > (1 << 20)) { err = BHRAY_E_STATE; fused_done_mask |= 1u << fb; break; }
+                continue;
+            }
+        } else {
             const unsigned long long need = __ballot(mode == M_EMPTY);
             if (need != 0ull && !exhausted && (BHRAY_REFILL_MIN <= 1 || __popcll(need) >= BHRAY_REFILL_MIN || !__any(mode == M_REL))) {
                 uint32_t n = (uint32_t)__popcll(need);
@@ -1215,7 +1526,17 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                 } else {
                     o = make_float4(cdir.x, cdir.y, cdir.z, 0.0f);
                 }
-                {
+                if (FUSED) {
+                    const FusedFrame& Z = *F.fz;
+                    const int ox = (int)(pix & 0x7fffu), oy = (int)((pix >> 15) & 0x7fffu), lv = (int)(pix >> 30);
+                    const FusedLevel& V = Z.lv[lv];
+                    const int orow = V.ray_rowmap ? V.ray_rowmap[oy] : oy;
+                    float4* d = V.ray_out + ((size_t)orow * (size_t)V.ray_pitch + (size_t)(ox - V.ray_x0));
+                    if (lv == Z.nl - 1) *d = o; else st_px_agent(d, o);          // a coarser level's pixel is read by other workgroups in this launch
+                    fused_tile = V.tile_base + (uint32_t)(V.row_index[oy] >> 3) * V.tiles_x + (uint32_t)((ox - V.L.x0) >> 3);
+                    fused_lv = lv;
+                    fused_fin = true;
+                } else {
                     const int ox = (int)(pix & 0x7fffu), oy = (int)((pix >> 15) & 0x7fffu);
                     if (SL.n > 0) {
                         const int lv = (int)(pix >> 30);
@@ -1235,6 +1556,21 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                     }
                 }
                 mode = M_EMPTY;
+            }
+            if (FUSED) {
+                // the pixels are stored (write-through, complete): each finished ray leaves its tile; whoever takes a tile's last ray
+                // hands the tile on (its dependents' classification, or - speculative level - its own)
+                const FusedFrame& Z = *F.fz;
+                drain_vm();
+                bool last_of_tile = false;
+                if (fused_fin) last_of_tile = atomicSub(&Z.pending[fused_tile], 1u) == 1u;
+                unsigned long long fm = __ballot(last_of_tile);
+                while (fm != 0ull) {
+                    const int k = (int)__builtin_ctzll(fm);
+                    fm &= fm - 1ull;
+                    fused_rays_done(Z, __shfl(fused_lv, k), (uint32_t)__shfl((int)fused_tile, k), lane);
+                }
+                fused_fin = false;
             }
         }
 
@@ -1475,6 +1811,63 @@ hipError_t launch_trace(const FrameParams* Pb, const FrameLaunch* Fb, int nb, in
     if (eval == 1) return launch_trace_e<1>(Pb, Fb, nb, method, models, count, dense, err_flag, grid_blocks, s);
     if (eval == 2) return launch_trace_e<2>(Pb, Fb, nb, method, models, count, dense, err_flag, grid_blocks, s);
     return launch_trace_e<0>(Pb, Fb, nb, method, models, count, dense, err_flag, grid_blocks, s);
+}
+
+// ---- fused ladder launchers -----------------------------------------------------------------------
+// Reset of the batch's tile state: deps[tile] = (coarse tile columns read) x (coarse tile rows read) (+ 1 for a speculative level >= 1:
+// its own traced values), pending = 0, the control words.  blockIdx.y = frame.
+__global__ __launch_bounds__(256) void fused_reset_kernel(const FrameLaunch* __restrict__ Fb) {
+    const FusedFrame& Z = *Fb[blockIdx.y].fz;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t == 0u) {
+        FusedCtl c; memset(&c, 0, sizeof c);
+        c.cq_tail = Z.n_initial; c.tiles_left = Z.total_tiles;
+        for (int q = 0; q < BHRAY_MAX_SPEC_LEVELS; q++) c.rq[q].unprocessed = q < Z.nl ? Z.lv[q].tiles_x * Z.lv[q].tiles_y : 0u;
+        *Z.ctl = c;
+    }
+    if (t >= Z.total_tiles) return;
+    int l = 0;
+#pragma unroll
+    for (int q = 1; q < BHRAY_MAX_SPEC_LEVELS; q++) if (q < Z.nl && t >= Z.lv[q].tile_base) l = q;
+    const FusedLevel& V = Z.lv[l];
+    uint32_t d = 0;
+    if (l > 0) {
+        const uint32_t k = t - V.tile_base;
+        d = (uint32_t)V.xdep[k % V.tiles_x] * (uint32_t)V.ydep[k / V.tiles_x] + (V.all_traced ? 1u : 0u);
+    }
+    Z.deps[t] = d;
+    Z.pending[t] = 0u;
+}
+hipError_t launch_fused_reset(const FrameLaunch* Fb, int nb, int max_tiles, hipStream_t s) {
+    if (nb <= 0 || max_tiles <= 0) return hipSuccess;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(fused_reset_kernel, dim3((unsigned)((max_tiles + 255) / 256), (unsigned)nb), dim3(256), 0, s, Fb);
+    return hipGetLastError();
+}
+template <int EVAL>
+static const void* fused_kernel_ptr(int method, int has_models, int count) {
+#define PICK(M, MD, C) (const void*)trace_kernel<M, MD, C, false, EVAL, true>
+    if (has_models) return method == 0 ? (count ? PICK(0, true, true) : PICK(0, true, false)) : (count ? PICK(1, true, true) : PICK(1, true, false));
+    return method == 0 ? (count ? PICK(0, false, true) : PICK(0, false, false)) : (count ? PICK(1, false, true) : PICK(1, false, false));
+#undef PICK
+}
+static const void* fused_kernel(int method, int has_models, int count, int eval) {
+    return eval == 1 ? fused_kernel_ptr<1>(method, has_models, count) : eval == 2 ? fused_kernel_ptr<2>(method, has_models, count) : fused_kernel_ptr<0>(method, has_models, count);
+}
+hipError_t launch_fused(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int method, bool models, bool count, int eval, int* err_flag, int grid_blocks, hipStream_t s) {
+    if (nb <= 0) return hipSuccess;
+    (void)hipGetLastError();
+    const size_t dyn_lds = models ? (size_t)BHRAY_BVH_LDS_TOP * 32 + (size_t)BHRAY_BVH_LDS_STACK * BHRAY_TRACE_THREADS * 8 : 0;
+    void* args[] = {(void*)&Pb, (void*)&Fb, (void*)&nb, (void*)&err_flag};
+    return hipLaunchKernel(fused_kernel(method, models ? 1 : 0, count ? 1 : 0, eval), dim3((unsigned)((grid_blocks * 256 + BHRAY_TRACE_THREADS - 1) / BHRAY_TRACE_THREADS)),
+                           dim3(BHRAY_TRACE_THREADS), args, dyn_lds, s);
+}
+int fused_blocks_per_cu(int method, int has_models, int count, int eval) {
+    int n = 0;
+    const size_t dyn_lds = has_models ? (size_t)BHRAY_BVH_LDS_TOP * 32 + (size_t)BHRAY_BVH_LDS_STACK * BHRAY_TRACE_THREADS * 8 : 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fused_kernel(method, has_models, count, eval), BHRAY_TRACE_THREADS, dyn_lds) != hipSuccess || n < 1) n = 2;
+    n = n * BHRAY_TRACE_THREADS / 256;
+    return n < 1 ? 1 : n;
 }
 
 template <int EVAL>
