@@ -958,7 +958,11 @@ int launch_batch(bhray_dev* c) {
         seq.push_back({3, d, (int)Z.total_tiles, false, {0, 1}, {}});
         std::vector<int> after = {2};
         for (uint32_t l = 1; l < nl; l++) { after.push_back((int)(3 * l)); after.push_back((int)(3 * l + 1)); after.push_back((int)(3 * l + 2)); }
-        int fb_ = c->bpc_override > 0 ? c->bpc_override : fused_blocks_per_cu(S.method, S.models, count, literal);
+        // 2 blocks of 256 threads per CU: every hand-off of the fused ladder is a round trip through the CU's memory queue, whose price grows
+        // with the number of memory-active waves on the CU (one 1080p frame at a time: 4 blocks 2.47 ms, 2 blocks 2.09, 1 block 2.27)
+        int fb_ = fused_blocks_per_cu(S.method, S.models, count, literal);
+        fb_ = fb_ > 2 ? 2 : fb_;
+        if (c->bpc_override > 0) fb_ = c->bpc_override;
         seq.push_back({4, d, (c->grid_override > 0 ? c->grid_override : c->num_cus * fb_), count, {}, after});
     }
     if (ns && any_rows && !fused) {

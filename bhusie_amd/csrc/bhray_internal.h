@@ -110,13 +110,16 @@ struct Counters64 { unsigned long long v[13]; };   // order = bhray_counters
 // workgroups are 8-byte agent-scope atomics both sides (MI355X: per-XCD L2s are not coherent, L1s are never refreshed by other
 // CUs): queue entries are {stamp, payload} granules, pixels of non-final levels are stored and loaded as two 8-byte halves.
 // ------------------------------------------------------------------------------------------
+// Every control word sits on its own 128-byte line: they are hit by atomics and polled from every CU, and words that share a line
+// share one L2 channel's queue (the first version kept them in one line: a 1080p frame took 14 ms instead of 1).
+struct alignas(128) FusedWord { uint32_t v; uint32_t pad[31]; };
 struct FusedCtl {                  // per frame, reset before every launch (fused_reset_kernel)
-    uint32_t cq_tail, cq_head;     // work ring of tiles (classify / enqueue-all items): entries published / taken
-    uint32_t tiles_left;           // tiles that are not final yet (all levels); 0 <=> the frame is complete
-    uint32_t done;                 // set by whoever finalises the last tile
-    struct { uint32_t reserve, head, final, unprocessed; } rq[BHRAY_MAX_SPEC_LEVELS];   // ray queue of each level: entries reserved by producers / slots handed
-                                   // out / (entries in total) + 1 once every tile of the level has been processed (0: open) / tiles not processed yet
-    uint32_t pad[4];
+    FusedWord cq_tail, cq_head;    // work ring of tiles (classify / enqueue-all items): entries published / tickets handed out
+    FusedWord tiles_left;          // tiles that are not final yet (all levels); 0 <=> the frame is complete
+    FusedWord done;                // set by whoever finalises the last tile
+    // ray queue of each level: entries reserved by producers / slots handed out / (entries in total) + 1 once every tile of the level
+    // has been processed (0: open) / tiles not processed yet
+    struct { FusedWord reserve, head, final, unprocessed; } rq[BHRAY_MAX_SPEC_LEVELS];
 };
 struct FusedLevel {
     LevelParams L;                 // geometry, prev / out, rows - what the classification of this level needs (L.spec: traced image of a speculative level >= 1)

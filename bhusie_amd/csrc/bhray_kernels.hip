@@ -779,6 +779,30 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #define BHRAY_REFILL_MIN 16      // refill from the queue (one atomic on its head + a dependent load) only when this many lanes are empty, or nobody is
                                  // stepping: measured 1 / 8 / 16 / 24 / 32 / 48 -> 5 357 / 5 428 / 5 435 / 5 414 / 5 387 / 5 254 Mrays/s (Euler 8 009 -> 8 148 at 16)
 #endif
+#ifndef BHRAY_FUSED_CLAIM_LAST
+#define BHRAY_FUSED_CLAIM_LAST 32      // fused ladder: smallest claim on the LAST level's ray queue (340 k rays at 1080p: claims of 4 are 85 k atomics on one word)
+#endif
+#ifndef BHRAY_FUSED_SLOT_SLEEP
+#define BHRAY_FUSED_SLOT_SLEEP 2        // x s_sleep(127) (~3.4 us each) between the slot polls of a wave that only waits
+#endif
+// Two refinements that were built and measured (one 1080p frame at a time, 2 blocks per CU; profiles/EXPERIMENTS.md): idle tracers helping
+// with bursts of tile items (2.09 -> 2.52 ms: their polls of the ring cost more than the help is worth) and second-tier tracers that join
+// only when a level holds a bulk of rays (2.09 -> 2.10 ms).  Both stay in the source, off.
+#ifndef BHRAY_FUSED_HELPERS
+#define BHRAY_FUSED_HELPERS 0
+#endif
+#ifndef BHRAY_FUSED_TIERS
+#define BHRAY_FUSED_TIERS 0
+#endif
+#ifndef BHRAY_FUSED_BULK
+#define BHRAY_FUSED_BULK 4096           // fused ladder: entries a level's queue must hold before the second-tier tracers join
+#endif
+#ifndef BHRAY_FUSED_TICKETS
+#define BHRAY_FUSED_TICKETS 4          // fused ladder: tile-ring tickets a classifier takes with one atomic
+#endif
+#ifndef BHRAY_FUSED_RAYS_AHEAD
+#define BHRAY_FUSED_RAYS_AHEAD 512    // fused ladder: slots of a level's ray queue that idle lanes may hold beyond the published entries
+#endif
 #ifndef BHRAY_MAILBOX_T
 #define BHRAY_MAILBOX_T 0        // drain merging (measured, off: DESIGN.md §4): a wave with this many live rays or fewer parks them; 0 disables
 #endif
@@ -828,13 +852,13 @@ __device__ __forceinline__ void fused_push_tiles(const FusedFrame& Z, bool ready
     if (m == 0ull) return;
     const int leader = (int)__builtin_ctzll(m);
     uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(&Z.ctl->cq_tail, (uint32_t)__popcll(m));
+    if (lane == leader) base = atomicAdd(&Z.ctl->cq_tail.v, (uint32_t)__popcll(m));
     base = (uint32_t)__shfl((int)base, leader);
     if (ready) st_u64_agent(&Z.cq[base + lanes_below(m)], ((unsigned long long)Z.stamp << 32) | ft);
 }
 // Tile `tile` (a global tile id of level l) is FINAL: every pixel of it has been stored.  Its dependents at level l+1 lose one
 // dependency each (the lanes take one dependent each); those that have none left become classify items.  Wave-uniform call.
-__device__ __forceinline__ void fused_tile_final(const FusedFrame& Z, int l, uint32_t tile, int lane) {
+__device__ __forceinline__ void fused_tile_final(const FusedFrame& Z, int l, uint32_t tile, int lane, uint32_t* batched_final = nullptr) {
     const FusedLevel& V = Z.lv[l];
     if (l + 1 < Z.nl) {
         const FusedLevel& W = Z.lv[l + 1];
@@ -851,7 +875,25 @@ __device__ __forceinline__ void fused_tile_final(const FusedFrame& Z, int l, uin
             fused_push_tiles(Z, ready, ft, lane);
         }
     }
-    if (lane == 0 && atomicSub(&Z.ctl->tiles_left, 1u) == 1u) st_u32_agent(&Z.ctl->done, 1u);
+    if (batched_final) { (*batched_final)++; return; }          // a classifier counts its final tiles and reports them in batches (fused_flush)
+    if (lane == 0 && atomicSub(&Z.ctl->tiles_left.v, 1u) == 1u) st_u32_agent(&Z.ctl->done.v, 1u);
+}
+// A classifier's batched bookkeeping: tiles it processed per level (closes the level's ray queue when the last one is in: every
+// producer's reservation precedes its own report, so the reserve counter read by whoever brings the count to zero is final) and tiles
+// it made final.  One atomic per word per batch instead of one per tile: 43 000 tiles per 1080p frame on one word are half a
+// millisecond of that word's L2 channel.
+__device__ __forceinline__ void fused_flush(const FusedFrame& Z, uint32_t (&processed)[BHRAY_MAX_SPEC_LEVELS], uint32_t& finals, int lane) {
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < BHRAY_MAX_SPEC_LEVELS; q++) {
+            if (processed[q] != 0u && atomicSub(&Z.ctl->rq[q].unprocessed.v, processed[q]) == processed[q])
+                st_u32_agent(&Z.ctl->rq[q].final.v, ld_u32_agent(&Z.ctl->rq[q].reserve.v) + 1u);
+        }
+        if (finals != 0u && atomicSub(&Z.ctl->tiles_left.v, finals) == finals) st_u32_agent(&Z.ctl->done.v, 1u);
+    }
+#pragma unroll
+    for (int q = 0; q < BHRAY_MAX_SPEC_LEVELS; q++) processed[q] = 0u;
+    finals = 0u;
 }
 // The rays a tile queued have all stored their pixels (pending reached 0).  Level 0 and the levels that are classified normally: the
 // tile is final.  A speculative level >= 1: its traced values are complete, which was the tile's own dependency for its classification.
@@ -872,9 +914,8 @@ __device__ __forceinline__ uint32_t fused_push_rays(const FusedFrame& Z, int l, 
     // the tile's pixel stores have completed (caller: drain_vm) and its pending count is in place BEFORE any ray can be taken
     uint32_t base = 0;
     if (lane == 0) {
-        st_u32_agent(&Z.pending[tile], cnt);
-        drain_vm();
-        base = atomicAdd(&Z.ctl->rq[l].reserve, cnt);
+        if (l != Z.nl - 1) { st_u32_agent(&Z.pending[tile], cnt); drain_vm(); }     // (nobody depends on a last-level tile: its rays are not counted)
+        base = atomicAdd(&Z.ctl->rq[l].reserve.v, cnt);
     }
     base = (uint32_t)__shfl((int)base, 0);
     if (want) st_u64_agent(&Z.lv[l].rq[base + lanes_below(m)], ((unsigned long long)Z.stamp << 32) | pix);
@@ -884,7 +925,8 @@ __device__ __forceinline__ uint32_t fused_push_rays(const FusedFrame& Z, int l, 
 // classification of ray.wgsl:167-243 for the tile's 64 pixels (one lane each), exactly as classify_kernel decides (same operations on
 // the same values), with the coarser level read through agent-scope loads.  Wave-uniform call by a wave that holds no rays.
 template <bool COUNT>
-__device__ __forceinline__ void fused_process_tile(const FrameParams& P, const FusedFrame& Z, int l, uint32_t tile, bool enqueue_all, int lane) {
+__device__ __forceinline__ void fused_process_tile(const FrameParams& P, const FusedFrame& Z, int l, uint32_t tile, bool enqueue_all, int lane,
+                                                   uint32_t (&processed)[BHRAY_MAX_SPEC_LEVELS], uint32_t& finals) {
     const FusedLevel& V = Z.lv[l];
     const LevelParams& L = V.L;
     const uint32_t t = tile - V.tile_base, tx = t % V.tiles_x, ty = t / V.tiles_x;
@@ -950,13 +992,49 @@ __device__ __forceinline__ void fused_process_tile(const FrameParams& P, const F
     drain_vm();                                      // this wave's pixel stores are complete before anything announces them
     const uint32_t pix = ((uint32_t)l << 30) | ((uint32_t)y << 15) | (uint32_t)x;
     const uint32_t cnt = fused_push_rays(Z, l, tile, need_trace, pix, lane);
-    // this level's ray queue closes when its last tile has been processed: every producer's reservation precedes its own decrement,
-    // so the reserve counter read by whoever brings the count to zero is final
-    if (lane == 0 && (enqueue_all || !V.all_traced) && atomicSub(&Z.ctl->rq[l].unprocessed, 1u) == 1u) st_u32_agent(&Z.ctl->rq[l].final, ld_u32_agent(&Z.ctl->rq[l].reserve) + 1u);
-    if (cnt == 0u) {
-        if (enqueue_all) fused_rays_done(Z, l, tile, lane);       // (a tile without a valid pixel cannot exist; kept total)
-        else fused_tile_final(Z, l, tile, lane);
+    if (enqueue_all || !V.all_traced) {                 // (a speculative level's queue closes with its enqueue-all items; its classify items queue nothing)
+#pragma unroll
+        for (int q = 0; q < BHRAY_MAX_SPEC_LEVELS; q++) if (q == l) processed[q]++;
     }
+    if (cnt == 0u || last) {                                       // a last-level tile counts as final once it is classified: nothing depends on it,
+        if (enqueue_all && !last) fused_rays_done(Z, l, tile, lane);  // and the launch itself ends only when the last level's queue has been traced
+        else fused_tile_final(Z, l, tile, lane, &finals);
+    }
+}
+
+// Serves ticket `tk` of the tile ring: resolves it to its item (an implicit enqueue-all item, or the classify item published at that
+// position - waiting for it if it is not there yet, after reporting what this wave has done so far: others may be waiting for that),
+// processes it.  false: the item never came (a bug, reported as BHRAY_E_STATE by the caller).  Wave-uniform.
+template <bool COUNT>
+__device__ __forceinline__ bool fused_serve(const FrameParams& P, const FusedFrame& Z, uint32_t tk, int lane,
+                                            uint32_t (&processed)[BHRAY_MAX_SPEC_LEVELS], uint32_t& finals, uint32_t& unflushed) {
+    uint32_t tile; int l = 0; bool enqueue_all;
+    if (tk < Z.n_initial) {
+#pragma unroll
+        for (int q = 0; q < BHRAY_MAX_SPEC_LEVELS - 1; q++) if (q + 1 < Z.nl && tk >= Z.init_end[q]) l = q + 1;
+        tile = Z.lv[l].tile_base + (tk - (l > 0 ? Z.init_end[l - 1] : 0u));
+        enqueue_all = true;
+    } else {
+        unsigned long long e = uniform_u64(ld_u64_agent(&Z.cq[tk]));
+        if ((uint32_t)(e >> 32) != Z.stamp) {
+            if (unflushed != 0u) { fused_flush(Z, processed, finals, lane); unflushed = 0u; }
+            int polls = 0;
+            for (;;) {                                   // the item this ticket stands for: published when its tile's last dependency resolves
+                e = uniform_u64(ld_u64_agent(&Z.cq[tk]));   // (one address for the whole wave: keep the loop's exit wave-uniform for the compiler too)
+                if ((uint32_t)(e >> 32) == Z.stamp) break;
+                polls++;
+                if (polls < 4) __builtin_amdgcn_s_sleep(16); else if (polls < 16) __builtin_amdgcn_s_sleep(64); else __builtin_amdgcn_s_sleep(127);
+                if (polls > (1 << 21)) return false;
+            }
+        }
+        tile = (uint32_t)e;
+#pragma unroll
+        for (int q = 1; q < BHRAY_MAX_SPEC_LEVELS; q++) if (q < Z.nl && tile >= Z.lv[q].tile_base) l = q;
+        enqueue_all = false;
+    }
+    fused_process_tile<COUNT>(P, Z, l, tile, enqueue_all, lane, processed, finals);
+    if (++unflushed >= 8u) { fused_flush(Z, processed, finals, lane); unflushed = 0u; }
+    return true;
 }
 
 // Cold per-lane ray state: values the integrator step loop reads or writes only on its rare paths (sphere exit, an actual hit)
@@ -1054,36 +1132,31 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
             const int fb = (int)(blockIdx.x % (unsigned)nb);
             const FrameParams& P = Pb[fb];
             const FusedFrame& Z = *Fb[fb].fz;
+#ifdef BHRAY_EXP_PROFILE
+            const long long xc_t0 = clock64(); long long xc_wait = 0; int xc_items = 0;
+#endif
+            uint32_t processed[BHRAY_MAX_SPEC_LEVELS] = {0u, 0u, 0u, 0u}, finals = 0u, unflushed = 0u;
+            uint32_t tk_next = 0u, tk_end = 0u;                  // tickets in hand: [tk_next, tk_end)
             for (;;) {
-                uint32_t tk = 0;
-                if (lane == 0) tk = atomicAdd(&Z.ctl->cq_head, 1u);
-                tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
-                if (tk >= Z.n_items) break;
-                uint32_t tile; int l = 0; bool enqueue_all;
-                if (tk < Z.n_initial) {
-#pragma unroll
-                    for (int q = 0; q < BHRAY_MAX_SPEC_LEVELS - 1; q++) if (q + 1 < Z.nl && tk >= Z.init_end[q]) l = q + 1;
-                    tile = Z.lv[l].tile_base + (tk - (l > 0 ? Z.init_end[l - 1] : 0u));
-                    enqueue_all = true;
-                } else {
-                    unsigned long long e = 0;
-                    int polls = 0;
-                    bool bad = false;
-                    for (;;) {                                   // the item this ticket stands for: published when its tile's last dependency resolves
-                        e = uniform_u64(ld_u64_agent(&Z.cq[tk]));   // (one address for the whole wave: keep the loop's exit wave-uniform for the compiler too)
-                        if ((uint32_t)(e >> 32) == Z.stamp) break;
-                        polls++;
-                        if (polls < 8) __builtin_amdgcn_s_sleep(4); else if (polls < 64) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(64);
-                        if (polls > (1 << 21)) { bad = true; break; }
-                    }
-                    if (bad) { err = BHRAY_E_STATE; break; }
-                    tile = (uint32_t)e;
-#pragma unroll
-                    for (int q = 1; q < BHRAY_MAX_SPEC_LEVELS; q++) if (q < Z.nl && tile >= Z.lv[q].tile_base) l = q;
-                    enqueue_all = false;
+                if (tk_next == tk_end) {
+                    uint32_t t0 = 0;
+                    if (lane == 0) t0 = atomicAdd(&Z.ctl->cq_head.v, (uint32_t)BHRAY_FUSED_TICKETS);
+                    tk_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)t0); tk_end = tk_next + (uint32_t)BHRAY_FUSED_TICKETS;
                 }
-                fused_process_tile<COUNT>(P, Z, l, tile, enqueue_all, lane);
+                const uint32_t tk = tk_next++;
+                if (tk >= Z.n_items) break;
+                if (!fused_serve<COUNT>(P, Z, tk, lane, processed, finals, unflushed)) { err = BHRAY_E_STATE; break; }
+#ifdef BHRAY_EXP_PROFILE
+                xc_items++;
+#endif
             }
+            fused_flush(Z, processed, finals, lane);
+#ifdef BHRAY_EXP_PROFILE
+            if (lane == 0) {
+                long long* d = xp_dump + (size_t)(blockIdx.x * (BHRAY_TRACE_THREADS / 64) + (threadIdx.x >> 6)) * 16;
+                d[13] = clock64() - xc_t0; d[14] = xc_wait; d[15] = xc_items;
+            }
+#endif
         }
     }
     // FUSED: a wave keeps cycling over the batch's frames until it has seen every one of them complete (FusedCtl::done); it leaves a
@@ -1145,14 +1218,15 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
     // step loop, taken or not - the latency build keeps it in a VGPR; the dense build has no VGPR to spare (80: 6 waves per SIMD).
     typename std::conditional<COLD_LDS, bool, int>::type hit = 0;
     bool exhausted = false;
-    int fused_wait_round = 0;   // FUSED: this wave's outstanding ticket of the tile ring
+    const bool fused_tier1 = !BHRAY_FUSED_TIERS || (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == ((blockIdx.x + 1u) & (BHRAY_TRACE_THREADS / 64 - 1));
+    int fused_wait_round = 0, fused_lo = 0, fused_skip = 0, fused_backoff = 0;     // FUSED tracer: rounds waited on slots; first level still worth a look; rounds until the next look at the queues   // FUSED: this wave's outstanding ticket of the tile ring
     uint32_t fused_tile = 0; int fused_lv = 0; bool fused_fin = false;      // FUSED: the tile the ray that has just finished belongs to
     int flat_round = 0;
     unsigned long long cnt[13];           // [0..9] = bhray_counters' frame counters, [10] wave steps (lane 0), [11] rays adopted, [12] longest ray
     if (COUNT) { for (int k = 0; k < 13; k++) cnt[k] = 0; }
 
 #ifdef BHRAY_EXP_PROFILE                  // timing-only build: where does the time of one wave go? (profiles/r02_experiments.json: lone_wave_phases)
-    long long xp_t0 = clock64(), xp_last = xp_t0, xp_t[5] = {0, 0, 0, 0, 0}; int xp_c[5] = {0, 0, 0, 0, 0}, xp_n = 0, xp_rounds = 0;
+    long long xp_t0 = clock64(), xp_last = xp_t0, xp_t[5] = {0, 0, 0, 0, 0}, xp_idle = 0; int xp_c[5] = {0, 0, 0, 0, 0}, xp_n = 0, xp_rounds = 0;
 #define XP(k, active) { const long long now_ = clock64(); xp_t[k] += now_ - xp_last; xp_last = now_; xp_c[k] += (active) ? 1 : 0; }
 #else
 #define XP(k, active)
@@ -1193,57 +1267,111 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                 if (COUNT) cnt[3]++;
             };
             const unsigned long long need = __ballot(mode == M_EMPTY);
-            // (a) slots for the empty lanes, coarsest level first (the coarse levels are the critical path).  A short queue is dealt out a
-            //     few rays per wave: a phase lasts as long as its longest ray, and what that ray pays per step is what its WAVE executes
-            if (need != 0ull && (__popcll(need) >= BHRAY_REFILL_MIN || !__any(mode == M_REL))) {
-                uint32_t first = 0, got = 0; int l = 0;
+            // (0) an idle tracer HELPS with the tile ring when items are published and untaken (the burst when a level's last tiles
+            //     become final: a thousand classifiers are too few for 32 000 last-level tiles).  It takes one ticket at a time and only
+            //     when it saw an item; a ticket that lost the race to another wave is waited for - the item it stands for comes with the
+            //     next tiles that resolve, and the waves that served the burst are free again to trace what it produced.
+            if (BHRAY_FUSED_HELPERS && need == ~0ull && fused_skip == 0) {
+                uint32_t processed[BHRAY_MAX_SPEC_LEVELS] = {0u, 0u, 0u, 0u}, finals = 0u, unflushed = 0u;
+                bool worked = false;
+                for (int guard = 0; guard < (1 << 16); guard++) {
+                    uint32_t tk = 0; int ok = 0;
+                    if (lane == 0) {
+                        const uint32_t h = ld_u32_agent(&Z.ctl->cq_head.v), t = ld_u32_agent(&Z.ctl->cq_tail.v);
+                        if (h < t && h < Z.n_items) { tk = atomicAdd(&Z.ctl->cq_head.v, 1u); ok = tk < Z.n_items ? 1 : 0; }
+                    }
+                    ok = __builtin_amdgcn_readfirstlane(ok); tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+                    if (!ok) break;
+                    if (!fused_serve<COUNT>(P, Z, tk, lane, processed, finals, unflushed)) { err = BHRAY_E_STATE; break; }
+                    worked = true;
+                }
+                if (worked) {                                    // report, and cut the liveness of the (dead) ray state across the tile work
+                    fused_flush(Z, processed, finals, lane);
+                    cpos = f3(0, 0, 0); cdir = f3(0, 0, 1); ppos = f3(0, 0, 0); pdir = f3(0, 0, 1); rkpos = f3(0, 0, 0); rkdir = f3(0, 0, 1);
+                    rkh = 0.0f; amount = 1.0f; closest = H.ray_distance; dist_c = P.ray_distance_f; cpos_dist = P.ray_distance_f; qrel = f3(0, 0, 0);
+                    it = 0; hit = 0; fused_idle = 0; fused_backoff = 0;
+                }
+            }
+            // (a) slots for the empty lanes, coarsest open level first (the coarse levels are the critical path).  Entries that are there
+            //     are dealt out a few per wave (a phase lasts as long as its longest ray, and what that ray pays per step is what its WAVE
+            //     executes); when nothing is there, idle lanes take slots AHEAD of the producers (a bounded number per level) and wait on
+            //     them: a ray is then picked up the moment it is published, by polling an address nobody else polls.  Levels that have
+            //     closed and handed out every entry are never looked at again (fused_lo).
+            if (need != 0ull && fused_skip == 0 && (__popcll(need) >= BHRAY_REFILL_MIN || !__any(mode == M_REL))) {
+                uint32_t first = 0, got = 0; int l = 0, lo = fused_lo;
                 const int src = (int)__builtin_ctzll(need);
                 if (lane == src) {
                     const uint32_t n = (uint32_t)__popcll(need);
                     const uint32_t waves = gridDim.x * (BHRAY_TRACE_THREADS / 64);
-                    for (int q = 0; q < BHRAY_MAX_SPEC_LEVELS; q++) {
+                    for (int q = lo; q < BHRAY_MAX_SPEC_LEVELS; q++) {
                         if (q >= Z.nl) break;
-                        const uint32_t r = ld_u32_agent(&Z.ctl->rq[q].reserve), h = ld_u32_agent(&Z.ctl->rq[q].head);
+                        const uint32_t r = ld_u32_agent(&Z.ctl->rq[q].reserve.v), h = ld_u32_agent(&Z.ctl->rq[q].head.v), f = ld_u32_agent(&Z.ctl->rq[q].final.v);
+                        if (f != 0u && h >= f - 1u) { if (q == lo) lo = q + 1; continue; }      // closed, every entry handed out
+                        if (h >= Z.lv[q].rq_cap) continue;
                         const int avail = (int)(r - h);
-                        if (avail <= 0) continue;
-                        uint32_t cap = ((uint32_t)avail + waves - 1u) / waves;
-                        cap = cap < 4u ? 4u : cap;
+                        uint32_t cap = 0;
+                        const uint32_t cmin = q == Z.nl - 1 ? (uint32_t)BHRAY_FUSED_CLAIM_LAST : 4u;   // thin on the coarse levels, coarse on the last
+                        // Tiers: ONE tracer per block (a different SIMD from block to block) takes whatever there is and runs ahead; the
+                        // others join only when a level holds a bulk of entries.  A few rays are best traced by one wave per SIMD - a
+                        // phase lasts as long as its longest ray, and a wave that shares its SIMD with working waves steps slower.
+                        if (avail > 0 && (fused_tier1 || avail >= BHRAY_FUSED_BULK)) { cap = ((uint32_t)avail + waves - 1u) / waves; cap = cap < cmin ? cmin : cap; }
+                        else if (fused_tier1 && f == 0u && -avail < BHRAY_FUSED_RAYS_AHEAD) cap = 4u;
+                        if (cap == 0u) continue;
                         got = n < cap ? n : cap;
-                        first = atomicAdd(&Z.ctl->rq[q].head, got);
+                        first = atomicAdd(&Z.ctl->rq[q].head.v, got);
                         l = q;
                         break;
                     }
                 }
-                got = (uint32_t)__shfl((int)got, src); first = (uint32_t)__shfl((int)first, src); l = __shfl(l, src);
+                got = (uint32_t)__shfl((int)got, src); first = (uint32_t)__shfl((int)first, src); l = __shfl(l, src); fused_lo = __shfl(lo, src);
                 if (got != 0u) {
-                    fused_idle = 0;
+                    fused_idle = 0; fused_backoff = 0;
                     const uint32_t rank = lanes_below(need);
                     if (mode == M_EMPTY && rank < got && first + rank < Z.lv[l].rq_cap) { mode = M_WAIT; cold.set_pix(first + rank); it = l; }
+                } else {                                         // nothing to take, nothing to wait for: look again after 1, 2, 4 ... 32 rounds
+                    fused_backoff = fused_backoff < 5 ? fused_backoff + 1 : 5;
+                    fused_skip = 1 << fused_backoff;
                 }
+            } else if (fused_skip > 0) {
+                fused_skip--;
             }
             // (b) lanes that hold a slot look at it
-            if (__any(mode == M_WAIT)) {
+            if (__any(mode == M_WAIT) && ((fused_wait_round & 1) == 0 || !__any(mode > M_EMPTY))) {
                 if (mode == M_WAIT) {
                     const uint32_t idx = cold.pix();
                     const int lw_ = it;
                     const unsigned long long e = ld_u64_agent(&Z.lv[lw_].rq[idx]);
                     if ((uint32_t)(e >> 32) == Z.stamp) {
                         start_ray((uint32_t)e);
-                    } else if ((fused_wait_round & 7) == 0) {                            // (the closing word is one address for everybody: look rarely)
-                        const uint32_t f = ld_u32_agent(&Z.ctl->rq[lw_].final);
+                    } else if ((fused_wait_round & 6) == 0) {                            // (the closing word is one address for everybody: look rarely)
+                        const uint32_t f = ld_u32_agent(&Z.ctl->rq[lw_].final.v);
                         if (f != 0u && idx >= f - 1u) { mode = M_EMPTY; it = 0; }     // the level closed below this slot: nothing will come
                     }
                 }
-                fused_wait_round++;
-                if (fused_wait_round > (1 << 22)) { err = BHRAY_E_STATE; if (mode == M_WAIT) { mode = M_EMPTY; it = 0; } }     // a slot that never fills: a bug, not a hang
-                if (!__any(mode > M_EMPTY)) __builtin_amdgcn_s_sleep(32);             // only waiting lanes: do not spin at full speed
+                if (fused_wait_round > (1 << 20)) { err = BHRAY_E_STATE; if (mode == M_WAIT) { mode = M_EMPTY; it = 0; } }     // a slot that never fills: a bug, not a hang
+                if (!__any(mode > M_EMPTY)) {                                        // only waiting lanes: every poll is a trip across the fabric - and steals issue slots from the SIMD's working waves
+#pragma unroll
+                    for (int z = 0; z < BHRAY_FUSED_SLOT_SLEEP; z++) __builtin_amdgcn_s_sleep(127);
+                }
             }
+            if (__any(mode == M_WAIT)) fused_wait_round++;
             if (!__any(mode != M_EMPTY)) {                       // this wave holds no ray, waits for none
-                if (__builtin_amdgcn_readfirstlane((int)ld_u32_agent(&Z.ctl->done)) != 0) { fused_done_mask |= 1u << fb; break; }
+                if (__builtin_amdgcn_readfirstlane((int)ld_u32_agent(&Z.ctl->done.v)) != 0) {
+                    // every tile is classified and every coarse ray stored; the last level's rays are not counted: the frame is complete for
+                    // this wave once every entry of the last level's (closed) queue has been handed out - the waves holding them finish them
+                    const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld_u32_agent(&Z.ctl->rq[Z.nl - 1].final.v));
+                    const uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld_u32_agent(&Z.ctl->rq[Z.nl - 1].head.v));
+                    if (f != 0u && h >= f - 1u) { fused_done_mask |= 1u << fb; break; }
+                }
                 fused_idle++;
                 if (nb > 1 && fused_idle > 8) break;            // look at the batch's other frames; this one is revisited
-                if (fused_idle < 4) __builtin_amdgcn_s_sleep(8); else if (fused_idle < 16) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(127);
-                if (fused_idle > (1 << 20)) { err = BHRAY_E_STATE; fused_done_mask |= 1u << fb; break; }
+#ifdef BHRAY_EXP_PROFILE
+                { const long long now_ = clock64(); xp_idle += now_ - xp_last; xp_last = now_; }
+#endif
+                fused_skip = 0;                                  // an idle wave looks at the queues every time it wakes: its sleep is the rate limit
+                if (fused_idle < 4) __builtin_amdgcn_s_sleep(8); else if (fused_idle < 16) __builtin_amdgcn_s_sleep(32);
+                else if (fused_idle < 64) __builtin_amdgcn_s_sleep(127); else { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
+                if (fused_idle > (1 << 19)) { err = BHRAY_E_STATE; fused_done_mask |= 1u << fb; break; }
                 continue;
             }
         } else {
@@ -1532,10 +1660,14 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                     const FusedLevel& V = Z.lv[lv];
                     const int orow = V.ray_rowmap ? V.ray_rowmap[oy] : oy;
                     float4* d = V.ray_out + ((size_t)orow * (size_t)V.ray_pitch + (size_t)(ox - V.ray_x0));
-                    if (lv == Z.nl - 1) *d = o; else st_px_agent(d, o);          // a coarser level's pixel is read by other workgroups in this launch
-                    fused_tile = V.tile_base + (uint32_t)(V.row_index[oy] >> 3) * V.tiles_x + (uint32_t)((ox - V.L.x0) >> 3);
-                    fused_lv = lv;
-                    fused_fin = true;
+                    if (lv == Z.nl - 1) {
+                        *d = o;                                                  // the frame: nobody reads it in this launch, nothing to report
+                    } else {
+                        st_px_agent(d, o);                                       // a coarser level's pixel is read by other workgroups in this launch
+                        fused_tile = V.tile_base + (uint32_t)(V.row_index[oy] >> 3) * V.tiles_x + (uint32_t)((ox - V.L.x0) >> 3);
+                        fused_lv = lv;
+                        fused_fin = true;
+                    }
                 } else {
                     const int ox = (int)(pix & 0x7fffu), oy = (int)((pix >> 15) & 0x7fffu);
                     if (SL.n > 0) {
@@ -1561,7 +1693,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                 // the pixels are stored (write-through, complete): each finished ray leaves its tile; whoever takes a tile's last ray
                 // hands the tile on (its dependents' classification, or - speculative level - its own)
                 const FusedFrame& Z = *F.fz;
-                drain_vm();
+                if (__any(fused_fin)) drain_vm();
                 bool last_of_tile = false;
                 if (fused_fin) last_of_tile = atomicSub(&Z.pending[fused_tile], 1u) == 1u;
                 unsigned long long fm = __ballot(last_of_tile);
@@ -1605,6 +1737,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
         long long* d = xp_dump + (size_t)(blockIdx.x * (BHRAY_TRACE_THREADS / 64) + (threadIdx.x >> 6)) * 16;
         d[0] = clock64() - xp_t0; d[1] = xp_rounds; d[2] = xp_n;
         for (int k = 0; k < 5; k++) { d[3 + k] = xp_t[k]; d[8 + k] = xp_c[k]; }
+        if (FUSED) d[12] = xp_idle;
 #ifdef BHRAY_EXP_PROFILE_FINE
         d[8] = xf_loop; d[9] = xf_step; d[10] = xf_cull; d[11] = xf_tail;
 #endif
@@ -1820,10 +1953,12 @@ __global__ __launch_bounds__(256) void fused_reset_kernel(const FrameLaunch* __r
     const FusedFrame& Z = *Fb[blockIdx.y].fz;
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t == 0u) {
-        FusedCtl c; memset(&c, 0, sizeof c);
-        c.cq_tail = Z.n_initial; c.tiles_left = Z.total_tiles;
-        for (int q = 0; q < BHRAY_MAX_SPEC_LEVELS; q++) c.rq[q].unprocessed = q < Z.nl ? Z.lv[q].tiles_x * Z.lv[q].tiles_y : 0u;
-        *Z.ctl = c;
+        FusedCtl* c = Z.ctl;
+        c->cq_tail.v = Z.n_initial; c->cq_head.v = 0u; c->tiles_left.v = Z.total_tiles; c->done.v = 0u;
+        for (int q = 0; q < BHRAY_MAX_SPEC_LEVELS; q++) {
+            c->rq[q].reserve.v = 0u; c->rq[q].head.v = 0u; c->rq[q].final.v = 0u;
+            c->rq[q].unprocessed.v = q < Z.nl ? Z.lv[q].tiles_x * Z.lv[q].tiles_y : 0u;
+        }
     }
     if (t >= Z.total_tiles) return;
     int l = 0;
