@@ -1,27 +1,35 @@
 #!/bin/bash
-# N-way row tiling emulated on ONE GPU, every rank's tiles in turn (before the gather): the slowest rank is what a real N-GPU frame costs.
-# Writes gpurun_out/emulate_all_ranks.json (copied to profiles/r02_emulate_all_ranks.json).
+# GPU box, repo root: renders every rank's row tiles of an N-way partition in turn on ONE GPU (bench.py --emulate-world N --emulate-rank r;
+# before the gather), for N = 2, 4, 8, with the driver's 20-frame blocks and with long blocks.  The slowest rank bounds the
+# multi-GPU frame rate.  Output: gpurun_out/emulate_all_ranks.json (copied to profiles/<tag>_emulate_all_ranks.json).
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-cd $ROOT; mkdir -p gpurun_out
+OUT=$ROOT/gpurun_out/emulate
+mkdir -p $OUT
+cd $ROOT
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs > $OUT/n1_short.json 2>/dev/null
+python bench.py --steps 400 --warmup 32 --no-cpu-baseline --no-extra-legs > $OUT/n1_long.json 2>/dev/null
+for N in 2 4 8; do for ((r=0; r<N; r++)); do
+  python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs --emulate-world $N --emulate-rank $r > $OUT/n${N}_r${r}_short.json 2>/dev/null
+  python bench.py --steps 400 --warmup 32 --no-cpu-baseline --no-extra-legs --emulate-world $N --emulate-rank $r --min-seconds 0.2 > $OUT/n${N}_r${r}_long.json 2>/dev/null
+done; done
 python - <<'PY'
-import json, subprocess, sys
-out = {}
-for n in (2, 4, 8):
-    for tag, extra in (("long_blocks", ["--steps", "192", "--warmup", "32"]), ("20_frame_blocks", ["--steps", "20", "--warmup", "5"])):
-        ms = []
-        for r in range(n):
-            p = subprocess.run([sys.executable, "bench.py", "--emulate-world", str(n), "--emulate-rank", str(r), "--no-cpu-baseline", "--min-seconds", "0.4"] + extra, capture_output=True, text=True)
-            ms.append(json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])["ms_per_step"])
-        out[f"n{n}_{tag}"] = {"ms_per_frame_by_rank": ms, "slowest": max(ms), "fastest": min(ms)}
-        print(n, tag, ms, flush=True)
-base = {}
-for tag, extra in (("long_blocks", ["--steps", "192", "--warmup", "32"]), ("20_frame_blocks", ["--steps", "20", "--warmup", "5"])):
-    p = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--min-seconds", "0.4"] + extra, capture_output=True, text=True)
-    base[tag] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])["ms_per_step"]
-out["n1"] = base
-for n in (2, 4, 8):
-    for tag in ("long_blocks", "20_frame_blocks"):
-        out[f"n{n}_{tag}"]["scaling_of_the_slowest_rank"] = round(base[tag] / out[f"n{n}_{tag}"]["slowest"], 3)
-json.dump(out, open("gpurun_out/emulate_all_ranks.json", "w"), indent=1)
-print(json.dumps({k: v.get("scaling_of_the_slowest_rank") for k, v in out.items() if k != "n1"}))
+import json, glob, os
+root = os.environ.get("GRAFT_REPO_ROOT", ".")
+d = os.path.join(root, "gpurun_out", "emulate")
+def load(n): return json.load(open(os.path.join(d, n)))
+out = {"note": "one GPU renders ONE rank's row tiles of an N-way partition (27-row interleaved stripes, frames per batch auto), before the gather; "
+               "scaling = N=1 ms per frame / slowest rank's ms per frame; valu.frac = THIS RANK's algorithmic flops / its time / the VALU peak",
+       "n1": {k: {"ms_per_step": load(f"n1_{k}.json")["ms_per_step"], "mrays_per_s": load(f"n1_{k}.json")["value"]} for k in ("short", "long")}}
+for N in (2, 4, 8):
+    for kind in ("short", "long"):
+        rows = []
+        for r in range(N):
+            j = load(f"n{N}_r{r}_{kind}.json")
+            rows.append({"rank": r, "ms_per_step": j["ms_per_step"], "valu_frac": j["valu"]["frac"], "frames_per_batch": j["config"]["frames_per_batch"]})
+        worst = max(x["ms_per_step"] for x in rows)
+        out[f"n{N}_{kind}"] = {"ranks": rows, "slowest_ms_per_step": worst, "scaling": round(out["n1"][kind]["ms_per_step"] / worst, 3),
+                               "blocks": "20-frame blocks (--steps 20 --warmup 5)" if kind == "short" else "400-frame blocks"}
+json.dump(out, open(os.path.join(root, "gpurun_out", "emulate_all_ranks.json"), "w"), indent=1)
+print(json.dumps({k: (v["scaling"], v["slowest_ms_per_step"]) for k, v in out.items() if k.startswith("n") and k != "n1"}))
 PY
+rm -rf $OUT
