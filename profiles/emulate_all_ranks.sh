@@ -30,6 +30,6 @@ for N in (2, 4, 8):
         out[f"n{N}_{kind}"] = {"ranks": rows, "slowest_ms_per_step": worst, "scaling": round(out["n1"][kind]["ms_per_step"] / worst, 3),
                                "blocks": "20-frame blocks (--steps 20 --warmup 5)" if kind == "short" else "400-frame blocks"}
 json.dump(out, open(os.path.join(root, "gpurun_out", "emulate_all_ranks.json"), "w"), indent=1)
-print(json.dumps({k: (v["scaling"], v["slowest_ms_per_step"]) for k, v in out.items() if k.startswith("n") and k != "n1"}))
+print(json.dumps({k: (v["scaling"], v["slowest_ms_per_step"]) for k, v in out.items() if k[0] == "n" and k[1].isdigit() and "_" in k}))
 PY
 rm -rf $OUT
