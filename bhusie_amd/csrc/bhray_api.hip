@@ -29,7 +29,6 @@ namespace {
 
 thread_local std::string g_create_error;
 
-#define BHRAY_COPY_STREAMS 2
 #define BHRAY_READ_RING 64
 constexpr int SPAN_MAX = BHRAY_MAX_LEVELS + 2;      // trace launches per batch (per-level, + speculative / predicted)
 
@@ -158,8 +157,7 @@ struct bhray_dev {
     int grid_override = 0;                 // BHRAY_TRACE_GRID: absolute number of persistent trace blocks (tuning experiments only)
     int dense_override = -1;               // BHRAY_TRACE_DENSE=0/1 (tuning experiments only)
     bool rendered = false;
-    // asynchronous hand-off (dev_read_hdr_async): copies run on their own streams (the SDMA engines), behind the frame's kernels
-    hipStream_t copy_stream[BHRAY_COPY_STREAMS] = {nullptr, nullptr};
+    // asynchronous hand-off (dev_read_hdr_async)
     hipEvent_t read_ev[BHRAY_READ_RING] = {nullptr};     // ticket t -> read_ev[t % BHRAY_READ_RING]
     uint64_t read_tickets = 0;
     std::string err;
@@ -397,7 +395,6 @@ void dev_destroy(bhray_dev* c) {
     for (auto& e : c->events) if (e) (void)hipEventDestroy(e);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->d_span) (void)hipFree(c->d_span);
-    for (auto& st : c->copy_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (auto& e : c->read_ev) if (e) (void)hipEventDestroy(e);
     delete c;
 }
@@ -1256,9 +1253,11 @@ int dev_read_hdr(bhray_dev* c, float* dst, size_t pitch) {
 }
 
 // Asynchronous hand-off of the most recently enqueued frame to host memory (a consumer on another device: the wgpu texture the
-// reference's SkyPipeline samples, ray_pipeline.rs:297-299, mod.rs:215).  The copy is enqueued on one of the engine's copy streams
-// (SDMA: no CU time) behind that frame's kernels; the call returns at once, frame k's copy overlaps frame k+1's render.  `dst` should be pinned (bhray_host_alloc / hipHostRegister): a pageable destination makes
-// the runtime stage the copy and the call synchronous.  The slot's next frame waits for the copy before it overwrites the image.
+// reference's SkyPipeline samples, ray_pipeline.rs:297-299, mod.rs:215).  The copy (SDMA: no CU time, 55.7 GB/s into pinned memory
+// on this box) is enqueued ON THE FRAME'S OWN SLOT STREAM, behind its kernels; the call returns at once and the other slots' frames
+// render while it runs.  (First version: dedicated copy streams ordered by events both ways - ROCm 7.2 then ran copies and kernels
+// strictly one after the other, 1.22 ms per 1080p frame; in stream order 0.62 ms, which is the link rate: profiles/EXPERIMENTS.md.)
+// `dst` should be pinned (bhray_host_alloc / hipHostRegister): a pageable destination makes the runtime stage the copy.
 int dev_read_hdr_async(bhray_dev* c, float* dst, size_t pitch, uint64_t* ticket) {
     if (!c || !ticket) return BHRAY_E_INVALID;
     const size_t rowb = (size_t)c->cfg.frame_w * sizeof(float4);
@@ -1274,20 +1273,11 @@ int dev_read_hdr_async(bhray_dev* c, float* dst, size_t pitch, uint64_t* ticket)
     if (rows) {
         if (!dst || pitch < rowb) return fail(c, BHRAY_E_INVALID, "bad destination / pitch");
         const uint8_t* src = (const uint8_t*)S.fr[(size_t)c->last_sub].out;
-        // ONE copy per frame (a single hipMemcpyAsync already runs at the link rate: 55.7 GB/s device -> pinned host on this box,
-        // profiles/ubench/pcie_handoff.hip; halves on two streams or a copy kernel are not faster), consecutive frames on alternating
-        // copy streams so that a copy whose frame is not finished yet does not hold back the next one
-        hipStream_t& cs = c->copy_stream[t % BHRAY_COPY_STREAMS];
-        if (!cs) HIPCHK(c, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-        HIPCHK(c, hipStreamWaitEvent(cs, S.done, 0));
-        if (pitch == rowb) HIPCHK(c, hipMemcpyAsync(dst, src, rows * rowb, hipMemcpyDeviceToHost, cs));
-        else HIPCHK(c, hipMemcpy2DAsync(dst, pitch, src, rowb, rowb, rows, hipMemcpyDeviceToHost, cs));
-        HIPCHK(c, hipEventRecord(ev, cs));
-    } else {
-        if (!c->copy_stream[0]) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream[0], hipStreamNonBlocking));
-        HIPCHK(c, hipEventRecord(ev, c->copy_stream[0]));
+        if (pitch == rowb) HIPCHK(c, hipMemcpyAsync(dst, src, rows * rowb, hipMemcpyDeviceToHost, S.stream));
+        else HIPCHK(c, hipMemcpy2DAsync(dst, pitch, src, rowb, rowb, rows, hipMemcpyDeviceToHost, S.stream));
     }
-    HIPCHK(c, hipStreamWaitEvent(S.stream, ev, 0));        // the slot's next batch overwrites the image only after the copy has read it
+    HIPCHK(c, hipEventRecord(ev, S.stream));
+    HIPCHK(c, hipEventRecord(S.done, S.stream));           // whatever is ordered behind this slot's frame is ordered behind its copy too
     *ticket = t;
     c->read_tickets = t + 1;
     return BHRAY_OK;

@@ -158,7 +158,6 @@ struct bhray_ctx {
     RowDesc* d_table = nullptr; uint32_t table_rows = 0;      // root GPU
     size_t staging_rows = 0;               // rows of one staging buffer (all non-root partitions, B frames)
     float4* bound = nullptr;               // bhray_bind_output: destination of the next frame (one-shot)
-    hipStream_t copy_stream = nullptr;     // gather mode: bhray_read_hdr_async (root GPU)
     hipEvent_t read_ev[64] = {nullptr};
     uint64_t read_tickets = 0;
     std::vector<void*> external;           // bhray_import_external_fd: hipExternalMemory_t handles, by mapped pointer (pairs: ptr, handle)
@@ -343,7 +342,6 @@ void group_free(bhray_ctx* c) {
         if (r.comm && R) (void)R->CommDestroy(r.comm);
         if (r.stream) (void)hipStreamDestroy(r.stream);
     }
-    if (c->copy_stream) { (void)hipSetDevice(c->parts[c->root].device); (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     for (auto& e : c->read_ev) if (e) (void)hipEventDestroy(e);
     for (size_t i = 0; i + 1 < c->external.size(); i += 2) if (c->external[i + 1]) (void)hipDestroyExternalMemory((hipExternalMemory_t)c->external[i + 1]);
     for (WaitEvent& w : c->wait_pool) if (w.ev) { (void)hipSetDevice(w.device); (void)hipEventDestroy(w.ev); }
@@ -756,19 +754,19 @@ int bhray_read_hdr_async(bhray_ctx* c, float* dst, size_t pitch, uint64_t* ticke
     const size_t rowb = (size_t)c->cfg.frame_w * sizeof(float4);
     if (!dst || pitch < rowb) return gfail(c, BHRAY_E_INVALID, "bad destination / pitch");
     Part& rp = *root_part(c);
+    CommRank* rr = rank_of(c, rp);
     GHIP(c, hipSetDevice(rp.device));
-    if (!c->copy_stream) GHIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     hipEvent_t& ev = c->read_ev[t % 64];
     if (!ev) GHIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     else if (t >= 64) GHIP(c, hipEventSynchronize(ev));
     GroupSlot& G = c->gslots[(size_t)c->last_slot];
-    GHIP(c, hipStreamWaitEvent(c->copy_stream, G.frame_done, 0));        // behind the de-interleave (and the sky pass, if it was resolved)
-    if (pitch == rowb) GHIP(c, hipMemcpyAsync(dst, G.dst[c->last_sub], rowb * c->cfg.frame_h, hipMemcpyDeviceToHost, c->copy_stream));
-    else GHIP(c, hipMemcpy2DAsync(dst, pitch, G.dst[c->last_sub], rowb, rowb, c->cfg.frame_h, hipMemcpyDeviceToHost, c->copy_stream));
-    GHIP(c, hipEventRecord(ev, c->copy_stream));
-    GHIP(c, hipStreamWaitEvent(dev_slot_stream(rp.dev, c->last_slot), ev, 0));   // the root's next render into this slot writes its own rows into that frame
-    CommRank* rr = rank_of(c, rp);
-    GHIP(c, hipStreamWaitEvent(rr->stream, ev, 0));                              // ... and so does the next de-interleave
+    // in stream order on the root's communication stream: behind the de-interleave (and the sky pass, if it was resolved) of this batch,
+    // ahead of the next batch's receive.  (Cross-stream event ordering made ROCm 7.2 serialise copies and kernels: see dev_read_hdr_async.)
+    if (pitch == rowb) GHIP(c, hipMemcpyAsync(dst, G.dst[c->last_sub], rowb * c->cfg.frame_h, hipMemcpyDeviceToHost, rr->stream));
+    else GHIP(c, hipMemcpy2DAsync(dst, pitch, G.dst[c->last_sub], rowb, rowb, c->cfg.frame_h, hipMemcpyDeviceToHost, rr->stream));
+    GHIP(c, hipEventRecord(ev, rr->stream));
+    GHIP(c, hipEventRecord(G.frame_done, rr->stream));
+    GHIP(c, hipStreamWaitEvent(dev_slot_stream(rp.dev, c->last_slot), G.frame_done, 0));   // the root's next render into this slot writes its own rows into that frame
     return BHRAY_OK;
 }
 
