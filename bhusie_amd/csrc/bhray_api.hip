@@ -1283,6 +1283,32 @@ int dev_read_hdr_async(bhray_dev* c, float* dst, size_t pitch, uint64_t* ticket)
     return BHRAY_OK;
 }
 
+// The same hand-off for the RGBA16F image of the sky pass (half the bytes): bhray_resolve_sky must have been called for the frame.
+int dev_read_sky_async(bhray_dev* c, uint16_t* dst, size_t pitch, uint64_t* ticket) {
+    if (!c || !ticket) return BHRAY_E_INVALID;
+    const size_t rowb = (size_t)c->cfg.frame_w * sizeof(uint2);
+    if (!c->rendered) return fail(c, BHRAY_E_STATE, "nothing rendered yet");
+    HIPCHK(c, hipSetDevice(c->device));
+    Slot& S = c->slots[(size_t)c->last_slot];
+    FrameRes& R = S.fr[(size_t)c->last_sub];
+    const size_t rows = c->local_rows.size();
+    if (rows && !R.sky_out) return fail(c, BHRAY_E_STATE, "dev_resolve_sky has not been called for this frame");
+    const uint64_t t = c->read_tickets;
+    hipEvent_t& ev = c->read_ev[t % BHRAY_READ_RING];
+    if (!ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    else if (t >= BHRAY_READ_RING) HIPCHK(c, hipEventSynchronize(ev));
+    if (rows) {
+        if (!dst || pitch < rowb) return fail(c, BHRAY_E_INVALID, "bad destination / pitch");
+        if (pitch == rowb) HIPCHK(c, hipMemcpyAsync(dst, R.sky_out, rows * rowb, hipMemcpyDeviceToHost, S.stream));
+        else HIPCHK(c, hipMemcpy2DAsync(dst, pitch, R.sky_out, rowb, rowb, rows, hipMemcpyDeviceToHost, S.stream));
+    }
+    HIPCHK(c, hipEventRecord(ev, S.stream));
+    HIPCHK(c, hipEventRecord(S.done, S.stream));
+    *ticket = t;
+    c->read_tickets = t + 1;
+    return BHRAY_OK;
+}
+
 int dev_wait_read(bhray_dev* c, uint64_t ticket) {
     if (!c) return BHRAY_E_INVALID;
     if (ticket >= c->read_tickets) return fail(c, BHRAY_E_INVALID, "unknown read ticket");

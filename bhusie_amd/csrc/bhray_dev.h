@@ -37,6 +37,7 @@ uint32_t dev_local_rows(const bhray_dev* c);
 int  dev_local_row_index(const bhray_dev* c, uint32_t i, uint32_t* frame_row);
 int  dev_read_hdr(bhray_dev* c, float* dst, size_t pitch);
 int  dev_read_hdr_async(bhray_dev* c, float* dst, size_t pitch, uint64_t* ticket);   // in stream order behind the last frame's kernels
+int  dev_read_sky_async(bhray_dev* c, uint16_t* dst, size_t pitch, uint64_t* ticket);
 int  dev_wait_read(bhray_dev* c, uint64_t ticket);
 int  dev_read_level(bhray_dev* c, uint32_t level, float* dst, size_t pitch);
 int  dev_hdr_device_ptr(bhray_dev* c, void** p, size_t* bytes);

@@ -770,6 +770,29 @@ int bhray_read_hdr_async(bhray_ctx* c, float* dst, size_t pitch, uint64_t* ticke
     return BHRAY_OK;
 }
 
+int bhray_read_sky_async(bhray_ctx* c, uint16_t* dst, size_t pitch, uint64_t* ticket) {
+    if (!c || !ticket) return BHRAY_E_INVALID;
+    if (c->single) { DEV(c, c->parts[0].dev, dev_read_sky_async(c->parts[0].dev, dst, pitch, ticket)); return BHRAY_OK; }
+    if (!c->rendered) return gfail(c, BHRAY_E_STATE, "nothing rendered yet");
+    const uint64_t t = c->read_tickets;
+    if (!c->root_local) { *ticket = t; c->read_tickets = t + 1; return BHRAY_OK; }
+    const size_t rowb = (size_t)c->cfg.frame_w * sizeof(uint2);
+    if (!dst || pitch < rowb) return gfail(c, BHRAY_E_INVALID, "bad destination / pitch");
+    uint2* src = c->gslots[(size_t)c->last_slot].sky[c->last_sub];
+    if (!src) return gfail(c, BHRAY_E_STATE, "bhray_resolve_sky has not been called for this frame");
+    Part& rp = *root_part(c);
+    CommRank* rr = rank_of(c, rp);
+    GHIP(c, hipSetDevice(rp.device));
+    hipEvent_t& ev = c->read_ev[t % 64];
+    if (!ev) GHIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    else if (t >= 64) GHIP(c, hipEventSynchronize(ev));
+    if (pitch == rowb) GHIP(c, hipMemcpyAsync(dst, src, rowb * c->cfg.frame_h, hipMemcpyDeviceToHost, rr->stream));     // behind the sky pass, in stream order
+    else GHIP(c, hipMemcpy2DAsync(dst, pitch, src, rowb, rowb, c->cfg.frame_h, hipMemcpyDeviceToHost, rr->stream));
+    GHIP(c, hipEventRecord(ev, rr->stream));
+    *ticket = t; c->read_tickets = t + 1;
+    return BHRAY_OK;
+}
+
 int bhray_wait_read(bhray_ctx* c, uint64_t ticket) {
     if (!c) return BHRAY_E_INVALID;
     if (c->single) { DEV(c, c->parts[0].dev, dev_wait_read(c->parts[0].dev, ticket)); return BHRAY_OK; }

@@ -253,9 +253,6 @@ __device__ __forceinline__ bool hit_triangle(F3 pos, F3 dir, float t_min, float 
     return false;
 }
 
-// trace_ray_model, ray.wgsl:287-363.  The traversal stack holds node indices (the reference
-// stacks 19 whole nodes and has no overflow check); an overflow raises *err instead of
-// corrupting memory.
 // trace_ray_model, ray.wgsl:287-363.
 // Latency is what matters here (a traversal is a chain of dependent loads executed for a few lanes of a wave), so
 // the data is laid out for ONE round trip per tree level and per leaf:
@@ -264,16 +261,11 @@ __device__ __forceinline__ bool hit_triangle(F3 pos, F3 dir, float t_min, float 
 //    descended into or pushed, because a node's bounds are not needed again once its parent has tested them;
 //  - leaf geometry is pre-gathered at upload into `leaf` (3 points + 3 normals per bvh_lookup slot), removing the
 //    bvh_lookup -> triangle -> point/normal index chain (ray.wgsl:333-343) from the traversal.
-// The reference stacks 19 whole nodes without an overflow check (ray.wgsl:292,327); here the stack holds the two
-// words per node and an overflow raises *err instead of corrupting memory.
-// LDS staging (north_star: "LDS-staged triangle/node tiles"), both optional at compile time and measured on the mesh workload
-// (profiles/r02_bvh_lds.md):
-//   BHRAY_BVH_LDS_TOP    the first N nodes of the breadth-first order - the levels every traversal starts with - are copied into
-//                        LDS once per block; a child pair inside that range is read with 4 ds_read_b128 (~64 cycles) instead of
-//                        a global load (L1/L2 hit: ~200 cycles).
-//   BHRAY_BVH_LDS_STACK  the first D entries of a lane's traversal stack live in LDS (entry k of lane t at [k * threads + t]:
-//                        conflict-free 8-byte accesses) instead of scratch, whose loads - a pop is on the critical path - go
-//                        through the vector memory pipeline; deeper entries fall back to scratch.
+// LDS (north_star: "LDS-staged triangle/node tiles"):
+//   BHRAY_BVH_LDS_STACK  entries of the short traversal stack (entry k of lane t at [k * threads + t]: conflict-free 8-byte accesses);
+//                        see "The traversal stack" below.
+//   BHRAY_BVH_LDS_TOP    optional, off: the first N nodes of the breadth-first order copied into LDS once per block (measured in round
+//                        2: no gain, the top of the tree is L1/L2-resident anyway - profiles/EXPERIMENTS.md).
 #ifndef BHRAY_TRACE_THREADS
 #define BHRAY_TRACE_THREADS 256  // threads per persistent trace block (a multiple of 64; 64 / 128 / 512 measured slower: DESIGN.md §4)
 #endif
@@ -281,32 +273,42 @@ __device__ __forceinline__ bool hit_triangle(F3 pos, F3 dir, float t_min, float 
 #define BHRAY_BVH_LDS_TOP 0
 #endif
 #ifndef BHRAY_BVH_LDS_STACK
-#define BHRAY_BVH_LDS_STACK 0
+#define BHRAY_BVH_LDS_STACK 8      // entries of the short traversal stack in LDS (16 KB per 256-thread block: 8 blocks per CU fit in 160 KB)
+#endif
+#ifndef BHRAY_MODEL_INLINE
+#define BHRAY_MODEL_INLINE __noinline__      // the traversal as a call (measured against __forceinline__: profiles/EXPERIMENTS.md R3.6)
 #endif
 struct BvhLds { const float4* nodes; int node_count; int2* stack; };     // stack: this lane's column (entry k at stack[k * BHRAY_TRACE_THREADS])
 
+// The traversal stack.  The reference stacks 19 whole nodes and has no overflow check (ray.wgsl:292,327); round 2 kept 64 two-word entries
+// per lane in scratch - 512 bytes per lane, 42 MB of scratch writes per 1080p launch.  Now: a SHORT stack of BHRAY_BVH_LDS_STACK entries
+// in LDS (a ring: a push onto a full ring overwrites the oldest - shallowest - entry) plus a RESTART TRAIL: two 64-bit masks, one bit per
+// tree level - `pend` (the far child of the node visited at that level was pushed and has not been visited yet) and `wentfar` (the
+// current path took the far child at that level).  A pop that finds the ring empty while `pend` has a bit set re-descends from the
+// root along `wentfar` to the deepest pending level and takes its far child.  The re-descent repeats no DECISION: near / far order is a
+// function of the ray and the boxes alone, and whether a far child is visited was decided when it was pushed (with the closest hit of
+// that moment, as the reference decides it) and is recorded in `pend` - so the nodes are visited in the same order, with the same
+// pruning, and equal-t ties between triangles resolve as in the reference.  Node pairs re-read on the way down are not counted.
+// A tree deeper than 64 levels raises BHRAY_E_BVH_DEPTH (D2).
 template <bool COUNT>
-__device__ __noinline__ void trace_ray_model(const ModelDev& M, const BvhLds lds, F3 pos, F3 dir, float t_min, float t_max,
+__device__ BHRAY_MODEL_INLINE void trace_ray_model(const ModelDev& M, const BvhLds lds, F3 pos, F3 dir, float t_min, float t_max,
                                              Hit& closest, F3& normal_out, unsigned long long* cnt, int* err) {
+    static_assert(BHRAY_BVH_LDS_STACK >= 2 && BHRAY_BVH_STACK <= 64, "short stack / trail sizes");
+    constexpr int D = BHRAY_BVH_LDS_STACK;
     F3 mpos = ld3(M.pos);
     F3 inv = f3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
     closest.hit = false; closest.t = t_max; closest.color = f3(0, 0, 0); closest.opacity = 0.0f;
     normal_out = f3(0, 0, 0);
-    int contents = __float_as_int(M.nodes[0].w), obj_count = __float_as_int(M.nodes[1].w);     // nodes[0], untested root (ray.wgsl:291)
-    constexpr int LSTK = BHRAY_BVH_LDS_STACK;
-    int2 stack[BHRAY_BVH_STACK - LSTK];                          // entries beyond the LDS part
-    int sp = 0;
-    auto push = [&](int2 v) {
-        if (LSTK > 0 && sp < LSTK) lds.stack[sp * BHRAY_TRACE_THREADS] = v; else stack[sp - LSTK] = v;
-        sp++;
-    };
-    auto pop = [&]() -> int2 {
-        --sp;
-        if (LSTK > 0 && sp < LSTK) return lds.stack[sp * BHRAY_TRACE_THREADS];
-        return stack[sp - LSTK];
-    };
+    const int root_contents = __float_as_int(M.nodes[0].w), root_count = __float_as_int(M.nodes[1].w);     // nodes[0], untested root (ray.wgsl:291)
+    int contents = root_contents, obj_count = root_count;
+    unsigned long long pend = 0ull, wentfar = 0ull;
+    int lev = 0;                      // tree level of the decision the current node's children are (root's children: 0)
+    int sp = 0, held = 0;             // ring position; valid entries in the ring (<= D)
+    int target = -1;                  // >= 0: re-descending to take the pending far child of that level
     for (;;) {
+        bool pop = false;
         if (obj_count == 0) {
+            if (lev >= BHRAY_BVH_STACK) { *err = BHRAY_E_BVH_DEPTH; break; }
             float4 a_lo, a_hi, b_lo, b_hi;
             if (BHRAY_BVH_LDS_TOP > 0 && contents + 1 < lds.node_count) {
                 const float4* pair = lds.nodes + 2 * contents;
@@ -315,20 +317,35 @@ __device__ __noinline__ void trace_ray_model(const ModelDev& M, const BvhLds lds
                 const float4* pair = M.nodes + 2 * (size_t)contents;
                 a_lo = pair[0]; a_hi = pair[1]; b_lo = pair[2]; b_hi = pair[3];
             }
-            if (COUNT) cnt[6]++;
             float d1 = hit_aabb(pos, inv, a_lo, a_hi, mpos);
             float d2 = hit_aabb(pos, inv, b_lo, b_hi, mpos);
             int2 n1 = make_int2(__float_as_int(a_lo.w), __float_as_int(a_hi.w));
             int2 n2 = make_int2(__float_as_int(b_lo.w), __float_as_int(b_hi.w));
             if (d1 > d2) { float td = d1; d1 = d2; d2 = td; int2 tn = n1; n1 = n2; n2 = tn; }
+            const unsigned long long bit = 1ull << lev;
+            if (target >= 0) {                                      // re-descent: follow the recorded path, decide nothing
+                if (lev < target) {
+                    const int2 n = (wentfar & bit) ? n2 : n1;
+                    contents = n.x; obj_count = n.y; lev++;
+                } else {                                            // the pending far child itself
+                    pend &= ~bit; wentfar |= bit;
+                    contents = n2.x; obj_count = n2.y; lev++;
+                    target = -1;
+                }
+                continue;
+            }
+            if (COUNT) cnt[6]++;
             if (d1 > closest.t) {
-                if (sp == 0) break;
-                const int2 e = pop(); contents = e.x; obj_count = e.y;
+                pop = true;
             } else {
                 contents = n1.x; obj_count = n1.y;
-                if (d2 < closest.t) {
-                    if (sp < BHRAY_BVH_STACK) push(n2); else *err = BHRAY_E_BVH_DEPTH;
+                wentfar &= ~bit;
+                if (d2 < closest.t) {                               // the far child will be visited, whatever closest.t becomes (as in the reference)
+                    pend |= bit;
+                    lds.stack[(sp % D) * BHRAY_TRACE_THREADS] = n2;
+                    sp++; held = held < D ? held + 1 : D;
                 }
+                lev++;
             }
         } else {
             for (int i = 0; i < obj_count; i++) {
@@ -342,8 +359,20 @@ __device__ __noinline__ void trace_ray_model(const ModelDev& M, const BvhLds lds
                     if (t < closest.t) { closest.hit = true; closest.t = t; closest.color = col; closest.opacity = 1.0f; normal_out = nrm; }
                 }
             }
-            if (sp == 0) break;
-            const int2 e = pop(); contents = e.x; obj_count = e.y;
+            pop = true;
+        }
+        if (pop) {
+            if (pend == 0ull) break;
+            const int k = 63 - __builtin_clzll(pend);               // the deepest level with a pending far child: the top of the stack, if it is still there
+            if (held > 0) {
+                sp--; held--;
+                const int2 e = lds.stack[(sp % D) * BHRAY_TRACE_THREADS];
+                contents = e.x; obj_count = e.y;
+                pend &= ~(1ull << k); wentfar |= 1ull << k;
+                lev = k + 1;
+            } else {                                                // its entry was overwritten: find it again from the root
+                target = k; contents = root_contents; obj_count = root_count; lev = 0;
+            }
         }
     }
 }

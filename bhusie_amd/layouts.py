@@ -148,6 +148,7 @@ SYMBOLS = {
     "bhray_hdr_device_ptr": (C.c_int, [vp, P(vp), P(sz)]),
     "bhray_bind_output": (C.c_int, [vp, vp, sz]),
     "bhray_read_hdr_async": (C.c_int, [vp, vp, sz, P(C.c_uint64)]),
+    "bhray_read_sky_async": (C.c_int, [vp, vp, sz, P(C.c_uint64)]),
     "bhray_wait_read": (C.c_int, [vp, C.c_uint64]),
     "bhray_host_alloc": (C.c_int, [sz, P(vp)]),
     "bhray_host_free": (C.c_int, [vp]),

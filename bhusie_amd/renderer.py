@@ -163,6 +163,12 @@ class RayPass:
         check(lib().bhray_read_hdr_async(self._h, C.c_void_p(dst.ptr), int(self.cfg.frame_w) * 16, C.byref(t)), self._h)
         return int(t.value)
 
+    def read_sky_async(self, dst: "PinnedFrame") -> int:
+        """The RGBA16F image of the sky pass (resolve_sky first) into pinned memory (a PinnedFrame(rows, width, channels16=True))."""
+        t = C.c_uint64()
+        check(lib().bhray_read_sky_async(self._h, C.c_void_p(dst.ptr), int(self.cfg.frame_w) * 8, C.byref(t)), self._h)
+        return int(t.value)
+
     def wait_read(self, ticket: int):
         check(lib().bhray_wait_read(self._h, C.c_uint64(ticket)), self._h)
 
@@ -245,12 +251,15 @@ class RayPass:
 class PinnedFrame:
     """Pinned host memory for one RGBA32F frame (bhray_host_alloc), viewed as a (rows, width, 4) float32 array."""
 
-    def __init__(self, rows: int, width: int):
+    def __init__(self, rows: int, width: int, channels16: bool = False):
         p = C.c_void_p()
-        self.nbytes = rows * width * 16
+        self.nbytes = rows * width * (8 if channels16 else 16)
         check(lib().bhray_host_alloc(self.nbytes, C.byref(p)))
         self.ptr = p.value
-        self.array = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(rows, width, 4))
+        if channels16:          # RGBA16F (the sky pass's image)
+            self.array = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint16)), shape=(rows, width, 4)).view(np.float16)
+        else:
+            self.array = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(rows, width, 4))
 
     def free(self):
         p, self.ptr = self.ptr, None

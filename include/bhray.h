@@ -40,7 +40,7 @@ enum {
     BHRAY_E_HIP         = -3,  /* a HIP runtime call failed; see bhray_last_error            */
     BHRAY_E_NOMEM       = -4,
     BHRAY_E_STATE       = -5,  /* call order violated (e.g. render before set_uniforms)      */
-    BHRAY_E_BVH_DEPTH   = -6,  /* BVH deeper than BHRAY_BVH_STACK                            */
+    BHRAY_E_BVH_DEPTH   = -6,  /* BVH deeper than BHRAY_BVH_STACK levels                     */
     BHRAY_E_IO          = -7,  /* file could not be read / parsed (OBJ loader)               */
     BHRAY_E_CAPACITY    = -8,  /* model exceeds the reference's fixed capacities             */
     BHRAY_E_COMM        = -9   /* RCCL could not be loaded / a collective call failed        */
@@ -141,7 +141,7 @@ typedef struct bhray_model_desc {
 #define BHRAY_MAX_FRAMES_IN_FLIGHT 32
 #define BHRAY_MAX_SPEC_LEVELS 4
 #define BHRAY_MAX_FRAMES_PER_BATCH 32
-#define BHRAY_BVH_STACK  64            /* reference: 19 whole nodes, no overflow check (ray.wgsl:292) */
+#define BHRAY_BVH_STACK  64            /* tree levels the traversal's restart trail covers (reference: a stack of 19 whole nodes, no overflow check, ray.wgsl:292) */
 #define BHRAY_MAX_DEVICES 16           /* GPUs one ctx can drive (one node: 8 MI355X)                 */
 #define BHRAY_COMM_ID_BYTES 128        /* an RCCL ncclUniqueId                                         */
 
@@ -356,6 +356,9 @@ int bhray_bind_output(bhray_ctx* ctx, void* dev_ptr, size_t bytes);
  *     1920x1080 RGBA32F (33.2 MB): 0.62 ms per frame with 4 frame slots = the link rate (55.7 GB/s), against 0.40 without the hand-off
  *     and 2.8 ms for bhray_read_hdr after every render. */
 int bhray_read_hdr_async(bhray_ctx* ctx, float* dst_rgba32f, size_t row_pitch_bytes, uint64_t* ticket);
+/* The same for the RGBA16F image of the sky pass (bhray_resolve_sky first): half the bytes - for a host that lets the library run the
+ * sky pass too and uploads into the texture its SkyPipeline would have written (sky_pipeline.rs:17-148).  Tickets are shared.      */
+int bhray_read_sky_async(bhray_ctx* ctx, uint16_t* dst_rgba16f, size_t row_pitch_bytes, uint64_t* ticket);
 int bhray_wait_read(bhray_ctx* ctx, uint64_t ticket);
 int bhray_host_alloc(size_t bytes, void** out);               /* pinned host memory (hipHostMalloc) for hosts that do not link HIP */
 int bhray_host_free(void* p);

@@ -88,6 +88,35 @@ def test_async_read_more_tickets_than_the_ring_and_a_padded_pitch():
     buf.free(); rp.close()
 
 
+def test_async_read_of_the_sky_pass_image():
+    """RGBA16F hand-off (half the bytes): render, resolve the sky, enqueue the copy, go on rendering; single ctx and gathered frame."""
+    tex = T.textures()
+    frames = _frames()
+    cfg = B.ladder_for_frame((200, 110), 3, 3)
+    want = []
+    for u in frames:
+        rp = B.RayPass(cfg, device=0); rp.set_textures(*tex); rp.set_uniforms(*u); rp.render(); rp.resolve_sky(); want.append(rp.read_sky()); rp.close()
+    for kw in (dict(device=0, frames_in_flight=2), dict(devices=[0, 0], stripe_rows=9, frames_in_flight=1)):
+        rp = B.RayPass(cfg, **kw)
+        rp.set_textures(*tex)
+        bufs = [B.PinnedFrame(110, 200, channels16=True) for _ in range(5)]
+        tk = []
+        for i in range(5):
+            rp.set_uniforms(*frames[i % 3]); rp.render(); rp.resolve_sky()
+            tk.append(rp.read_sky_async(bufs[i]))
+        for t in tk:
+            rp.wait_read(t)
+        for i in range(5):
+            assert np.array_equal(bufs[i].array.view(np.uint16), want[i % 3].view(np.uint16)), f"{kw}: frame {i}"
+        for b in bufs:
+            b.free()
+        rp.close()
+    rp = B.RayPass(cfg, device=0); rp.set_textures(*tex); rp.set_uniforms(*frames[0]); rp.render()
+    with pytest.raises(B.BhrayError):
+        rp.read_sky_async(B.PinnedFrame(110, 200, channels16=True))       # the sky pass has not run for this frame
+    rp.close()
+
+
 def test_async_read_of_a_gathered_frame():
     """Multi-partition ctx: the copy reads the ASSEMBLED frame on the root, behind the gather and the de-interleave; the root's next
     render into the same slot (its own rows go straight into that frame) waits for it."""
