@@ -1413,7 +1413,8 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                     base = (blockIdx.x * (BHRAY_TRACE_THREADS / 64) + (threadIdx.x >> 6)) * thin_share;
                     exhausted = true;
                 } else {
-                    if (lane == (int)__builtin_ctzll(need)) base = atomicAdd(qhead, n);
+                    // (the lane id recomputed here - two instructions - instead of held in a VGPR across the step loop: the dense build has none to spare)
+                    if ((int)lanes_below(~0ull) == (int)__builtin_ctzll(need)) base = atomicAdd(qhead, n);
                     base = (uint32_t)__shfl((int)base, (int)__builtin_ctzll(need));
                     if (base + n >= qcount) exhausted = true;
                 }
@@ -1629,7 +1630,10 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                         }
                     }
                     float ths = t_max;
-                    const bool hs = hit_sphere(ppos, pdir, H.R, bpos, t_min, t_max, ths);
+                    // (the radius through an opaque copy: R*R is loop-invariant, and hoisted out of the frame loop it costs the dense build a
+                    // VGPR it does not have - it was the kernel's one spill, 8 bytes of scratch per lane)
+                    float Rflat = H.R; asm volatile("" : "+v"(Rflat));
+                    const bool hs = hit_sphere(ppos, pdir, Rflat, bpos, t_min, t_max, ths);
                     if (!hs && !rs.hit) {
                         mode = M_FINISH;                                   // break (no increment)
                     } else {
