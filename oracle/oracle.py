@@ -87,6 +87,8 @@ def lib():
         L.oracle_get_eval.restype = C.c_int
         L.oracle_render_aux.restype = C.c_int
         L.oracle_render_aux.argtypes = [C.POINTER(_Scene), C.c_int, C.c_int, C.c_void_p]
+        L.oracle_classify_level.restype = C.c_int
+        L.oracle_classify_level.argtypes = [C.POINTER(_Scene), C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.oracle_num_threads.restype = C.c_int
         L.oracle_set_threads.argtypes = [C.c_int]
         _lib = L
@@ -269,5 +271,16 @@ def render_aux(scene: OracleScene, size) -> np.ndarray:
     s, keep = scene._pack()
     out = np.zeros((h, w, 4), dtype=np.float32)
     assert lib().oracle_render_aux(C.byref(s), w, h, out.ctypes.data) == 0
+    del keep
+    return out
+
+
+def classify_level(scene: OracleScene, size, prev: np.ndarray) -> np.ndarray:
+    """The grid decision alone for every pixel of a (W, H) level: 0 copy, 1 interpolate, 2 trace (diagnostics)."""
+    w, h = size
+    s, keep = scene._pack()
+    prev = np.ascontiguousarray(prev, dtype=np.float32)
+    out = np.zeros((h, w), dtype=np.uint8)
+    assert lib().oracle_classify_level(C.byref(s), w, h, prev.ctypes.data, prev.shape[1], prev.shape[0], out.ctypes.data) == 0
     del keep
     return out

@@ -960,6 +960,34 @@ int oracle_render_aux(const oracle_scene* os, int sw, int sh, float* aux) {
     return 0;
 }
 
+/* Diagnostics: the grid decision of ray.wgsl:167-243 alone, for every pixel of a level - 0 copy, 1 interpolate, 2 trace - without
+ * tracing anything (the parity analysis and the queue-order simulation of profiles/queue_order_sim.py want to know WHICH pixels a
+ * level traces). */
+int oracle_classify_level(const oracle_scene* os, int sw, int sh, const float* prev, int pw, int ph, uint8_t* kind) {
+    if (!os || !kind || !prev || sw < 1 || sh < 1 || pw < 2 || ph < 2) return -1;
+    const float thr = os->details->angle_division_threshold;
+    const int sfx = (sw - 1) / (pw - 1), sfy = (sh - 1) / (ph - 1);
+    const float rx = (float)pw / (float)(sw + (sfx - 1)), ry = (float)ph / (float)(sh + (sfy - 1));
+#pragma omp parallel for schedule(static)
+    for (int py = 0; py < sh; py++) {
+        for (int px = 0; px < sw; px++) {
+            const float ppx = (float)px * rx, ppy = (float)py * ry;
+            const float tlx = floorf(ppx), tly = floorf(ppy);
+            uint8_t k = 2;
+            if (fabsf(tlx - ppx) < 0.001f && fabsf(tly - ppy) < 0.001f) k = 0;
+            else {
+                v4 c_tl = load4(prev, pw, ph, (int)tlx, (int)tly), c_bl = load4(prev, pw, ph, (int)tlx, (int)(tly + 1.0f));
+                v4 c_tr = load4(prev, pw, ph, (int)(tlx + 1.0f), (int)tly), c_br = load4(prev, pw, ph, (int)(tlx + 1.0f), (int)(tly + 1.0f));
+                const int alphas0 = c_tl.w == 0.0f && c_tr.w == 0.0f && c_bl.w == 0.0f && c_br.w == 0.0f;
+                if (alphas0 && angle_between(xyz(c_bl), xyz(c_tl)) < thr && angle_between(xyz(c_br), xyz(c_tr)) < thr &&
+                    angle_between(xyz(c_tl), xyz(c_tr)) < thr && angle_between(xyz(c_bl), xyz(c_br)) < thr) k = 1;
+            }
+            kind[(size_t)py * (size_t)sw + (size_t)px] = k;
+        }
+    }
+    return 0;
+}
+
 /* Per-function probes for known-answer tests and cross-checks (tests/ only). */
 void oracle_create_ray(const oracle_scene* os, int px, int py, int sw, int sh, float out6[6]) {
     scene S; memset(&S, 0, sizeof S); S.camera = os->camera; S.details = os->details; S.bh = os->bh;
