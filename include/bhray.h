@@ -158,13 +158,15 @@ enum {                                  /* bhray_config.flags */
                                            border pixels: DESIGN.md §4), +8 % rays; 1080p, one frame at a time: 0.78 ms with a static
                                            camera, 0.84-0.87 ms with a moving one, 1.20 ms without the flag.  levels <= 4, no
                                            speculative / superset levels.                                                    */
-    BHRAY_F_FUSED      = 1u << 6,       /* fused ladder: ONE persistent launch per batch runs every level.  The grid classification
-                                           (ray.wgsl:167-243) becomes work items of 8x8-pixel tiles inside the trace kernel; a tile of
-                                           level l+1 is classified as soon as the level-l tiles it reads are final (classified and all
-                                           their rays stored), so a level's tail - its few longest rays - overlaps the next level's head
-                                           instead of idling the device until the next launch.  Same pixels.  For latency-bound uses:
-                                           one frame at a time, small per-GPU row tiles, short bursts.  levels <= 4; combines with
-                                           speculative_levels and frames_per_batch; not with superset levels or BHRAY_F_TEMPORAL.      */
+    BHRAY_F_FUSED      = 1u << 6,       /* fused ladder (an OPTION, off by default): ONE persistent launch per batch runs every level.
+                                           The grid classification (ray.wgsl:167-243) becomes work items of 8x8-pixel tiles inside the
+                                           trace kernel; a tile of level l+1 is classified as soon as the level-l tiles it reads are
+                                           final (classified and all their rays stored), so a level's tail overlaps the next level's
+                                           head.  Same pixels (tests/test_gpu_fused.py).  MEASURED SLOWER than the launch-per-level
+                                           ladder on MI355X - 2.1 against 1.2 ms for one 1080p frame at a time: 43 000 tile hand-offs
+                                           through the memory system cost more than the launch boundaries they replace (DESIGN.md §4.6,
+                                           profiles/EXPERIMENTS.md R3.1).  levels <= 4; combines with speculative_levels and
+                                           frames_per_batch; not with superset levels or BHRAY_F_TEMPORAL.                          */
     BHRAY_F_EVAL_FMA   = 1u << 5,       /* a THIRD evaluation of the integrator: the shader text with fused multiply-add contraction only
                                            (every `x*y + z` of ray.wgsl:401-480 one fma), none of the contract's reassociations (N9/N10).
                                            Like BHRAY_F_LITERAL it exists for measurement: the pixels on which it differs from the literal
