@@ -4,7 +4,8 @@ TEST INFRASTRUCTURE ONLY.  Written directly from /root/reference/src/renderer/sh
 (line references below), not from oracle/ray_oracle.c, as a vectorised masked state machine over
 all pixels of a level.  Its jobs: (1) cross-check the C oracle (tests/test_oracle_cross.py requires
 bit-identical direction pixels and classes), (2) generate the committed fixtures under tests/golden/
-(tests/golden/make_golden.py).  PARITY UNPINNED by the reference itself (no tests, cannot be built).
+(tests/golden/make_golden.py).  Pinned to the reference's shader TEXT (oracle/wgsl_exec.py executes ray.wgsl; this module's literal
+mode reproduces its classes and direction pixels bit for bit: tests/test_wgsl_pin.py), not to a driver run (no tests, cannot be built).
 
 All arithmetic is numpy.float32 array arithmetic: every operator is one IEEE binary32 operation (no
 fused multiply-add, no wider intermediates).  The numerics contract N1..N6 of DESIGN.md applies:

@@ -1,8 +1,8 @@
 """ctypes front-end of the CPU oracle (oracle/ray_oracle.c).  TEST INFRASTRUCTURE ONLY.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
-product package (bhusie_amd) never does.  PARITY UNPINNED by the reference (it has no tests and
-cannot be built here) — see the header of ray_oracle.c for what pins this restatement instead.
+product package (bhusie_amd) never does.  Pinned to the reference's shader text as executed by oracle/wgsl_exec.py
+(tests/test_wgsl_pin.py), not to a driver run (the reference has no tests and cannot be built here) — see the header of ray_oracle.c.
 
 The ladder driver below restates src/renderer/mod.rs:170-207 (level sizes r <- 3r-2, each level
 reads the previous one, level 0 reads a 1x1 base texture) on top of the per-level entry point.

@@ -6,11 +6,12 @@
  * src/renderer/texture.rs:16-69 (RGBA8 unorm, bilinear, clamp-to-edge, one mip, no sRGB) and
  * the dispatch of src/renderer/pipelines/ray_pipeline.rs:301-309 (one invocation per pixel).
  *
- * PARITY UNPINNED: the reference has no tests, golden vectors or benchmarks
- * and cannot be built here (Rust + WGSL, no toolchain, missing assets: F1/F2).  This file is
- * pinned instead by (1) an independently written NumPy restatement (oracle/np_ray.py) that
- * must agree with it, (2) analytic known-answer tests (tests/test_oracle_kat.py), (3) the
- * committed fixtures under tests/golden/.
+ * PINNED TO THE REFERENCE'S SHADER TEXT, not to a driver run: the reference has no tests, golden vectors or benchmarks
+ *  and cannot be built or run here (Rust + WGSL, no toolchain, missing assets: F1/F2), but its shader text is
+ * EXECUTED by oracle/wgsl_exec.py (an interpreter; nothing restated) and this file's literal mode reproduces those frames
+ * word for word (tests/golden/wgsl_exec.npz, tests/test_wgsl_pin.py).  Also pinned by (1) an independently written NumPy
+ * restatement (oracle/np_ray.py) that must agree with it, (2) analytic known-answer tests (tests/test_oracle_kat.py),
+ * (3) the committed fixtures under tests/golden/.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  * The product (libbhray) never links, loads or calls it.

@@ -5,8 +5,10 @@ in the integrator: N3/N7/N9/N10 — evaluations WGSL permits).  Every other -m g
 SAME contract.  This file pins the distance to the shader text itself, three ways:
 
  1. BHRAY_F_LITERAL — a trace-kernel variant whose integrator is the shader text operator by operator — must reproduce, bit for
-    bit on every direction pixel, (a) the frozen literal fixtures tests/golden/frames_literal.npz (written from the WGSL by the
-    NumPy restatement, never regenerated when the contract changes) and (b) the C oracle's literal mode at full frame size.
+    bit on every direction pixel, (a) tests/golden/wgsl_exec.npz: frames written by EXECUTING the reference's own ray.wgsl
+    (oracle/wgsl_exec.py, an interpreter of the shader text), (b) the frozen literal fixtures tests/golden/frames_literal.npz (written
+    from the WGSL by the NumPy restatement, never regenerated when the contract changes) and (c) the C oracle's literal mode at full
+    frame size.
  2. The DEFAULT kernels against the literal oracle at the bench frame (1920x1080, both integrators): identical pixel classes, a
     bounded median, and >= 99.7 % of the pixels inside the 1e-4 bar of BASELINE.json's north_star.  The remainder are the chaotic
     rays (photon sphere, disk edge) on which any two conforming evaluations disagree; their maximum is recorded, not bounded.
@@ -77,6 +79,32 @@ def test_literal_kernel_reproduces_the_frozen_literal_fixtures(name):
     if name in ("rk_l0", "euler_l0"):
         dflt = _gpu(cfg, u, tex).read_hdr()
         assert not np.array_equal(dflt, rp.read_hdr())
+
+
+WGSL_CASES = ["euler_l0", "rk_l0", "rk_ladder", "euler_ladder", "rk_outside", "rk_off_origin", "rk_highlight", "euler_tight", "rk_mesh", "euler_mesh", "rk_mesh_near", "euler_mesh_near"]
+
+
+@pytest.mark.parametrize("name", WGSL_CASES)
+def test_literal_kernel_reproduces_frames_made_by_executing_the_shader_text(name, tmp_path):
+    """tests/golden/wgsl_exec.npz: frames written by running the reference's own ray.wgsl through oracle/wgsl_exec.py (an interpreter;
+    nothing restated).  The literal kernel: same classes, direction pixels bit for bit, colours within the device-pow tolerance."""
+    g = np.load(os.path.join(GOLD, "wgsl_exec.npz"))
+    tex = (g["t_temp"], g["t_disk"], g["t_sky"])
+    u = (g[f"{name}.camera"].tobytes(), g[f"{name}.black_hole"].tobytes(), g[f"{name}.details"].tobytes())
+    sizes = [tuple(int(v) for v in s) for s in g[f"{name}.sizes"]]
+    cfg = B.ladder_from_base(sizes[0], 3, len(sizes))
+    assert cfg.sizes() == sizes
+    rp = B.RayPass(cfg, device=0, literal=True)
+    rp.set_textures(*tex)
+    if int(g[f"{name}.mesh"][0]):
+        p = tmp_path / "m.obj"; p.write_bytes(g["mesh.obj"].tobytes())
+        rp.upload_model(B.load_model(str(p)))
+    rp.set_uniforms(*u)
+    rp.render()
+    n = 0
+    for l in range(len(sizes)):
+        n += _same_to_the_bit_where_specified(rp.read_level(l), g[f"{name}.level{l}"], f"executed shader, {name} level {l}")
+    assert n > 0 or name.endswith("mesh") or name == "euler_tight"
 
 
 @pytest.mark.parametrize("method", [1, 0])

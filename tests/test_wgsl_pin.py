@@ -1,0 +1,142 @@
+"""CPU: the restatements against frames made by EXECUTING the reference's own shader text.
+
+tests/golden/wgsl_exec.npz was written by tests/golden/make_golden_wgsl.py, which parses /root/reference/src/renderer/shaders/ray.wgsl
+and runs it (oracle/wgsl_exec.py: a WGSL-subset interpreter; nothing of the shader is restated in it).  The fixtures are data only -
+uniform bytes, small synthetic textures / mesh arrays, frames.  What WGSL leaves to the implementation is fixed as the LITERAL evaluation
+fixes it, so:
+
+  * the C oracle in literal mode (oracle_set_eval(1)) must reproduce EVERY WORD of every frame - directions, colours, classes, mesh
+    shading, interpolated pixels, ladder levels;
+  * the NumPy restatement in literal mode must reproduce classes and direction pixels bit for bit (its float32 pow(., 1.3) is numpy's
+    vectorised one, an ulp away from glibc's on ~20 % of arguments, so colours are held to 1e-6);
+  * where the reference is present (this container, not the GPU box) a slice of one frame is re-executed from the shader text and must
+    equal the committed fixture - the fixture is what the generator says it is.
+
+tests/test_gpu_literal.py holds the BHRAY_F_LITERAL kernel to the same file.  The contract kernels (the shipped default) are tied to the
+literal evaluation by the population bounds of tests/test_gpu_literal.py, and the contract oracle to the contract kernels bit for bit.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import host_oracle as H
+from oracle import np_ray as N
+from oracle import oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ["euler_l0", "rk_l0", "rk_ladder", "euler_ladder", "rk_outside", "rk_off_origin", "rk_highlight", "euler_tight", "rk_mesh", "euler_mesh", "rk_mesh_near", "euler_mesh_near"]
+
+
+@pytest.fixture(scope="module")
+def g():
+    return np.load(os.path.join(GOLD, "wgsl_exec.npz"))
+
+
+def scene_of(g, name, structured_nodes=False):
+    tex = (g["t_temp"], g["t_disk"], g["t_sky"])
+    u = tuple(g[f"{name}.{k}"].tobytes() for k in ("camera", "black_hole", "details"))
+    sizes = [tuple(int(v) for v in s) for s in g[f"{name}.sizes"]]
+    models = []
+    if int(g[f"{name}.mesh"][0]):
+        nodes = g["mesh.nodes"].view(H.NODE_DTYPE) if structured_nodes else g["mesh.nodes"]
+        models = [dict(position=tuple(float(v) for v in g["mesh.position"]), visible=1, points=g["mesh.points"], normals=g["mesh.normals"],
+                       triangles=g["mesh.triangles"], nodes=nodes, bvh_lookup=g["mesh.bvh_lookup"])]
+    return u, tex, sizes, models
+
+
+def test_fixture_covers_every_path_of_the_shader(g):
+    """Traced rays of every fate, interpolated and copied pixels, disk and sky colours, mesh shading."""
+    seen_mesh = False
+    for name in CASES:
+        sizes = g[f"{name}.sizes"]
+        for l in range(len(sizes)):
+            im = g[f"{name}.level{l}"]
+            assert im.shape == (int(sizes[l][1]), int(sizes[l][0]), 4) and im.dtype == np.float32
+            assert set(np.unique(im[..., 3][~np.isnan(im[..., 3])])) <= {0.0, 1.0}
+        seen_mesh |= bool(g[f"{name}.mesh"][0])
+    top = g["rk_ladder.level2"]
+    assert (top[..., 3] == 0).any() and (top[..., 3] == 1).any()
+    assert seen_mesh
+    # mesh shading is IN the frames: the near-mesh scene without its model is a different picture
+    u, tex, sizes, models = scene_of(g, "rk_mesh_near")
+    det0 = H.ray_details(integration_method=1, model_count=0)
+    O.set_eval(O.EVAL_LITERAL)
+    try:
+        bare = O.render_ladder(O.OracleScene(u[0], u[1], det0, *tex), sizes)[0]
+    finally:
+        O.set_eval(O.EVAL_CONTRACT)
+    assert int((bare != g["rk_mesh_near.level0"]).any(axis=-1).sum()) >= 40
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_c_oracle_literal_mode_equals_the_executed_shader_word_for_word(g, name):
+    u, tex, sizes, models = scene_of(g, name)
+    O.set_eval(O.EVAL_LITERAL)
+    try:
+        imgs = O.render_ladder(O.OracleScene(*u, *tex, models=models), sizes)
+    finally:
+        O.set_eval(O.EVAL_CONTRACT)
+    for l, im in enumerate(imgs):
+        want = g[f"{name}.level{l}"]
+        bad = im.view(np.uint32) != want.view(np.uint32)
+        both_nan = np.isnan(im) & np.isnan(want)                 # NaN payloads are not specified; NaN in the same place is
+        assert not (bad & ~both_nan).any(), f"{name} level {l}: {int((bad & ~both_nan).sum())} words differ, first at {np.argwhere(bad & ~both_nan)[:4].tolist()}"
+
+
+@pytest.mark.parametrize("name", ["euler_l0", "rk_l0", "rk_ladder", "rk_off_origin", "euler_mesh", "rk_mesh_near"])
+def test_numpy_literal_mode_equals_the_executed_shader(g, name):
+    u, tex, sizes, models = scene_of(g, name, structured_nodes=True)
+    N.set_literal(True)
+    try:
+        imgs = N.render_ladder(N.Scene(*u, *tex, models=models), sizes, {})
+    finally:
+        N.set_literal(False)
+    for l, im in enumerate(imgs):
+        want = g[f"{name}.level{l}"]
+        ok = ~np.isnan(want).any(axis=-1)
+        assert np.array_equal(np.isnan(im).any(axis=-1), ~ok)
+        assert np.array_equal(im[..., 3][ok], want[..., 3][ok]), f"{name} level {l}: classes"
+        d = ok & (want[..., 3] == 0)
+        assert np.array_equal(im[d].view(np.uint32), want[d].view(np.uint32)), f"{name} level {l}: direction pixels"
+        e = np.abs(im[ok] - want[ok]) / np.maximum(np.abs(want[ok]), 1e-3)
+        assert float(e.max(initial=0.0)) <= 1e-6, f"{name} level {l}: colours {float(e.max())}"
+
+
+def test_the_contract_oracle_is_not_this_evaluation_but_close(g):
+    """The shipped contract (FMA + reassociation in the integrator) differs from the text in the last bits only."""
+    u, tex, sizes, models = scene_of(g, "rk_l0")
+    im = O.render_ladder(O.OracleScene(*u, *tex), sizes)[0]
+    want = g["rk_l0.level0"]
+    assert not np.array_equal(im.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(im[..., 3], want[..., 3])
+    d = want[..., 3] == 0
+    err = np.linalg.norm(im[d][:, :3] - want[d][:, :3], axis=-1)
+    assert float(np.median(err)) < 2e-6
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/renderer/shaders/ray.wgsl"), reason="the reference's shader is not on this machine")
+def test_fixture_is_what_executing_the_shader_text_gives():
+    from oracle import wgsl_exec as W
+    g = np.load(os.path.join(GOLD, "wgsl_exec.npz"))
+    ns = W.compile_shader()
+    for name, level, rows in (("rk_l0", 0, (20, 21)), ("euler_ladder", 1, (17, 19)), ("euler_mesh_near", 1, (9, 10))):
+        u, tex, sizes, models = scene_of(g, name)
+        W.bind_scene(ns, *u, *tex, models)
+        prev = g[f"{name}.level{level - 1}"] if level else None
+        got = W.render_level(ns, sizes[level], prev, rows)[rows[0]:rows[1]]
+        want = g[f"{name}.level{level}"][rows[0]:rows[1]]
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), name
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/renderer/shaders/ray.wgsl"), reason="the reference's shader is not on this machine")
+def test_executor_parses_the_whole_shader_and_nothing_is_left_out():
+    from oracle import wgsl_exec as W
+    src = open(W.SHADER).read()
+    decls = W.Parser(W.tokenize(src)).module()
+    fns = [d[1] for d in decls if d[0] == "fn"]
+    assert src.count("\nfn ") + src.startswith("fn ") == len(fns) and "main" in fns and "trace_ray" in fns and "next_ray_rk" in fns
+    ns = W.compile_shader()
+    assert all(("fn_" + f) in ns for f in fns)
+    # AbstractFloat constants stay binary64 until they meet an f32 (b_1 - b_a_1 is one rounding, not three)
+    assert isinstance(ns["C_b_1"], float) and ns["C_b_1"] == 37.0 / 378.0 and isinstance(ns["C_PI"], np.float32)
