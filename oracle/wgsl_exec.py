@@ -1,7 +1,7 @@
 """wgsl_exec.py - executes the REFERENCE'S OWN shader text.  TEST INFRASTRUCTURE ONLY; runs only where /root/reference exists.
 
 Every other oracle in this directory is a restatement written by reading ray.wgsl.  This module instead READS
-/root/reference/src/renderer/shaders/ray.wgsl at run time, parses it (a recursive-descent parser for the WGSL subset the file
+/root/reference/src/renderer/shaders/ray.wgsl (and sky.wgsl, the resolve pass behind it) at run time, parses it (a recursive-descent parser for the WGSL subset the file
 uses), translates every function into Python and runs it - one invocation of `main` per pixel, as
 RayPipeline::pass dispatches it (src/renderer/pipelines/ray_pipeline.rs:301-309).  Nothing of the shader is restated here: if a
 line of the shader changed, the frames this module produces would change with it.  What IS defined here is what WGSL leaves to the
@@ -834,21 +834,21 @@ class Gen:
         return "\n".join(self.lines)
 
 
-_COMPILED = None
+SKY_SHADER = "/root/reference/src/renderer/shaders/sky.wgsl"
+_COMPILED = {}
 
 
 def compile_shader(path=SHADER):
-    """Parses the reference's shader and returns the namespace holding its translated functions (fn_main, fn_trace_ray, ...)."""
-    global _COMPILED
-    if _COMPILED is not None:
-        return _COMPILED
+    """Parses one of the reference's shaders and returns the namespace holding its translated functions (fn_main, fn_trace_ray, ...)."""
+    if path in _COMPILED:
+        return _COMPILED[path]
     src = open(path).read()
     decls = Parser(tokenize(src)).module()
     code = Gen(decls).module()
     ns = {k: v for k, v in globals().items() if not k.startswith("__")}
     exec(compile(code, "<ray.wgsl>", "exec"), ns)
     ns["__source__"] = code
-    _COMPILED = ns
+    _COMPILED[path] = ns
     return ns
 
 
@@ -910,6 +910,28 @@ def render_level(ns, size, prev=None, rows=None):
     for (x, y), v in target.out.items():
         out[y, x] = v
     return out
+
+
+def render_sky(prev, t_sky):
+    """The sky resolve pass: sky.wgsl's `main` for every pixel of the last ladder level (sky_pipeline.rs dispatches it like the ray pass).
+    The target is rgba16float (sky.wgsl:1): the stored f32 values are converted with round-to-nearest-even (numpy's cast) - returns
+    (H, W, 4) float16."""
+    ns = compile_shader(SKY_SHADER)
+    prev = np.ascontiguousarray(prev, dtype=np.float32)
+    h, w = prev.shape[:2]
+    target = StoreTarget(w, h)
+    ns["G_color_buffer"] = target
+    ns["G_t_prev"] = Texture(f32img=prev)
+    ns["G_t_sky"] = Texture(rgba8=t_sky); ns["G_s_sky"] = None
+    with np.errstate(all="ignore"):
+        for y in range(h):
+            for x in range(w):
+                ns["fn_main"](Vec((x, y, 0)))
+    out = np.zeros((h, w, 4), dtype=np.float32)
+    for (x, y), v in target.out.items():
+        out[y, x] = v
+    with np.errstate(over="ignore"):
+        return out.astype(np.float16)
 
 
 def _rows_job(job):

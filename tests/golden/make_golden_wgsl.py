@@ -42,7 +42,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--processes", type=int, default=os.cpu_count() or 8)
     ap.add_argument("--only", default="")
+    ap.add_argument("--sky-only", action="store_true", help="add the sky.wgsl frames to an existing file from its stored last levels")
     args = ap.parse_args()
+    if args.sky_only:
+        dst = os.path.join(HERE, "wgsl_exec.npz")
+        g = dict(np.load(dst))
+        for name in ("rk_ladder", "rk_outside", "euler_mesh_near"):
+            last = len(g[f"{name}.sizes"]) - 1
+            g[f"{name}.sky"] = W.render_sky(g[f"{name}.level{last}"], g["t_sky"]).view(np.uint16)
+            print(name, "sky", g[f"{name}.sky"].shape, flush=True)
+        np.savez_compressed(dst, **g)
+        return
     W.compile_shader()                                        # parse once, before the pool forks
     tex = (assets.temp_lut(32), assets.disk_texture(96, seed=11), assets.sky_texture(128, 64, seed=12))
     out = dict(t_temp=tex[0], t_disk=tex[1], t_sky=tex[2])
@@ -83,6 +93,8 @@ def main():
         for l, im in enumerate(imgs):
             assert not np.isnan(im[..., 3]).any(), "a pixel was not stored"
             out[f"{name}.level{l}"] = im
+        if name in ("rk_ladder", "rk_outside", "euler_mesh_near"):          # sky.wgsl executed over the last level (rgba16float)
+            out[f"{name}.sky"] = W.render_sky(imgs[-1], tex[2]).view(np.uint16)
         print(f"{name}: {sizes} {time.time() - t0:.0f} s", flush=True)
     dst = os.path.join(HERE, "wgsl_exec.npz")
     if args.only and os.path.exists(dst):

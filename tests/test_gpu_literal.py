@@ -105,6 +105,12 @@ def test_literal_kernel_reproduces_frames_made_by_executing_the_shader_text(name
     for l in range(len(sizes)):
         n += _same_to_the_bit_where_specified(rp.read_level(l), g[f"{name}.level{l}"], f"executed shader, {name} level {l}")
     assert n > 0 or name.endswith("mesh") or name == "euler_tight"
+    if f"{name}.sky" in g.files:         # sky.wgsl executed by the same interpreter over the executed frame: the resolve kernel on the literal frame
+        rp.resolve_sky()
+        sky, want = rp.read_sky().view(np.uint16), g[f"{name}.sky"]
+        direction = g[f"{name}.level{len(sizes) - 1}"][..., 3] == 0
+        assert direction.sum() > 100 and np.array_equal(sky[direction], want[direction]), f"{name}: resolved direction pixels"
+        assert ((sky == want).all(axis=-1)).mean() > 0.99           # colour pixels pass through: device pow(., 1.3) is 1-2 f32 ulp from glibc's, usually the same binary16
 
 
 @pytest.mark.parametrize("method", [1, 0])

@@ -103,6 +103,17 @@ def test_numpy_literal_mode_equals_the_executed_shader(g, name):
         assert float(e.max(initial=0.0)) <= 1e-6, f"{name} level {l}: colours {float(e.max())}"
 
 
+@pytest.mark.parametrize("name", ["rk_ladder", "rk_outside", "euler_mesh_near"])
+def test_sky_pass_restatements_equal_the_executed_sky_shader(g, name):
+    """sky.wgsl run by the same interpreter over the executed ray frames: rgba16float, every half-word."""
+    last = len(g[f"{name}.sizes"]) - 1
+    prev, want = g[f"{name}.level{last}"], g[f"{name}.sky"]
+    assert want.dtype == np.uint16 and want.shape == prev.shape
+    assert np.array_equal(O.sky_resolve(prev, g["t_sky"]).view(np.uint16), want)
+    assert np.array_equal(N.sky_resolve(prev, g["t_sky"]).view(np.uint16), want)
+    assert (prev[..., 3] == 0).sum() > 100 and np.all(want.view(np.float16)[..., 3] == 1.0)
+
+
 def test_the_contract_oracle_is_not_this_evaluation_but_close(g):
     """The shipped contract (FMA + reassociation in the integrator) differs from the text in the last bits only."""
     u, tex, sizes, models = scene_of(g, "rk_l0")
@@ -127,6 +138,8 @@ def test_fixture_is_what_executing_the_shader_text_gives():
         got = W.render_level(ns, sizes[level], prev, rows)[rows[0]:rows[1]]
         want = g[f"{name}.level{level}"][rows[0]:rows[1]]
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), name
+    sky = W.render_sky(g["euler_mesh_near.level1"], g["t_sky"])
+    assert np.array_equal(sky.view(np.uint16), g["euler_mesh_near.sky"])
 
 
 @pytest.mark.skipif(not os.path.exists("/root/reference/src/renderer/shaders/ray.wgsl"), reason="the reference's shader is not on this machine")
