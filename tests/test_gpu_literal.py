@@ -81,7 +81,7 @@ def test_literal_kernel_reproduces_the_frozen_literal_fixtures(name):
         assert not np.array_equal(dflt, rp.read_hdr())
 
 
-WGSL_CASES = ["euler_l0", "rk_l0", "rk_ladder", "euler_ladder", "rk_outside", "rk_off_origin", "rk_highlight", "euler_tight", "rk_mesh", "euler_mesh", "rk_mesh_near", "euler_mesh_near"]
+WGSL_CASES = ["euler_l0", "rk_l0", "rk_ladder", "euler_ladder", "rk_outside", "rk_off_origin", "rk_highlight", "euler_tight", "rk_mesh", "euler_mesh", "rk_mesh_near", "euler_mesh_near"] + [f"fuzz{k:02d}" for k in range(24)]
 
 
 @pytest.mark.parametrize("name", WGSL_CASES)
@@ -104,7 +104,7 @@ def test_literal_kernel_reproduces_frames_made_by_executing_the_shader_text(name
     n = 0
     for l in range(len(sizes)):
         n += _same_to_the_bit_where_specified(rp.read_level(l), g[f"{name}.level{l}"], f"executed shader, {name} level {l}")
-    assert n > 0 or name.endswith("mesh") or name == "euler_tight"
+    assert n > 0 or name.endswith("mesh") or name == "euler_tight" or name.startswith("fuzz")
     if f"{name}.sky" in g.files:         # sky.wgsl executed by the same interpreter over the executed frame: the resolve kernel on the literal frame
         rp.resolve_sky()
         sky, want = rp.read_sky().view(np.uint16), g[f"{name}.sky"]

@@ -26,6 +26,7 @@ from oracle import oracle as O
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ["euler_l0", "rk_l0", "rk_ladder", "euler_ladder", "rk_outside", "rk_off_origin", "rk_highlight", "euler_tight", "rk_mesh", "euler_mesh", "rk_mesh_near", "euler_mesh_near"]
+FUZZ = [f"fuzz{k:02d}" for k in range(24)]            # 24 seeded random points of the UI's uniform space, both integrators, two-level ladders
 
 
 @pytest.fixture(scope="module")
@@ -48,6 +49,9 @@ def scene_of(g, name, structured_nodes=False):
 def test_fixture_covers_every_path_of_the_shader(g):
     """Traced rays of every fate, interpolated and copied pixels, disk and sky colours, mesh shading."""
     seen_mesh = False
+    assert sorted(k[:-6] for k in g.files if k.endswith(".sizes")) == sorted(CASES + FUZZ)
+    methods = {int(np.frombuffer(g[f"{n}.details"].tobytes(), dtype=np.int32)[3]) for n in FUZZ}
+    assert methods == {0, 1}
     for name in CASES:
         sizes = g[f"{name}.sizes"]
         for l in range(len(sizes)):
@@ -69,7 +73,7 @@ def test_fixture_covers_every_path_of_the_shader(g):
     assert int((bare != g["rk_mesh_near.level0"]).any(axis=-1).sum()) >= 40
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + FUZZ)
 def test_c_oracle_literal_mode_equals_the_executed_shader_word_for_word(g, name):
     u, tex, sizes, models = scene_of(g, name)
     O.set_eval(O.EVAL_LITERAL)
