@@ -832,6 +832,9 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #ifndef BHRAY_FUSED_RAYS_AHEAD
 #define BHRAY_FUSED_RAYS_AHEAD 512    // fused ladder: slots of a level's ray queue that idle lanes may hold beyond the published entries
 #endif
+#ifndef BHRAY_HIT_LDS
+#define BHRAY_HIT_LDS 0         // dense build: "a hit happened" in the cold LDS state rather than an SGPR pair merged at every join of the step loop (A/B: profiles/EXPERIMENTS.md R3.9)
+#endif
 #ifndef BHRAY_MAILBOX_T
 #define BHRAY_MAILBOX_T 0        // drain merging (measured, off: DESIGN.md §4): a wave with this many live rays or fewer parks them; 0 disables
 #endif
@@ -1083,6 +1086,8 @@ template <> struct ColdState<false> {
     __device__ __forceinline__ void set_rdir(F3 v) { rdir_ = v; }
     __device__ __forceinline__ float pend_t() const { return pend_t_; }
     __device__ __forceinline__ void set_pend_t(float v) { pend_t_ = v; }
+    __device__ __forceinline__ bool hit() const { return false; }
+    __device__ __forceinline__ void set_hit(bool) {}
 };
 template <> struct ColdState<true> {
     float* b;                                                                     // this lane's column: plane k at b[S * k]
@@ -1096,6 +1101,8 @@ template <> struct ColdState<true> {
     __device__ __forceinline__ void set_rdir(F3 v) { b[4 * S] = v.x; b[5 * S] = v.y; b[6 * S] = v.z; }
     __device__ __forceinline__ float pend_t() const { return b[7 * S]; }
     __device__ __forceinline__ void set_pend_t(float v) { b[7 * S] = v; }
+    __device__ __forceinline__ bool hit() const { return b[8 * S] != 0.0f; }                      // (BHRAY_HIT_LDS)
+    __device__ __forceinline__ void set_hit(bool v) { b[8 * S] = v ? 1.0f : 0.0f; }
 };
 
 #ifdef BHRAY_EXP_PROFILE
@@ -1113,7 +1120,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
     if (Fb[0].span && threadIdx.x == 0) atomicMax(&Fb[0].span[0], ~(unsigned long long)wall_clock64());
 #endif
     constexpr bool COLD_LDS = DENSE && !MODELS;
-    __shared__ float cold_lds[COLD_LDS ? 8 * BHRAY_TRACE_THREADS : 1];
+    __shared__ float cold_lds[COLD_LDS ? (8 + BHRAY_HIT_LDS) * BHRAY_TRACE_THREADS : 1];
     // mesh variant: optional LDS staging of the top of the BVH and of the shallow part of the traversal stacks (trace_ray_model)
     constexpr int BVH_TOP = MODELS ? BHRAY_BVH_LDS_TOP : 0;
     // (dynamic LDS: with a static array the compiler assumes 64 KB of LDS per CU - gfx950 has 160 KB -, concludes that occupancy is
@@ -1246,6 +1253,9 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
     // "a hit happened" (0 / 1).  As a bool it lives in an SGPR pair and costs three scalar operations at every control-flow join of the
     // step loop, taken or not - the latency build keeps it in a VGPR; the dense build has no VGPR to spare (80: 6 waves per SIMD).
     typename std::conditional<COLD_LDS, bool, int>::type hit = 0;
+    constexpr bool HIT_IN_LDS = COLD_LDS && BHRAY_HIT_LDS != 0;      // dense build: the flag in the cold LDS state instead (no mask merging at the step loop's joins)
+#define HIT_SET(v) do { if (HIT_IN_LDS) cold.set_hit(v); else hit = (v); } while (0)
+#define HIT_GET() (HIT_IN_LDS ? cold.hit() : (bool)hit)
     bool exhausted = false;
     const bool fused_tier1 = !BHRAY_FUSED_TIERS || (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == ((blockIdx.x + 1u) & (BHRAY_TRACE_THREADS / 64 - 1));
     int fused_wait_round = 0, fused_lo = 0, fused_skip = 0, fused_backoff = 0;     // FUSED tracer: rounds waited on slots; first level still worth a look; rounds until the next look at the queues   // FUSED: this wave's outstanding ticket of the tile ring
@@ -1291,7 +1301,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                 rkpos = cam; rkdir = rdir; rkh = P.step_size;
                 cold.set_color(f3(0, 0, 0)); amount = 1.0f; closest = H.ray_distance;
                 dist_c = P.ray_distance_f; cpos_dist = P.ray_distance_f; qrel = cam - bpos;
-                it = 0; hit = 0;
+                it = 0; HIT_SET(0);
                 mode = P.relativity0 ? M_REL : M_FLAT;
                 if (COUNT) cnt[3]++;
             };
@@ -1318,7 +1328,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                     fused_flush(Z, processed, finals, lane);
                     cpos = f3(0, 0, 0); cdir = f3(0, 0, 1); ppos = f3(0, 0, 0); pdir = f3(0, 0, 1); rkpos = f3(0, 0, 0); rkdir = f3(0, 0, 1);
                     rkh = 0.0f; amount = 1.0f; closest = H.ray_distance; dist_c = P.ray_distance_f; cpos_dist = P.ray_distance_f; qrel = f3(0, 0, 0);
-                    it = 0; hit = 0; fused_idle = 0; fused_backoff = 0;
+                    it = 0; HIT_SET(0); fused_idle = 0; fused_backoff = 0;
                 }
             }
             // (a) slots for the empty lanes, coarsest open level first (the coarse levels are the critical path).  Entries that are there
@@ -1444,7 +1454,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                     rkpos = cam; rkdir = rdir; rkh = P.step_size;
                     cold.set_color(f3(0, 0, 0)); amount = 1.0f; closest = H.ray_distance;
                     dist_c = P.ray_distance_f; cpos_dist = P.ray_distance_f; qrel = cam - bpos;
-                    it = 0; hit = 0;
+                    it = 0; HIT_SET(0);
                     mode = P.relativity0 ? M_REL : M_FLAT;
                     if (COUNT) cnt[3]++;
                 }
@@ -1490,7 +1500,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                             cold.set_pend_t(sp[32 * MB_CAP]);
                             cold.set_pix(__float_as_uint(sp[33 * MB_CAP]));
                             const int mh = __float_as_int(sp[34 * MB_CAP]);
-                            mode = mh & 0xff; hit = (mh >> 8) != 0 ? 1 : 0;
+                            mode = mh & 0xff; HIT_SET((mh >> 8) != 0 ? 1 : 0);
                             it = __float_as_int(sp[35 * MB_CAP]);
                             if (COUNT) cnt[11]++;
                         }
@@ -1537,7 +1547,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                             sp[29 * MB_CAP] = rd.x; sp[30 * MB_CAP] = rd.y; sp[31 * MB_CAP] = rd.z;
                             sp[32 * MB_CAP] = cold.pend_t();
                             sp[33 * MB_CAP] = __uint_as_float(cold.pix());
-                            sp[34 * MB_CAP] = __int_as_float(mode | (hit ? 0x100 : 0));
+                            sp[34 * MB_CAP] = __int_as_float(mode | (HIT_GET() ? 0x100 : 0));
                             sp[35 * MB_CAP] = __int_as_float(it);
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1572,7 +1582,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                 const F3 cc = f3(clamp_(crs.color.x, 0.0f, 1.0f), clamp_(crs.color.y, 0.0f, 1.0f), clamp_(crs.color.z, 0.0f, 1.0f));
                 cold.set_color(cold.color() + cc * (amount * crs.opacity));
                 amount *= 1.0f - crs.opacity;
-                hit = 1;
+                HIT_SET(1);
                 if (amount < 0.005f) mode = M_FINISH;
                 else { it++; mode = (mode == M_SHADE_FLAT) ? M_FLAT : M_REL; }
             }
@@ -1647,7 +1657,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                             const F3 cc = f3(clamp_(crs.color.x, 0.0f, 1.0f), clamp_(crs.color.y, 0.0f, 1.0f), clamp_(crs.color.z, 0.0f, 1.0f));
                             cold.set_color(cold.color() + cc * (amount * crs.opacity));
                             amount *= 1.0f - crs.opacity;
-                            hit = 1;
+                            HIT_SET(1);
                         }
                         if (amount < 0.005f) mode = M_FINISH; else it++;
                     }
@@ -1669,7 +1679,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                 F3 color = cold.color();
                 const uint32_t pix = cold.pix();
                 if (COUNT && (unsigned long long)it > cnt[12]) cnt[12] = (unsigned long long)it;
-                if (hit || it <= 5) {
+                if (HIT_GET() || it <= 5) {
                     if (amount > 0.001f) {
                         if (COUNT) cnt[9]++;
                         // cartesian_to_spherical(dir.xzy), ray.wgsl:255-261, 585-586
