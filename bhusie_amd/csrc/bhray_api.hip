@@ -118,6 +118,8 @@ struct bhray_dev {
     uint32_t batch = 1;                    // frames per batch
     int last_slot = 0, last_sub = 0;       // slot / position in its batch of the most recently rendered frame
     uint64_t batch_counter = 0;            // batches launched so far; the staging slot is batch_counter % slots
+    uint64_t retired = 0;                  // batches known to have completed (polled oldest-first at every launch): batch_counter - retired are in flight
+    int dynamic_dense = -1;                // BHRAY_DYNAMIC_DENSE=n overrides the policy below (0: by the slot count; n > 0: by the batches in flight now, threshold n)
     bhray::DevOptions opt;
     float4* bound_out = nullptr;           // dev_bind_output: destination of the next frame (one-shot)
     std::vector<hipEvent_t> waits;         // dev_wait_event: pending dependencies of the next render (events owned by the caller)
@@ -457,6 +459,7 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
         c->temporal_radius_coarse = rc < 0 ? 0 : (rc > 4 ? 4 : (uint32_t)rc);
     }
     if (const char* e = getenv("BHRAY_TRACE_DENSE")) c->dense_override = atoi(e) != 0;
+    if (const char* e = getenv("BHRAY_DYNAMIC_DENSE")) c->dynamic_dense = atoi(e);
     const uint32_t nslots = cfg->frames_in_flight ? cfg->frames_in_flight : 4;
     c->cfg.frames_in_flight = nslots;
     c->slots.resize(nslots);
@@ -877,8 +880,22 @@ int launch_batch(bhray_dev* c) {
     // rays - at least ~4 whole frames' worth in flight (slots x frames per batch / row partitions) - otherwise the latency
     // build (measured on MI355X: 1920x1080, 16 slots: 4830 vs 4160 Mrays/s; 1/8 row tile, 16 slots x 8 frames: 0.070 vs
     // 0.080 ms per frame; one slot: the latency build is 7-15 % faster per launch).
+    // ... with four or more row partitions a rank's launches are small and a timed block may hold only a few batches: there the count is
+    // the batches IN FLIGHT when this one is launched (completed ones are retired oldest-first, one or two event queries per launch),
+    // dense from 8 partitions' worth on (emulated ranks, 20-frame blocks: N = 8 0.1018 -> 0.0992 ms per frame, N = 4 0.1469 -> 0.1403;
+    // 400-frame blocks unchanged; a whole frame per GPU loses 1-2 % with it: profiles/EXPERIMENTS.md R3.11).
+    const int dyn = c->dynamic_dense >= 0 ? c->dynamic_dense : (c->cfg.row_world >= 4 ? 8 : 0);
+    size_t in_flight = c->slots.size();
+    if (dyn > 0) {
+        while (c->retired < c->batch_counter) {
+            const Slot& O = c->slots[(size_t)(c->retired % c->slots.size())];
+            if (O.batch_id == c->retired && hipEventQuery(O.done) != hipSuccess) break;
+            c->retired++;
+        }
+        in_flight = (size_t)(c->batch_counter - c->retired) + 1;
+    }
     const bool dense = c->dense_override >= 0 ? c->dense_override != 0
-                                              : (c->slots.size() * (size_t)c->batch >= 4 * (size_t)c->cfg.row_world);
+                                              : (in_flight * (size_t)c->batch >= (size_t)(dyn > 0 ? dyn : 4) * (size_t)c->cfg.row_world);
     const int literal = (c->cfg.flags & BHRAY_F_LITERAL) ? 1 : ((c->cfg.flags & BHRAY_F_EVAL_FMA) ? 2 : 0);   // the integrator's evaluation (launch_trace's `eval`)
     int bpc = trace_blocks_per_cu(S.method, S.models, count, dense, literal);
     if (c->slots.size() > 1 && bpc > 1) bpc = bpc > 4 ? 2 : (bpc / 2 > 1 ? bpc / 2 : 1);     // measured: 2 blocks per CU is best at 8-16 slots

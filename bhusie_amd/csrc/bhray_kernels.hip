@@ -833,7 +833,7 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #define BHRAY_FUSED_RAYS_AHEAD 512    // fused ladder: slots of a level's ray queue that idle lanes may hold beyond the published entries
 #endif
 #ifndef BHRAY_HIT_LDS
-#define BHRAY_HIT_LDS 0         // dense build: "a hit happened" in the cold LDS state rather than an SGPR pair merged at every join of the step loop (A/B: profiles/EXPERIMENTS.md R3.9)
+#define BHRAY_HIT_LDS 1         // dense build: "a hit happened" in the cold LDS state rather than an SGPR pair merged at every join of the step loop (+0.3 %, A/B in two sessions: profiles/EXPERIMENTS.md R3.9)
 #endif
 #ifndef BHRAY_MAILBOX_T
 #define BHRAY_MAILBOX_T 0        // drain merging (measured, off: DESIGN.md §4): a wave with this many live rays or fewer parks them; 0 disables
