@@ -479,7 +479,8 @@ __device__ constexpr float DB1 = KF(37.0 / 378.0 - 2825.0 / 27648.0),
 // In isolation it does what it should (profiles/ubench/lone_xyz.hip: 856 -> 723 cycles per bare RK step for a lone wave, +1-2 % on a
 // saturated chip, 35 VALU instructions fewer, no extra copies) and the whole -m gpu suite passes bit for bit - and the product gets
 // SLOWER with it: 5 050 -> 4 690 Mrays/s in 20-frame blocks, 5 615 -> 5 210 in long ones, one frame at a time 1.21 -> 1.245 ms, the
-// emulated N = 8 rank 0.0992 -> 0.1024 ms (A/B, three rounds: profiles/r03_ab_pkxy.txt; EXPERIMENTS.md R3.13).
+// emulated N = 8 rank 0.0992 -> 0.1024 ms (A/B, three rounds: profiles/r03_ab_pkxy.txt; EXPERIMENTS.md R3.13).  A packed instruction takes no
+// literal: every tableau coefficient becomes an s_mov in front of its use (the kernel is at its 106 SGPRs, they cannot stay resident).
 #ifndef BHRAY_PK_XY
 #define BHRAY_PK_XY 0
 #endif
