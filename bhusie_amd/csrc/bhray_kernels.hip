@@ -473,56 +473,10 @@ __device__ constexpr float DB1 = KF(37.0 / 378.0 - 2825.0 / 27648.0),
                            DB3 = KF(250.0 / 621.0 - 18575.0 / 48384.0), DB4 = KF(125.0 / 594.0 - 13525.0 / 55296.0),
                            DB5 = KF(0.0 - 277.0 / 14336.0), DB6 = KF(512.0 / 1771.0 - 1.0 / 4.0);
 
-// EXPERIMENT, off (BHRAY_PK_XY): the (x, y) components of the integrator's 3-vector operations in ONE packed instruction (v_pk_fma_f32 /
-// v_pk_mul_f32 / v_pk_add_f32: two IEEE binary32 operations, each exactly what the scalar instruction computes), z in a scalar one - 2
-// instructions per vector operation instead of 3, for the waves that run alone and pay ~5.5 cycles per INSTRUCTION whatever it carries.
-// In isolation it does what it should (profiles/ubench/lone_xyz.hip: 856 -> 723 cycles per bare RK step for a lone wave, +1-2 % on a
-// saturated chip, 35 VALU instructions fewer, no extra copies) and the whole -m gpu suite passes bit for bit - and the product gets
-// SLOWER with it: 5 050 -> 4 690 Mrays/s in 20-frame blocks, 5 615 -> 5 210 in long ones, one frame at a time 1.21 -> 1.245 ms, the
-// emulated N = 8 rank 0.0992 -> 0.1024 ms (A/B, three rounds: profiles/r03_ab_pkxy.txt; EXPERIMENTS.md R3.13).  A packed instruction takes no
-// literal: every tableau coefficient becomes an s_mov in front of its use (the kernel is at its 106 SGPRs, they cannot stay resident).
-#ifndef BHRAY_PK_XY
-#define BHRAY_PK_XY 0
-#endif
-typedef float v2f __attribute__((ext_vector_type(2)));
-struct Q3 { v2f xy; float z; };
-__device__ __forceinline__ v2f splat2(float s) { v2f r = {s, s}; return r; }
-__device__ __forceinline__ Q3 q3(F3 a) { Q3 r; r.xy.x = a.x; r.xy.y = a.y; r.z = a.z; return r; }
-__device__ __forceinline__ F3 f3(Q3 a) { return f3(a.xy.x, a.xy.y, a.z); }
-__device__ __forceinline__ Q3 fmadd3(Q3 w, float s, Q3 v) { Q3 r; r.xy = __builtin_elementwise_fma(w.xy, splat2(s), v.xy); r.z = fmaf(w.z, s, v.z); return r; }   // v + w*s
-__device__ __forceinline__ Q3 operator*(Q3 w, float s) { Q3 r; r.xy = w.xy * splat2(s); r.z = w.z * s; return r; }
-__device__ __forceinline__ Q3 operator+(Q3 a, Q3 b) { Q3 r; r.xy = a.xy + b.xy; r.z = a.z + b.z; return r; }
-
 // next_ray_rk, ray.wgsl:405-465.  The retry loop (425-451) cannot change h and is run once.  N7: fused arithmetic.
 // `dist` = flength(pos - bpos), carried from the previous step's exit test (same operands, same value).
-#if BHRAY_PK_XY
-__device__ __forceinline__ void next_ray_rk(F3 q0f, F3& pos, F3& dir, float& h_io, float dist) {
-    const F3 p0 = pos, d0 = dir;
-    const F3 cr = fcross(p0, d0);
-    const float h2 = fdot(cr, cr);                   // N3: pow(length(v), 2.0) = dot(v, v)
-    const float s = (-1.5f * h2) * rcp_rn(pow5(dist));   // N9
-    const float h = h_io;
-    const float sh = s * h;                          // N10
-    const Q3 q0 = q3(q0f);
-    const Q3 K1 = q0 * sh;
-    const Q3 K2 = fmadd3(K1, A21, q0) * sh;
-    const Q3 K3 = fmadd3(K2, A32, fmadd3(K1, A31, q0)) * sh;
-    const Q3 K4 = fmadd3(K2, A43, fmadd3(K2, A42, fmadd3(K1, A41, q0))) * sh;
-    const Q3 K5 = fmadd3(K4, A54, fmadd3(K3, A53, fmadd3(K2, A52, fmadd3(K1, A51, q0)))) * sh;
-    const Q3 K6 = fmadd3(K5, A65, fmadd3(K4, A64, fmadd3(K3, A63, fmadd3(K2, A62, fmadd3(K1, A61, q0))))) * sh;
-    const Q3 e = fmadd3(K6, DB6, fmadd3(K5, DB5, fmadd3(K4, DB4, fmadd3(K3, DB3, K1 * DB1))));
-    const float e_max = max_(max_(fabsf(e.xy.x), fabsf(e.xy.y)), fabsf(e.z));
-    const Q3 ds = fmadd3(K6, BA6, fmadd3(K5, BA5, fmadd3(K4, BA4, fmadd3(K3, BA3, K1 * BA1))));
-    const Q3 a = q3(d0) + ds;
-    const float d = fdot(f3(a), f3(a));              // == fnormalize_rn(a): a * (1 / sqrt(fdot(a, a)))
-    float r = rcp_newton(sqrt_corrected(d));
-    if (__builtin_expect(__ballot(!sqrt_in_range(d)) != 0ull, 0)) r = 1.0f / sqrtf(d);
-    dir = f3(a * r);
-    pos = f3(fmadd3(q3(d0), h, q3(p0)));
-    if (e_max > 0.00002f) h_io = h * (0.9f * pow_m001_step(e_max));
-    else h_io = h * 1.0001f;
-}
-#else
+// (A form with the (x, y) components of every 3-vector operation in one packed instruction was built and measured: faster in isolation,
+// slower in this kernel - a packed instruction takes no literal, and the kernel has no SGPRs left for the 25 coefficients: EXPERIMENTS.md R3.13.)
 __device__ __forceinline__ void next_ray_rk(F3 q0, F3& pos, F3& dir, float& h_io, float dist) {
     const F3 p0 = pos, d0 = dir;           // q0 = p0 - bpos (N9), carried by the caller together with dist = flength(q0)
     const F3 cr = fcross(p0, d0);
@@ -546,7 +500,6 @@ __device__ __forceinline__ void next_ray_rk(F3 q0, F3& pos, F3& dir, float& h_io
     if (e_max > 0.00002f) h_io = h * (0.9f * pow_m001_step(e_max));
     else h_io = h * 1.0001f;
 }
-#endif
 
 // next_ray_euler, ray.wgsl:467-480 (N7, N9).
 __device__ __forceinline__ void next_ray_euler(F3 q0, F3& pos, F3& dir, float step, float dist) {
