@@ -838,6 +838,17 @@ SKY_SHADER = "/root/reference/src/renderer/shaders/sky.wgsl"
 _COMPILED = {}
 
 
+def compile_source(src, name="<wgsl>"):
+    """Translates WGSL text (the subset above) and returns the namespace holding its functions (fn_<name>), constants (C_<name>) and
+    struct classes (S_<name>); module-scope `var`s are looked up as G_<name> and must be bound by the caller."""
+    decls = Parser(tokenize(src)).module()
+    code = Gen(decls).module()
+    ns = {k: v for k, v in globals().items() if not k.startswith("__")}
+    exec(compile(code, name, "exec"), ns)
+    ns["__source__"] = code
+    return ns
+
+
 def compile_shader(path=SHADER):
     """Parses one of the reference's shaders and returns the namespace holding its translated functions (fn_main, fn_trace_ray, ...)."""
     if path in _COMPILED:
