@@ -1,4 +1,5 @@
-"""wgsl_exec.py - executes the REFERENCE'S OWN shader text.  TEST INFRASTRUCTURE ONLY; runs only where /root/reference exists.
+"""wgsl_exec.py - executes the REFERENCE'S OWN shader text.  TEST INFRASTRUCTURE ONLY; the reference's shaders are read only where /root/reference exists
+(the build container); compile_source() runs any WGSL text of the subset.
 
 Every other oracle in this directory is a restatement written by reading ray.wgsl.  This module instead READS
 /root/reference/src/renderer/shaders/ray.wgsl (and sky.wgsl, the resolve pass behind it) at run time, parses it (a recursive-descent parser for the WGSL subset the file
@@ -16,7 +17,8 @@ Deviation D1 (the Runge-Kutta retry loop of ray.wgsl:425-451 cannot terminate on
 whose variables are bit-identical at the top of two successive passes is left there - which yields exactly what one pass computed.
 
 Its frames are committed as tests/golden/wgsl_exec.npz by tests/golden/make_golden_wgsl.py; the C oracle's literal mode, the NumPy
-restatement's and the literal HIP kernel are held to them bit for bit (tests/test_oracle_golden.py, tests/test_gpu_literal.py): that
+restatement's and the literal HIP kernel are held to them bit for bit (tests/test_wgsl_pin.py, tests/test_gpu_literal.py; the interpreter's
+own unit tests: tests/test_wgsl_exec_unit.py): that
 pins the restatements to the reference's text - not to a driver's floating-point choices, which nothing in this image can run.
 """
 from __future__ import annotations
