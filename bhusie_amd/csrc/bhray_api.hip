@@ -56,9 +56,11 @@ struct FrameRes {
 
     uint32_t* d_qctl = nullptr;         // [2*BHRAY_MAX_LEVELS]: qcount[l], qhead[l]   (a slice of Slot::d_qctl)
     Counters64* d_counters = nullptr;   // [BHRAY_MAX_LEVELS]                         (a slice of Slot::d_counters)
+    unsigned long long* d_row_work = nullptr;   // BHRAY_F_COUNTERS: iterations per level row, level l at bhray_dev::row_work_off[l] (bhray_get_row_work)
     float4* own_out = nullptr;
     float4* out = nullptr;              // where this frame is written (own_out or a bound buffer)
     uint2* sky_out = nullptr;           // RGBA16F image of the sky resolve pass (allocated on first use)
+    uint64_t sky_frame_id = ~0ull;      // frame_id of the frame sky_out was resolved from (a slot position is reused: an older frame's image is stale)
     uint64_t frame_id = 0;              // frame_counter value of the frame held here
     // fused ladder: per-frame tile state and queues (bhray_internal.h)
     FusedCtl* fz_ctl = nullptr; uint32_t* fz_deps = nullptr; uint32_t* fz_pending = nullptr; unsigned long long* fz_cq = nullptr;
@@ -127,6 +129,7 @@ struct bhray_dev {
     uint32_t launched_frames = 0;
     size_t out_bytes = 0;
     std::vector<uint32_t> local_rows;      // frame rows of this partition, increasing
+    size_t row_work_off[BHRAY_MAX_LEVELS + 1] = {0};   // BHRAY_F_COUNTERS: offset of every level's rows in FrameRes::d_row_work; [levels] = total
     // scene
     uint8_t* tex[3] = {nullptr, nullptr, nullptr};
     int tex_w[3] = {0, 0, 0}, tex_h[3] = {0, 0, 0};
@@ -180,8 +183,9 @@ int fail(bhray_dev* ctx, int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(ctx, BHRAY_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
+}  // namespace
 // rows of level k-1 that the rows `fine` of level k read (ray.wgsl:185-201), same binary32 math
-std::vector<int32_t> coarse_rows_needed(const std::vector<int32_t>& fine, int h, int ph) {
+std::vector<int32_t> bhray::coarse_rows_needed(const std::vector<int32_t>& fine, int h, int ph) {
     std::vector<uint8_t> need((size_t)ph, 0);
     if (ph == 1) return {};
     const int sf = (h - 1) / (ph - 1);
@@ -197,6 +201,7 @@ std::vector<int32_t> coarse_rows_needed(const std::vector<int32_t>& fine, int h,
     for (int y = 0; y < ph; y++) if (need[(size_t)y]) out.push_back(y);
     return out;
 }
+namespace {
 
 // bh_acos(c) < thr  <=>  c > acos_threshold(thr)  for c in [-1, 1]: bh_acos is monotone non-increasing over all binary32 values
 // of the interval (exhaustive check: dev_selftest), so the set where the predicate holds is an upper interval; its lower end is
@@ -369,6 +374,7 @@ void dev_destroy(bhray_dev* c) {
             for (auto p : R.need) if (p) (void)hipFree(p);
             for (auto p : R.stamp) if (p) (void)hipFree(p);
             if (R.own_out) (void)hipFree(R.own_out);
+            if (R.d_row_work) (void)hipFree(R.d_row_work);
             if (R.sky_out) (void)hipFree(R.sky_out);
             if (R.fz_ctl) (void)hipFree(R.fz_ctl);
             if (R.fz_deps) (void)hipFree(R.fz_deps);
@@ -412,8 +418,9 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
     const uint32_t lw = cfg->level_w[cfg->levels - 1], lh = cfg->level_h[cfg->levels - 1];
     if (cfg->frame_w < 1 || cfg->frame_h < 1 || cfg->crop_x + cfg->frame_w > lw || cfg->crop_y + cfg->frame_h > lh)
         return fail(nullptr, BHRAY_E_INVALID, "frame window outside the last level");
-    if (cfg->row_world < 1 || cfg->row_rank >= cfg->row_world || cfg->stripe_rows < 1)
+    if (cfg->row_world < 1 || cfg->row_rank >= cfg->row_world)
         return fail(nullptr, BHRAY_E_INVALID, "bad row partition");
+    if (const char* why = partition_error(*cfg, cfg->row_world)) return fail(nullptr, BHRAY_E_INVALID, "bad row partition: %s", why);
     if (cfg->frames_in_flight > BHRAY_MAX_FRAMES_IN_FLIGHT) return fail(nullptr, BHRAY_E_INVALID, "frames_in_flight > %d", BHRAY_MAX_FRAMES_IN_FLIGHT);
     if (cfg->frames_per_batch > BHRAY_MAX_FRAMES_PER_BATCH) return fail(nullptr, BHRAY_E_INVALID, "frames_per_batch > %d", BHRAY_MAX_FRAMES_PER_BATCH);
     if (cfg->speculative_levels == 1 || cfg->speculative_levels > BHRAY_MAX_SPEC_LEVELS || (cfg->speculative_levels && cfg->speculative_levels >= cfg->levels))
@@ -423,6 +430,8 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
         return fail(nullptr, BHRAY_E_INVALID, "superset_levels must be 0 or 2..%d and leave at least one coarser level (beyond the speculative ones)", BHRAY_MAX_SPEC_LEVELS);
     if ((cfg->flags & BHRAY_F_TEMPORAL) && (cfg->levels > BHRAY_MAX_SPEC_LEVELS || cfg->speculative_levels || cfg->superset_levels))
         return fail(nullptr, BHRAY_E_INVALID, "BHRAY_F_TEMPORAL needs levels <= %d and no speculative / superset levels", BHRAY_MAX_SPEC_LEVELS);
+    if ((cfg->flags & BHRAY_F_FUSED) && fused_blocks_per_cu(0, 0, 0, 0) == 0)
+        return fail(nullptr, BHRAY_E_INVALID, "this build of libbhray has no fused ladder (BHRAY_F_FUSED): it is a build option, `make -C bhusie_amd/csrc fused` -> libbhray_fused.so");
     if ((cfg->flags & BHRAY_F_FUSED) && (cfg->levels > BHRAY_MAX_SPEC_LEVELS || cfg->superset_levels || (cfg->flags & BHRAY_F_TEMPORAL)))
         return fail(nullptr, BHRAY_E_INVALID, "BHRAY_F_FUSED needs levels <= %d and neither superset levels nor BHRAY_F_TEMPORAL", BHRAY_MAX_SPEC_LEVELS);
     int ndev = 0;
@@ -467,12 +476,12 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
     c->cfg.frames_per_batch = c->batch;
 
     // rows of the frame owned by this partition
-    for (uint32_t r = 0; r < cfg->frame_h; r++)
-        if ((r / cfg->stripe_rows) % cfg->row_world == cfg->row_rank) c->local_rows.push_back(r);
+    c->local_rows = partition_row_list(*cfg, cfg->row_world, cfg->row_rank);
 
     const uint32_t nl = cfg->levels;
     c->levels.resize(nl);
     for (uint32_t l = 0; l < nl; l++) { c->levels[l].w = (int)cfg->level_w[l]; c->levels[l].h = (int)cfg->level_h[l]; }
+    for (uint32_t l = 0; l < nl; l++) c->row_work_off[l + 1] = c->row_work_off[l] + (size_t)cfg->level_h[l];
     // top-down row dependency
     {
         Level& F = c->levels[nl - 1];
@@ -645,6 +654,10 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
                     const size_t cap = c->levels[l].queue_cap + 64;
                     CHK(hipMalloc(&R.fz_rq[l], cap * sizeof(unsigned long long))); CHK(hipMemset(R.fz_rq[l], 0, cap * sizeof(unsigned long long)));
                 }
+            }
+            if ((cfg->flags & BHRAY_F_COUNTERS) && !(cfg->flags & BHRAY_F_FUSED)) {
+                CHK(hipMalloc(&R.d_row_work, c->row_work_off[nl] * sizeof(unsigned long long)));
+                CHK(hipMemset(R.d_row_work, 0, c->row_work_off[nl] * sizeof(unsigned long long)));
             }
             if (c->out_bytes && !opt.external_out) {
                 CHK(hipMalloc(&R.own_out, c->out_bytes));
@@ -1003,6 +1016,7 @@ int launch_batch(bhray_dev* c) {
                 for (uint32_t l = 0; l < ns; l++) {
                     const Level& Lv = c->levels[l];
                     h[k].SL.l[l].w = Lv.w; h[k].SL.l[l].h = Lv.h; h[k].SL.l[l].out = (l == 0) ? R.level_out[0] : R.spec_out[l]; h[k].SL.l[l].out_pitch = Lv.w;
+                    h[k].SL.l[l].row_work = (count && R.d_row_work) ? R.d_row_work + c->row_work_off[l] : nullptr;
                 }
                 h[k].queue = R.spec_queue; h[k].qctl = R.d_qctl; h[k].counters = count ? R.d_counters : nullptr;
             }
@@ -1060,6 +1074,7 @@ int launch_batch(bhray_dev* c) {
                     LevelParams Lp; level_params(R, l, Lp);
                     SpecLevel& sl = h[k].SL.l[l];
                     sl.w = Lp.w; sl.h = Lp.h; sl.out = Lp.out; sl.out_pitch = Lp.out_pitch; sl.out_x0 = Lp.out_x0; sl.rowmap = Lp.rowmap; sl.stamp = R.stamp[l];
+                    sl.row_work = (count && R.d_row_work) ? R.d_row_work + c->row_work_off[l] : nullptr;
                 }
                 h[k].queue = R.pred_queue; h[k].qctl = R.pred_ctl; h[k].counters = count ? R.d_counters : nullptr;
                 h[k].stamp_value = R.stamp_value; h[k].probe_empty = 1;
@@ -1077,6 +1092,7 @@ int launch_batch(bhray_dev* c) {
                 h[k].queue = R.queue[l]; h[k].qctl = R.d_qctl + 2 * l; h[k].counters = count ? R.d_counters + l : nullptr;
                 h[k].need = R.need[l];
                 h[k].stamp = R.stamp[l]; h[k].stamp_value = R.stamp_value; h[k].probe_empty = 1;
+                h[k].row_work = (count && R.d_row_work) ? R.d_row_work + c->row_work_off[l] : nullptr;
             }
             seq.push_back({0, d, classify_blocks(l), count, {(int)(3 * l)}, {(int)(3 * l + 1)}, -1, true});
             seq.push_back({1, d, c->num_cus * trace_blocks_per_cu(S.method, S.models, count, 0, literal), count, {}, {(int)(3 * l + 2)}, 0});
@@ -1091,6 +1107,7 @@ int launch_batch(bhray_dev* c) {
             const FrameRes& R = S.fr[k];
             level_params(R, l, h[k].L);
             h[k].queue = R.queue[l]; h[k].qctl = R.d_qctl + 2 * l; h[k].counters = count ? R.d_counters + l : nullptr;
+            h[k].row_work = (count && R.d_row_work) ? R.d_row_work + c->row_work_off[l] : nullptr;
         }
         seq.push_back({0, d, classify_blocks(l), count, {(int)(3 * l)}, {(int)(3 * l + 1)}});
         seq.push_back({1, d, grid, count, {}, {(int)(3 * l + 2)}});
@@ -1126,6 +1143,7 @@ int launch_batch(bhray_dev* c) {
                     LevelParams Lp; level_params(R, l, Lp);
                     SpecLevel& sl = h[k].SL.l[l - u0];
                     sl.w = Lp.w; sl.h = Lp.h; sl.out = Lp.out; sl.out_pitch = Lp.out_pitch; sl.out_x0 = Lp.out_x0; sl.rowmap = Lp.rowmap;
+                    sl.row_work = (count && R.d_row_work) ? R.d_row_work + c->row_work_off[l] : nullptr;
                 }
                 h[k].queue = R.super_queue; h[k].qctl = R.d_qctl + 2 * u0; h[k].counters = count ? R.d_counters + u0 : nullptr;
             }
@@ -1162,6 +1180,7 @@ int launch_batch(bhray_dev* c) {
     HIPCHK(c, launch_upload(S.h_args, S.d_args, (args_used + 15) / 16, S.d_qctl, (size_t)nb * 2 * BHRAY_MAX_LEVELS, st));   // + queue control reset
     HIPCHK(c, hipEventRecord(S.uploaded, st));
     if (count) HIPCHK(c, hipMemsetAsync(S.d_counters, 0, (size_t)nb * BHRAY_MAX_LEVELS * sizeof(Counters64), st));
+    if (count) for (uint32_t k = 0; k < nb; k++) if (S.fr[k].d_row_work) HIPCHK(c, hipMemsetAsync(S.fr[k].d_row_work, 0, c->row_work_off[nl] * sizeof(unsigned long long), st));
     hipEvent_t* fev = timing ? &c->events[ring * (nl * 3 + 4)] : nullptr;
     if (timing) { c->sky_recorded[ring] = 0; c->ring_frames[ring] = (uint8_t)nb; }
     for (const Launch& Ln : seq) {
@@ -1306,10 +1325,11 @@ int dev_read_sky_async(bhray_dev* c, uint16_t* dst, size_t pitch, uint64_t* tick
     const size_t rowb = (size_t)c->cfg.frame_w * sizeof(uint2);
     if (!c->rendered) return fail(c, BHRAY_E_STATE, "nothing rendered yet");
     HIPCHK(c, hipSetDevice(c->device));
+    { int rc = launch_batch(c); if (rc) return rc; }          // (dev_resolve_sky launched the frame's batch; a render since then would be another frame)
     Slot& S = c->slots[(size_t)c->last_slot];
     FrameRes& R = S.fr[(size_t)c->last_sub];
     const size_t rows = c->local_rows.size();
-    if (rows && !R.sky_out) return fail(c, BHRAY_E_STATE, "dev_resolve_sky has not been called for this frame");
+    if (rows && (!R.sky_out || R.sky_frame_id != R.frame_id)) return fail(c, BHRAY_E_STATE, "dev_resolve_sky has not been called for this frame");
     const uint64_t t = c->read_tickets;
     hipEvent_t& ev = c->read_ev[t % BHRAY_READ_RING];
     if (!ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -1389,6 +1409,7 @@ int dev_resolve_sky(bhray_dev* c) {
     hipEvent_t* ev = timing ? &c->events[ring * (c->cfg.levels * 3 + 4) + c->cfg.levels * 3] : nullptr;
     if (timing) HIPCHK(c, hipEventRecord(ev[0], S.stream));
     HIPCHK(c, launch_sky(sky, R.out, R.sky_out, npix, S.stream));
+    R.sky_frame_id = R.frame_id;
     if (timing) { HIPCHK(c, hipEventRecord(ev[1], S.stream)); c->sky_recorded[ring] = 1; }
     HIPCHK(c, hipEventRecord(S.done, S.stream));
     return BHRAY_OK;
@@ -1400,7 +1421,7 @@ int dev_read_sky(bhray_dev* c, uint16_t* dst, size_t pitch) {
     if (c->local_rows.empty()) return dev_sync(c);
     if (!dst || pitch < rowb) return fail(c, BHRAY_E_INVALID, "bad destination / pitch");
     FrameRes& S = c->slots[(size_t)c->last_slot].fr[(size_t)c->last_sub];
-    if (!S.sky_out) return fail(c, BHRAY_E_STATE, "dev_resolve_sky has not been called for this frame");
+    if (!S.sky_out || S.sky_frame_id != S.frame_id) return fail(c, BHRAY_E_STATE, "dev_resolve_sky has not been called for this frame");
     int rc = dev_sync(c);
     if (rc) return rc;
     if (c->local_rows.empty()) return BHRAY_OK;
@@ -1493,6 +1514,20 @@ int dev_get_level_counters(bhray_dev* c, uint32_t level, bhray_counters* out) {
     if (rc) return rc;
     static_assert(sizeof(bhray_counters) == sizeof(Counters64), "counter layout");
     HIPCHK(c, hipMemcpy(out, c->slots[(size_t)c->last_slot].fr[(size_t)c->last_sub].d_counters + level, sizeof(Counters64), hipMemcpyDeviceToHost));
+    return BHRAY_OK;
+}
+
+int dev_add_row_work(bhray_dev* c, uint32_t level, uint64_t* acc, uint32_t n) {
+    if (!c || !acc) return BHRAY_E_INVALID;
+    if (!(c->cfg.flags & BHRAY_F_COUNTERS)) return fail(c, BHRAY_E_STATE, "ctx created without BHRAY_F_COUNTERS");
+    if (c->cfg.flags & BHRAY_F_FUSED) return fail(c, BHRAY_E_STATE, "bhray_get_row_work is not available with BHRAY_F_FUSED");
+    if (level >= c->cfg.levels || n != c->cfg.level_h[level]) return fail(c, BHRAY_E_INVALID, "level out of range, or n is not the level's height");
+    int rc = dev_sync(c);
+    if (rc) return rc;
+    const FrameRes& R = c->slots[(size_t)c->last_slot].fr[(size_t)c->last_sub];
+    std::vector<unsigned long long> tmp(n);
+    HIPCHK(c, hipMemcpy(tmp.data(), R.d_row_work + c->row_work_off[level], (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (uint32_t y = 0; y < n; y++) acc[y] += tmp[y];
     return BHRAY_OK;
 }
 

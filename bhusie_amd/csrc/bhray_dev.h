@@ -12,9 +12,35 @@
 
 #include "../../include/bhray.h"
 
+#include <vector>
+
 struct bhray_dev;
 
 namespace bhray {
+// Row partition arithmetic shared by the engine, the gather tables and the ABI helpers (bhray_config.partition).
+// nullptr: the partition described by cfg for `world` partitions is valid; otherwise what is wrong with it.
+inline const char* partition_error(const bhray_config& cfg, uint32_t world) {
+    if (world < 1) return "no partitions";
+    if (cfg.partition == BHRAY_PARTITION_STRIPES) return cfg.stripe_rows < 1 ? "stripe_rows must be >= 1" : nullptr;
+    if (cfg.partition != BHRAY_PARTITION_SLABS) return "unknown partition mode";
+    if (world > BHRAY_MAX_DEVICES) return "BHRAY_PARTITION_SLABS: more partitions than slab_row0 holds";
+    if (cfg.slab_row0[0] != 0 || cfg.slab_row0[world] != cfg.frame_h) return "BHRAY_PARTITION_SLABS: slab_row0 must start at 0 and end at frame_h";
+    for (uint32_t p = 0; p < world; p++) if (cfg.slab_row0[p] > cfg.slab_row0[p + 1]) return "BHRAY_PARTITION_SLABS: slab_row0 must be non-decreasing";
+    return nullptr;
+}
+// frame rows of partition `part`, increasing (a valid partition: partition_error)
+inline std::vector<uint32_t> partition_row_list(const bhray_config& cfg, uint32_t world, uint32_t part) {
+    std::vector<uint32_t> rows;
+    if (cfg.partition == BHRAY_PARTITION_SLABS) {
+        for (uint32_t r = cfg.slab_row0[part]; r < cfg.slab_row0[part + 1]; r++) rows.push_back(r);
+    } else {
+        for (uint32_t r = 0; r < cfg.frame_h; r++) if ((r / cfg.stripe_rows) % world == part) rows.push_back(r);
+    }
+    return rows;
+}
+// rows of level k-1 that the rows `fine` (sorted) of level k read (ray.wgsl:185-201), same binary32 arithmetic as the kernels' (bhray_api.hip)
+std::vector<int32_t> coarse_rows_needed(const std::vector<int32_t>& fine, int h, int ph);
+
 struct DevOptions {
     bool external_out = false;   // the ctx binds every frame's destination (send buffer / assembled frame): no own output buffers
     bool frame_rowmap = false;   // the destination is a whole frame_h x frame_w frame: row r of the frame lands in row r (root partition of a gather)
@@ -50,6 +76,7 @@ int  dev_next_stream(bhray_dev* c, void** s);
 int  dev_signal_stream(bhray_dev* c, void* s);
 int  dev_selftest(bhray_dev* c, uint64_t mismatches[3]);
 int  dev_get_level_counters(bhray_dev* c, uint32_t level, bhray_counters* out);
+int  dev_add_row_work(bhray_dev* c, uint32_t level, uint64_t* acc, uint32_t n);   // acc[y] += iterations of the last render's rays of level row y
 int  dev_debug_read_queue(bhray_dev* c, uint32_t level, uint32_t* out, uint32_t cap, uint32_t* count);   // diagnostics only
 int  dev_get_counters(bhray_dev* c, bhray_counters* out);
 int  dev_get_timing(bhray_dev* c, bhray_timing* out);

@@ -23,7 +23,9 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <unistd.h>
 
+#include <algorithm>
 #include <mutex>
 #include <new>
 #include <string>
@@ -117,6 +119,7 @@ struct Part {                      // one row partition of the frame
     int device = -1;
     int rank = -1;                 // rank of the communicator this partition's tiles leave from / arrive at
     uint32_t rows = 0;
+    std::vector<uint32_t> row_list; // its frame rows, increasing (bhray_config.partition)
     size_t stage_row0 = 0;         // root staging: first row of this partition's block (units of rows, for batch index 0)
 };
 
@@ -383,6 +386,98 @@ int bhray_partition_row_index(uint32_t frame_h, uint32_t world, uint32_t stripe_
     return BHRAY_OK;
 }
 
+static uint32_t config_world(const bhray_config* cfg) { return cfg->device_count >= 2 ? cfg->device_count : (cfg->row_world ? cfg->row_world : 1); }
+
+uint32_t bhray_config_partition_rows(const bhray_config* cfg, uint32_t part) {
+    if (!cfg) return 0;
+    bhray_config one = *cfg;
+    if (one.partition == BHRAY_PARTITION_STRIPES && one.stripe_rows == 0) one.stripe_rows = 27;
+    const uint32_t world = config_world(cfg);
+    if (part >= world || partition_error(one, world)) return 0;
+    return (uint32_t)partition_row_list(one, world, part).size();
+}
+
+int bhray_config_partition_row_index(const bhray_config* cfg, uint32_t part, uint32_t i, uint32_t* frame_row) {
+    if (!cfg || !frame_row) return BHRAY_E_INVALID;
+    bhray_config one = *cfg;
+    if (one.partition == BHRAY_PARTITION_STRIPES && one.stripe_rows == 0) one.stripe_rows = 27;
+    const uint32_t world = config_world(cfg);
+    if (part >= world || partition_error(one, world)) return BHRAY_E_INVALID;
+    const std::vector<uint32_t> rows = partition_row_list(one, world, part);
+    if (i >= rows.size()) return BHRAY_E_INVALID;
+    *frame_row = rows[i];
+    return BHRAY_OK;
+}
+
+// Slab bounds that minimise the largest partition's work.  The work of the slab [a, b) is, at every level, the work of the level rows
+// its frame rows depend on - for consecutive frame rows a consecutive range of level rows, found with the ladder's own arithmetic
+// (coarse_rows_needed on the two end rows) - so with prefix sums it is O(levels); the optimum over contiguous partitions is found
+// by bisection on the load a slab may carry (greedy packing decides feasibility: the work of [a, b) is non-decreasing in b).
+int bhray_balance_slabs(const bhray_config* cfg, const uint64_t* const* row_work, uint32_t world, uint32_t* slab_row0) {
+    if (!cfg || !row_work || !slab_row0 || world < 1 || world > BHRAY_MAX_DEVICES) return BHRAY_E_INVALID;
+    const uint32_t nl = cfg->levels;
+    if (nl < 1 || nl > BHRAY_MAX_LEVELS || cfg->frame_h < 1 || cfg->crop_y + cfg->frame_h > cfg->level_h[nl - 1]) return BHRAY_E_INVALID;
+    std::vector<std::vector<double>> pre(nl);                      // pre[l][y] = work of level rows [0, y)
+    for (uint32_t l = 0; l < nl; l++) {
+        if (!row_work[l] || cfg->level_h[l] < 2) return BHRAY_E_INVALID;
+        pre[l].assign((size_t)cfg->level_h[l] + 1, 0.0);
+        for (uint32_t y = 0; y < cfg->level_h[l]; y++) pre[l][y + 1] = pre[l][y] + (double)row_work[l][y];
+    }
+    auto work = [&](uint32_t a, uint32_t b) -> double {         // frame rows [a, b), b > a
+        int lo = (int)(cfg->crop_y + a), hi = (int)(cfg->crop_y + b - 1);
+        double w = 0.0;
+        for (int l = (int)nl - 1; l >= 0; l--) {
+            w += pre[(size_t)l][(size_t)hi + 1] - pre[(size_t)l][(size_t)lo];
+            if (l > 0) {
+                const std::vector<int32_t> ends = coarse_rows_needed({lo, hi}, (int)cfg->level_h[l], (int)cfg->level_h[l - 1]);
+                if (ends.empty()) break;
+                lo = ends.front(); hi = ends.back();
+            }
+        }
+        return w;
+    };
+    const uint32_t H = cfg->frame_h;
+    auto pack = [&](double cap, uint32_t* bounds) -> bool {      // greedy: every slab as long as its work stays within cap
+        uint32_t a = 0;
+        for (uint32_t p = 0; p < world; p++) {
+            if (bounds) bounds[p] = a;
+            if (a < H) {
+                if (work(a, a + 1) > cap) return false;
+                uint32_t lo = a + 1, hi = H;                      // largest b with work(a, b) <= cap
+                while (lo < hi) { const uint32_t mid = lo + (hi - lo + 1) / 2; if (work(a, mid) <= cap) lo = mid; else hi = mid - 1; }
+                a = lo;
+            }
+        }
+        if (bounds) bounds[world] = H;
+        return a >= H;
+    };
+    double lo = 0.0, hi = work(0, H);
+    if (!(hi > 0.0)) {                                             // no work measured: equal rows
+        for (uint32_t p = 0; p <= world; p++) slab_row0[p] = (uint32_t)((uint64_t)H * p / world);
+        return BHRAY_OK;
+    }
+    for (int it = 0; it < 60 && hi - lo > 1e-9 * hi; it++) { const double mid = 0.5 * (lo + hi); if (pack(mid, nullptr)) hi = mid; else lo = mid; }
+    if (!pack(hi, slab_row0)) return BHRAY_E_STATE;
+    // the greedy packing front-loads: the last slabs may be short.  Spread the slack by a few rounds of moving each interior bound
+    // to the position that evens out its two neighbours (never beyond the cap found above).
+    for (int round = 0; round < 8; round++) {
+        for (uint32_t p = 1; p < world; p++) {
+            const uint32_t a = slab_row0[p - 1], b = slab_row0[p + 1];
+            if (b <= a + 1) continue;
+            uint32_t best = slab_row0[p]; double bestv = 1e300;
+            uint32_t l2 = a + 1, h2 = b - 1;                       // work(a, m) rises, work(m, b) falls with m: bisect to the crossing
+            if (h2 < l2) continue;
+            while (l2 < h2) { const uint32_t mid = l2 + (h2 - l2) / 2; if (work(a, mid) < work(mid, b)) l2 = mid + 1; else h2 = mid; }
+            for (uint32_t m = (l2 > a + 1 ? l2 - 1 : l2); m <= l2 && m < b; m++) {
+                const double v = std::max(work(a, m), work(m, b));
+                if (v < bestv) { bestv = v; best = m; }
+            }
+            slab_row0[p] = best;
+        }
+    }
+    return BHRAY_OK;
+}
+
 int bhray_comm_unique_id(uint8_t id[BHRAY_COMM_ID_BYTES]) {
     if (!id) return BHRAY_E_INVALID;
     Rccl* R = rccl();
@@ -445,6 +540,7 @@ int bhray_create(const bhray_config* cfg_in, bhray_ctx** out) {
     c->cfg.row_world = c->world;
     const uint32_t stripe = cfg->stripe_rows ? cfg->stripe_rows : 27;
     c->cfg.stripe_rows = stripe;
+    if (const char* why = partition_error(c->cfg, c->world)) FAIL(BHRAY_E_INVALID, "bad row partition: %s", why);
     c->parts.resize(c->world);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) FAIL(BHRAY_E_NO_DEVICE, "no HIP device visible (libbhray has no CPU path)");
@@ -452,7 +548,8 @@ int bhray_create(const bhray_config* cfg_in, bhray_ctx** out) {
     std::vector<int> rank_dev;
     for (uint32_t q = 0; q < c->world; q++) {
         Part& p = c->parts[q];
-        p.rows = part_rows(cfg->frame_h, c->world, stripe, q);
+        p.row_list = partition_row_list(c->cfg, c->world, q);
+        p.rows = (uint32_t)p.row_list.size();
         if (multi_dev) {
             if (cfg->devices[q] < 0 || cfg->devices[q] >= ndev) FAIL(BHRAY_E_NO_DEVICE, "device %d not present (%d visible)", cfg->devices[q], ndev);
             p.device = cfg->devices[q];
@@ -514,7 +611,7 @@ int bhray_create(const bhray_config* cfg_in, bhray_ctx** out) {
         if (q == c->root) continue;
         p.stage_row0 = row0;
         for (uint32_t i = 0; i < p.rows; i++) {
-            RowDesc d; d.src_row0 = (uint32_t)(row0 + i); d.part_rows = p.rows; d.frame_row = (uint32_t)part_row(c->world, stripe, q, i); d.pad = 0;
+            RowDesc d; d.src_row0 = (uint32_t)(row0 + i); d.part_rows = p.rows; d.frame_row = p.row_list[i]; d.pad = 0;
             table.push_back(d);
         }
         row0 += (size_t)c->B * p.rows;
@@ -749,8 +846,7 @@ int bhray_read_hdr_async(bhray_ctx* c, float* dst, size_t pitch, uint64_t* ticke
     if (!c->rendered) return gfail(c, BHRAY_E_STATE, "nothing rendered yet");
     { int rc = group_flush(c); if (rc) return rc; }
     const uint64_t t = c->read_tickets;
-    *ticket = t; c->read_tickets = t + 1;
-    if (!c->root_local) return BHRAY_OK;                        // the frame lives on another rank: nothing to copy here
+    if (!c->root_local) { *ticket = t; c->read_tickets = t + 1; return BHRAY_OK; }   // the frame lives on another rank: nothing to copy here
     const size_t rowb = (size_t)c->cfg.frame_w * sizeof(float4);
     if (!dst || pitch < rowb) return gfail(c, BHRAY_E_INVALID, "bad destination / pitch");
     Part& rp = *root_part(c);
@@ -765,6 +861,7 @@ int bhray_read_hdr_async(bhray_ctx* c, float* dst, size_t pitch, uint64_t* ticke
     if (pitch == rowb) GHIP(c, hipMemcpyAsync(dst, G.dst[c->last_sub], rowb * c->cfg.frame_h, hipMemcpyDeviceToHost, rr->stream));
     else GHIP(c, hipMemcpy2DAsync(dst, pitch, G.dst[c->last_sub], rowb, rowb, c->cfg.frame_h, hipMemcpyDeviceToHost, rr->stream));
     GHIP(c, hipEventRecord(ev, rr->stream));
+    *ticket = t; c->read_tickets = t + 1;                       // the ticket exists once its event does (an error above consumes none)
     GHIP(c, hipEventRecord(G.frame_done, rr->stream));
     GHIP(c, hipStreamWaitEvent(dev_slot_stream(rp.dev, c->last_slot), G.frame_done, 0));   // the root's next render into this slot writes its own rows into that frame
     return BHRAY_OK;
@@ -825,13 +922,16 @@ int bhray_import_external_fd(bhray_ctx* c, int fd, size_t bytes, void** dev_ptr)
     const int dev = c->single ? c->parts[0].device : (c->root_local ? root_part(c)->device : -1);
     if (dev < 0) return gfail(c, BHRAY_E_STATE, "this rank does not deliver the frame");
     GHIP(c, hipSetDevice(dev));
+    // the runtime owns an imported descriptor (CUDA semantics): hand it a duplicate, the caller keeps the original (include/bhray.h)
+    const int own = dup(fd);
+    if (own < 0) return gfail(c, BHRAY_E_INVALID, "dup(fd %d) failed: not an open descriptor", fd);
     hipExternalMemoryHandleDesc hd; memset(&hd, 0, sizeof hd);
     hd.type = hipExternalMemoryHandleTypeOpaqueFd;
-    hd.handle.fd = fd;
+    hd.handle.fd = own;
     hd.size = bytes;
     hipExternalMemory_t em = nullptr;
     hipError_t e = hipImportExternalMemory(&em, &hd);
-    if (e != hipSuccess) return gfail(c, BHRAY_E_HIP, "hipImportExternalMemory(fd %d, %zu bytes): %s", fd, bytes, hipGetErrorString(e));
+    if (e != hipSuccess) { (void)close(own); return gfail(c, BHRAY_E_HIP, "hipImportExternalMemory(fd %d, %zu bytes): %s", fd, bytes, hipGetErrorString(e)); }
     hipExternalMemoryBufferDesc bd; memset(&bd, 0, sizeof bd);
     bd.offset = 0; bd.size = bytes;
     void* p = nullptr;
@@ -967,6 +1067,15 @@ int bhray_get_level_counters(bhray_ctx* c, uint32_t level, bhray_counters* out) 
         const uint64_t* a = (const uint64_t*)&t; uint64_t* b = (uint64_t*)out;
         for (size_t k = 0; k < sizeof(bhray_counters) / 8; k++) { if (k == 12) b[k] = a[k] > b[k] ? a[k] : b[k]; else b[k] += a[k]; }   // [12] max_ray_iterations
     }
+    return BHRAY_OK;
+}
+
+int bhray_get_row_work(bhray_ctx* c, uint32_t level, uint64_t* out, uint32_t n) {
+    if (!c || !out) return BHRAY_E_INVALID;
+    if (level >= c->cfg.levels || n != c->cfg.level_h[level]) return gfail(c, BHRAY_E_INVALID, "level out of range, or n is not the level's height");
+    if (c->gather) { int rc = group_sync(c); if (rc) return rc; }
+    memset(out, 0, (size_t)n * sizeof(uint64_t));
+    for (Part& p : c->parts) if (p.dev) DEV(c, p.dev, dev_add_row_work(p.dev, level, out, n));
     return BHRAY_OK;
 }
 

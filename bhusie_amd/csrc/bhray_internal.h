@@ -96,7 +96,8 @@ enum : int { CLASSIFY_NORMAL = 0,
 
 // Speculative tracing of several levels in one launch: per-level geometry and destination, selected by the entry's tag.
 struct SpecLevel { int w, h; float4* out; int out_pitch; int out_x0; const int32_t* rowmap;    // rowmap/out_x0 as in LevelParams
-                   uint32_t* stamp; };   // temporal speculation: stamp[y*w + x] = FrameLaunch::stamp_value when the pixel is stored
+                   uint32_t* stamp;      // temporal speculation: stamp[y*w + x] = FrameLaunch::stamp_value when the pixel is stored
+                   unsigned long long* row_work; };   // counting builds: as FrameLaunch::row_work, for this level
 struct SpecLevels { int n; SpecLevel l[BHRAY_MAX_SPEC_LEVELS]; };   // n == 0: one level, described by LevelParams
 
 struct Counters64 { unsigned long long v[13]; };   // order = bhray_counters
@@ -157,6 +158,7 @@ struct FrameLaunch {
     uint32_t* queue;       // ray queue of this frame and level(s)
     uint32_t* qctl;        // [0] entries appended (classify), [1] entries taken (trace)
     Counters64* counters;  // nullptr unless BHRAY_F_COUNTERS
+    unsigned long long* row_work;   // counting builds: row_work[y] += iterations of every ray traced for level row y (bhray_get_row_work); nullptr: off
     // temporal speculation (BHRAY_F_TEMPORAL): the exact classification records every pixel that needs tracing for the NEXT frame's
     // predicted launch, and sends to this frame's queue only those the predicted launch has not traced already
     uint8_t* need;         // this level's per-pixel mark "the shader traces this pixel" (written by the exact classification, read by predict_kernel)

@@ -264,13 +264,10 @@ __device__ __forceinline__ bool hit_triangle(F3 pos, F3 dir, float t_min, float 
 // LDS (north_star: "LDS-staged triangle/node tiles"):
 //   BHRAY_BVH_LDS_STACK  entries of the short traversal stack (entry k of lane t at [k * threads + t]: conflict-free 8-byte accesses);
 //                        see "The traversal stack" below.
-//   BHRAY_BVH_LDS_TOP    optional, off: the first N nodes of the breadth-first order copied into LDS once per block (measured in round
-//                        2: no gain, the top of the tree is L1/L2-resident anyway - profiles/EXPERIMENTS.md).
+//   (The first N nodes of the breadth-first order staged in LDS once per block were built and measured in round 2: no gain, the top
+//   of the tree is L1/L2-resident anyway - profiles/EXPERIMENTS.md; removed in round 4.)
 #ifndef BHRAY_TRACE_THREADS
 #define BHRAY_TRACE_THREADS 256  // threads per persistent trace block (a multiple of 64; 64 / 128 / 512 measured slower: DESIGN.md §4)
-#endif
-#ifndef BHRAY_BVH_LDS_TOP
-#define BHRAY_BVH_LDS_TOP 0
 #endif
 #ifndef BHRAY_BVH_LDS_STACK
 #define BHRAY_BVH_LDS_STACK 8      // entries of the short traversal stack in LDS (16 KB per 256-thread block: 8 blocks per CU fit in 160 KB)
@@ -278,7 +275,7 @@ __device__ __forceinline__ bool hit_triangle(F3 pos, F3 dir, float t_min, float 
 #ifndef BHRAY_MODEL_INLINE
 #define BHRAY_MODEL_INLINE __noinline__      // the traversal as a call (measured against __forceinline__: profiles/EXPERIMENTS.md R3.6)
 #endif
-struct BvhLds { const float4* nodes; int node_count; int2* stack; };     // stack: this lane's column (entry k at stack[k * BHRAY_TRACE_THREADS])
+struct BvhLds { int2* stack; };     // stack: this lane's column (entry k at stack[k * BHRAY_TRACE_THREADS])
 
 // The traversal stack.  The reference stacks 19 whole nodes and has no overflow check (ray.wgsl:292,327); round 2 kept 64 two-word entries
 // per lane in scratch - 512 bytes per lane, 42 MB of scratch writes per 1080p launch.  Now: a SHORT stack of BHRAY_BVH_LDS_STACK entries
@@ -309,14 +306,8 @@ __device__ BHRAY_MODEL_INLINE void trace_ray_model(const ModelDev& M, const BvhL
         bool pop = false;
         if (obj_count == 0) {
             if (lev >= BHRAY_BVH_STACK) { *err = BHRAY_E_BVH_DEPTH; break; }
-            float4 a_lo, a_hi, b_lo, b_hi;
-            if (BHRAY_BVH_LDS_TOP > 0 && contents + 1 < lds.node_count) {
-                const float4* pair = lds.nodes + 2 * contents;
-                a_lo = pair[0]; a_hi = pair[1]; b_lo = pair[2]; b_hi = pair[3];
-            } else {
-                const float4* pair = M.nodes + 2 * (size_t)contents;
-                a_lo = pair[0]; a_hi = pair[1]; b_lo = pair[2]; b_hi = pair[3];
-            }
+            const float4* pair = M.nodes + 2 * (size_t)contents;
+            const float4 a_lo = pair[0], a_hi = pair[1], b_lo = pair[2], b_hi = pair[3];
             float d1 = hit_aabb(pos, inv, a_lo, a_hi, mpos);
             float d2 = hit_aabb(pos, inv, b_lo, b_hi, mpos);
             int2 n1 = make_int2(__float_as_int(a_lo.w), __float_as_int(a_hi.w));
@@ -424,7 +415,7 @@ __device__ __forceinline__ F3 fnormalize_rn(F3 a) {
 // == bh_pow_m001(x) (bhray_math.h) for every x > 0.00002f, the only values next_ray_rk passes (all of them, +inf included, checked
 // by bhray_selftest).  The portable form's NaN / negative / zero / denormal arms are dead there, +inf becomes a select, and the
 // quotient (m - 1) / (m + 1), m + 1 in [1.70, 2.42], is the short correctly rounded sequence: reciprocal, product, one residual
-// correction: 63 -> 46 instructions.  (The arm is rare - 0.3 % of the wave-steps of a 1080p frame, -DBHRAY_EXP_POWSTAT - so what
+// correction: 63 -> 46 instructions.  (The arm is rare - 0.3 % of the wave-steps of a 1080p frame, counted in round 2 - so what
 // its length buys is code layout: +0.6 % at saturation, measured.)
 __device__ __forceinline__ float pow_m001_step(float x) {
     const uint32_t u = f2u(x);
@@ -810,266 +801,18 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #define BHRAY_REFILL_MIN 16      // refill from the queue (one atomic on its head + a dependent load) only when this many lanes are empty, or nobody is
                                  // stepping: measured 1 / 8 / 16 / 24 / 32 / 48 -> 5 357 / 5 428 / 5 435 / 5 414 / 5 387 / 5 254 Mrays/s (Euler 8 009 -> 8 148 at 16)
 #endif
-#ifndef BHRAY_FUSED_CLAIM_LAST
-#define BHRAY_FUSED_CLAIM_LAST 32      // fused ladder: smallest claim on the LAST level's ray queue (340 k rays at 1080p: claims of 4 are 85 k atomics on one word)
-#endif
-#ifndef BHRAY_FUSED_SLOT_SLEEP
-#define BHRAY_FUSED_SLOT_SLEEP 2        // x s_sleep(127) (~3.4 us each) between the slot polls of a wave that only waits
-#endif
-// Two refinements that were built and measured (one 1080p frame at a time, 2 blocks per CU; profiles/EXPERIMENTS.md): idle tracers helping
-// with bursts of tile items (2.09 -> 2.52 ms: their polls of the ring cost more than the help is worth) and second-tier tracers that join
-// only when a level holds a bulk of rays (2.09 -> 2.10 ms).  Both stay in the source, off.
-#ifndef BHRAY_FUSED_HELPERS
-#define BHRAY_FUSED_HELPERS 0
-#endif
-#ifndef BHRAY_FUSED_TIERS
-#define BHRAY_FUSED_TIERS 0
-#endif
-#ifndef BHRAY_FUSED_BULK
-#define BHRAY_FUSED_BULK 4096           // fused ladder: entries a level's queue must hold before the second-tier tracers join
-#endif
-#ifndef BHRAY_FUSED_TICKETS
-#define BHRAY_FUSED_TICKETS 4          // fused ladder: tile-ring tickets a classifier takes with one atomic
-#endif
-#ifndef BHRAY_FUSED_RAYS_AHEAD
-#define BHRAY_FUSED_RAYS_AHEAD 512    // fused ladder: slots of a level's ray queue that idle lanes may hold beyond the published entries
+#ifndef BHRAY_WITH_FUSED
+#define BHRAY_WITH_FUSED 0       // 1 (make fused -> libbhray_fused.so): the fused ladder, BHRAY_F_FUSED - measured slower than the launch-per-level ladder, a tested option
 #endif
 #ifndef BHRAY_HIT_LDS
 #define BHRAY_HIT_LDS 1         // dense build: "a hit happened" in the cold LDS state rather than an SGPR pair merged at every join of the step loop (+0.3 %, A/B in two sessions: profiles/EXPERIMENTS.md R3.9)
 #endif
-#ifndef BHRAY_MAILBOX_T
-#define BHRAY_MAILBOX_T 0        // drain merging (measured, off: DESIGN.md §4): a wave with this many live rays or fewer parks them; 0 disables
+
+#if BHRAY_WITH_FUSED
+#define BHRAY_FUSED_PART 0
+#include "bhray_fused.inc"
+#undef BHRAY_FUSED_PART
 #endif
-
-// ------------------------------------------------------------------------------------------
-// fused ladder (BHRAY_F_FUSED; structures and protocol: bhray_internal.h)
-// ------------------------------------------------------------------------------------------
-// Every word another workgroup reads or writes is an 8-byte (or 4-byte) agent-scope atomic on BOTH sides: such accesses bypass the
-// per-CU L1 and are coherent between the XCDs' L2s (MI355X_MICROARCH.md: "8-B agent atomics both sides"); no fences are needed.
-#define BHRAY_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-__device__ __forceinline__ unsigned long long ld_u64_agent(const unsigned long long* p) { return __hip_atomic_load(p, BHRAY_RLX_AGENT); }
-__device__ __forceinline__ void st_u64_agent(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, BHRAY_RLX_AGENT); }
-__device__ __forceinline__ uint32_t ld_u32_agent(const uint32_t* p) { return __hip_atomic_load(p, BHRAY_RLX_AGENT); }
-__device__ __forceinline__ void st_u32_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, BHRAY_RLX_AGENT); }
-__device__ __forceinline__ float4 ld_px_agent(const float4* p) {
-    const unsigned long long a = ld_u64_agent(reinterpret_cast<const unsigned long long*>(p));
-    const unsigned long long b = ld_u64_agent(reinterpret_cast<const unsigned long long*>(p) + 1);
-    return make_float4(u2f((uint32_t)a), u2f((uint32_t)(a >> 32)), u2f((uint32_t)b), u2f((uint32_t)(b >> 32)));
-}
-__device__ __forceinline__ void st_px_agent(float4* p, float4 v) {
-    st_u64_agent(reinterpret_cast<unsigned long long*>(p), (unsigned long long)f2u(v.x) | ((unsigned long long)f2u(v.y) << 32));
-    st_u64_agent(reinterpret_cast<unsigned long long*>(p) + 1, (unsigned long long)f2u(v.z) | ((unsigned long long)f2u(v.w) << 32));
-}
-// every vector memory operation of this wave has completed (write-through stores included): what must precede the publication of a
-// counter / queue entry that tells another workgroup the data is there.  Inline asm: the compiler may drop a builtin wait.
-__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
-    return (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
-}
-__device__ __forceinline__ void drain_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// Takes up to `want` items of the half-open range [*head, *tail) - ONE lane calls.  `tail` only grows; a CAS bounded by it never
-// reserves an item no producer has reserved (an unbounded atomicAdd would leave lanes waiting for entries that never come).
-__device__ __forceinline__ uint32_t take_bounded(uint32_t* head, const uint32_t* tail, uint32_t want, uint32_t& first) {
-    uint32_t h = ld_u32_agent(head);
-    for (;;) {
-        const uint32_t t = ld_u32_agent(tail);
-        if (h >= t) return 0u;
-        const uint32_t n = want < t - h ? want : t - h;
-        const uint32_t seen = atomicCAS(head, h, h + n);
-        if (seen == h) { first = h; return n; }
-        h = seen;
-    }
-}
-// lanes with `ready` publish tile `ft` as a classify item (wave-uniform call)
-__device__ __forceinline__ void fused_push_tiles(const FusedFrame& Z, bool ready, uint32_t ft, int lane) {
-    const unsigned long long m = __ballot(ready);
-    if (m == 0ull) return;
-    const int leader = (int)__builtin_ctzll(m);
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(&Z.ctl->cq_tail.v, (uint32_t)__popcll(m));
-    base = (uint32_t)__shfl((int)base, leader);
-    if (ready) st_u64_agent(&Z.cq[base + lanes_below(m)], ((unsigned long long)Z.stamp << 32) | ft);
-}
-// Tile `tile` (a global tile id of level l) is FINAL: every pixel of it has been stored.  Its dependents at level l+1 lose one
-// dependency each (the lanes take one dependent each); those that have none left become classify items.  Wave-uniform call.
-__device__ __forceinline__ void fused_tile_final(const FusedFrame& Z, int l, uint32_t tile, int lane, uint32_t* batched_final = nullptr) {
-    const FusedLevel& V = Z.lv[l];
-    if (l + 1 < Z.nl) {
-        const FusedLevel& W = Z.lv[l + 1];
-        const uint32_t t = tile - V.tile_base, tx = t % V.tiles_x, ty = t / V.tiles_x;
-        const uint32_t x0 = V.nx_off[tx], nx = V.nx_off[tx + 1] - x0, y0 = V.ny_off[ty], ny = V.ny_off[ty + 1] - y0;
-        const uint32_t n = nx * ny;
-        for (uint32_t k0 = 0; k0 < n; k0 += 64u) {
-            const uint32_t k = k0 + (uint32_t)lane;
-            bool ready = false; uint32_t ft = 0;
-            if (k < n) {
-                ft = W.tile_base + (uint32_t)V.ny_list[y0 + k / nx] * W.tiles_x + (uint32_t)V.nx_list[x0 + k % nx];
-                ready = atomicSub(&Z.deps[ft], 1u) == 1u;
-            }
-            fused_push_tiles(Z, ready, ft, lane);
-        }
-    }
-    if (batched_final) { (*batched_final)++; return; }          // a classifier counts its final tiles and reports them in batches (fused_flush)
-    if (lane == 0 && atomicSub(&Z.ctl->tiles_left.v, 1u) == 1u) st_u32_agent(&Z.ctl->done.v, 1u);
-}
-// A classifier's batched bookkeeping: tiles it processed per level (closes the level's ray queue when the last one is in: every
-// producer's reservation precedes its own report, so the reserve counter read by whoever brings the count to zero is final) and tiles
-// it made final.  One atomic per word per batch instead of one per tile: 43 000 tiles per 1080p frame on one word are half a
-// millisecond of that word's L2 channel.
-__device__ __forceinline__ void fused_flush(const FusedFrame& Z, uint32_t (&processed)[BHRAY_MAX_SPEC_LEVELS], uint32_t& finals, int lane) {
-    if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < BHRAY_MAX_SPEC_LEVELS; q++) {
-            if (processed[q] != 0u && atomicSub(&Z.ctl->rq[q].unprocessed.v, processed[q]) == processed[q])
-                st_u32_agent(&Z.ctl->rq[q].final.v, ld_u32_agent(&Z.ctl->rq[q].reserve.v) + 1u);
-        }
-        if (finals != 0u && atomicSub(&Z.ctl->tiles_left.v, finals) == finals) st_u32_agent(&Z.ctl->done.v, 1u);
-    }
-#pragma unroll
-    for (int q = 0; q < BHRAY_MAX_SPEC_LEVELS; q++) processed[q] = 0u;
-    finals = 0u;
-}
-// The rays a tile queued have all stored their pixels (pending reached 0).  Level 0 and the levels that are classified normally: the
-// tile is final.  A speculative level >= 1: its traced values are complete, which was the tile's own dependency for its classification.
-__device__ __forceinline__ void fused_rays_done(const FusedFrame& Z, int l, uint32_t tile, int lane) {
-    if (Z.lv[l].all_traced && l > 0) {
-        bool ready = false;
-        if (lane == 0) ready = atomicSub(&Z.deps[tile], 1u) == 1u;
-        fused_push_tiles(Z, ready, tile, lane);
-    } else {
-        fused_tile_final(Z, l, tile, lane);
-    }
-}
-// publishes the rays of one tile (lanes with `want`) in level l's ray queue; returns their number (wave-uniform call)
-__device__ __forceinline__ uint32_t fused_push_rays(const FusedFrame& Z, int l, uint32_t tile, bool want, uint32_t pix, int lane) {
-    const unsigned long long m = __ballot(want);
-    const uint32_t cnt = (uint32_t)__popcll(m);
-    if (cnt == 0u) return 0u;
-    // the tile's pixel stores have completed (caller: drain_vm) and its pending count is in place BEFORE any ray can be taken
-    uint32_t base = 0;
-    if (lane == 0) {
-        if (l != Z.nl - 1) { st_u32_agent(&Z.pending[tile], cnt); drain_vm(); }     // (nobody depends on a last-level tile: its rays are not counted)
-        base = atomicAdd(&Z.ctl->rq[l].reserve.v, cnt);
-    }
-    base = (uint32_t)__shfl((int)base, 0);
-    if (want) st_u64_agent(&Z.lv[l].rq[base + lanes_below(m)], ((unsigned long long)Z.stamp << 32) | pix);
-    return cnt;
-}
-// One work item of the tile ring: `enqueue_all` - every pixel of a tile of an all-traced level becomes a ray; otherwise the
-// classification of ray.wgsl:167-243 for the tile's 64 pixels (one lane each), exactly as classify_kernel decides (same operations on
-// the same values), with the coarser level read through agent-scope loads.  Wave-uniform call by a wave that holds no rays.
-template <bool COUNT>
-__device__ __forceinline__ void fused_process_tile(const FrameParams& P, const FusedFrame& Z, int l, uint32_t tile, bool enqueue_all, int lane,
-                                                   uint32_t (&processed)[BHRAY_MAX_SPEC_LEVELS], uint32_t& finals) {
-    const FusedLevel& V = Z.lv[l];
-    const LevelParams& L = V.L;
-    const uint32_t t = tile - V.tile_base, tx = t % V.tiles_x, ty = t / V.tiles_x;
-    const int x = L.x0 + (int)tx * 8 + (lane & 7), j = (int)ty * 8 + (lane >> 3);
-    const bool valid = x < L.x1 && j < L.nrows;
-    const int y = valid ? L.rows[j] : 0;
-    const bool last = l == Z.nl - 1;
-    bool need_trace = false;
-    int kind = -1;
-    if (valid) {
-        if (enqueue_all) {
-            need_trace = true; kind = 2;
-        } else {
-            const float ppx = (float)x * L.rx, ppy = (float)y * L.ry;
-            const float tlx = floorf(ppx), tly = floorf(ppy);
-            auto ldp = [&](int cx, int cy) {
-                cx = cx < 0 ? 0 : (cx > L.pw - 1 ? L.pw - 1 : cx);
-                cy = cy < 0 ? 0 : (cy > L.ph - 1 ? L.ph - 1 : cy);
-                return ld_px_agent(L.prev + ((size_t)cy * (size_t)L.pw + (size_t)cx));
-            };
-            auto store = [&](float4 v) {
-                float4* dst = L.out + out_index(L, x, y);
-                if (last) *dst = v; else st_px_agent(dst, v);
-            };
-            const float4 c_tl = ldp((int)tlx, (int)tly);
-            if (fabsf(tlx - ppx) < 0.001f && fabsf(tly - ppy) < 0.001f) {
-                store(c_tl); kind = 0;
-            } else {
-                const float4 c_bl = ldp((int)tlx, (int)(tly + 1.0f));
-                const float4 c_tr = ldp((int)(tlx + 1.0f), (int)tly);
-                const float4 c_br = ldp((int)(tlx + 1.0f), (int)(tly + 1.0f));
-                const bool alphas0 = c_tl.w == 0.0f && c_tr.w == 0.0f && c_bl.w == 0.0f && c_br.w == 0.0f;
-                bool interp = false;
-                if (alphas0) {
-                    const float cs = P.acos_cstar;
-                    interp = cosine_below_threshold(angle_cosine(c_bl, c_tl), cs) && cosine_below_threshold(angle_cosine(c_br, c_tr), cs) &&
-                             cosine_below_threshold(angle_cosine(c_tl, c_tr), cs) && cosine_below_threshold(angle_cosine(c_bl, c_br), cs);
-                }
-                if (interp) {
-                    const float tx_ = ppx - tlx, ty_ = ppy - tly;
-                    const F3 top = mix3(f3(c_tl.x, c_tl.y, c_tl.z), f3(c_tr.x, c_tr.y, c_tr.z), tx_);
-                    const F3 bot = mix3(f3(c_bl.x, c_bl.y, c_bl.z), f3(c_br.x, c_br.y, c_br.z), tx_);
-                    const F3 p = mix3(top, bot, ty_);
-                    store(make_float4(p.x, p.y, p.z, 0.0f)); kind = 1;
-                } else {
-                    need_trace = true; kind = 2;
-                    if (L.spec) {                    // a speculative level: the traced value exists (its rays were this tile's own dependency)
-                        store(ld_px_agent(L.spec + ((size_t)y * (size_t)L.w + (size_t)x)));
-                        need_trace = false;
-                    }
-                }
-            }
-        }
-    }
-    if (COUNT && !enqueue_all && V.counters) {
-        const unsigned long long nv = __popcll(__ballot(valid)), nc = __popcll(__ballot(kind == 0)), ni = __popcll(__ballot(kind == 1));
-        if (lane == 0) { atomicAdd(&V.counters->v[0], nv); atomicAdd(&V.counters->v[1], nc); atomicAdd(&V.counters->v[2], ni); }
-    }
-    if (COUNT && enqueue_all && l == 0 && Z.ns == 0 && V.counters) {     // level 0's pixels are all traced pixels: counted as the classify kernel counts them (it does not in speculative mode)
-        const unsigned long long nv = __popcll(__ballot(valid));
-        if (lane == 0) atomicAdd(&V.counters->v[0], nv);
-    }
-    drain_vm();                                      // this wave's pixel stores are complete before anything announces them
-    const uint32_t pix = ((uint32_t)l << 30) | ((uint32_t)y << 15) | (uint32_t)x;
-    const uint32_t cnt = fused_push_rays(Z, l, tile, need_trace, pix, lane);
-    if (enqueue_all || !V.all_traced) {                 // (a speculative level's queue closes with its enqueue-all items; its classify items queue nothing)
-#pragma unroll
-        for (int q = 0; q < BHRAY_MAX_SPEC_LEVELS; q++) if (q == l) processed[q]++;
-    }
-    if (cnt == 0u || last) {                                       // a last-level tile counts as final once it is classified: nothing depends on it,
-        if (enqueue_all && !last) fused_rays_done(Z, l, tile, lane);  // and the launch itself ends only when the last level's queue has been traced
-        else fused_tile_final(Z, l, tile, lane, &finals);
-    }
-}
-
-// Serves ticket `tk` of the tile ring: resolves it to its item (an implicit enqueue-all item, or the classify item published at that
-// position - waiting for it if it is not there yet, after reporting what this wave has done so far: others may be waiting for that),
-// processes it.  false: the item never came (a bug, reported as BHRAY_E_STATE by the caller).  Wave-uniform.
-template <bool COUNT>
-__device__ __forceinline__ bool fused_serve(const FrameParams& P, const FusedFrame& Z, uint32_t tk, int lane,
-                                            uint32_t (&processed)[BHRAY_MAX_SPEC_LEVELS], uint32_t& finals, uint32_t& unflushed) {
-    uint32_t tile; int l = 0; bool enqueue_all;
-    if (tk < Z.n_initial) {
-#pragma unroll
-        for (int q = 0; q < BHRAY_MAX_SPEC_LEVELS - 1; q++) if (q + 1 < Z.nl && tk >= Z.init_end[q]) l = q + 1;
-        tile = Z.lv[l].tile_base + (tk - (l > 0 ? Z.init_end[l - 1] : 0u));
-        enqueue_all = true;
-    } else {
-        unsigned long long e = uniform_u64(ld_u64_agent(&Z.cq[tk]));
-        if ((uint32_t)(e >> 32) != Z.stamp) {
-            if (unflushed != 0u) { fused_flush(Z, processed, finals, lane); unflushed = 0u; }
-            int polls = 0;
-            for (;;) {                                   // the item this ticket stands for: published when its tile's last dependency resolves
-                e = uniform_u64(ld_u64_agent(&Z.cq[tk]));   // (one address for the whole wave: keep the loop's exit wave-uniform for the compiler too)
-                if ((uint32_t)(e >> 32) == Z.stamp) break;
-                polls++;
-                if (polls < 4) __builtin_amdgcn_s_sleep(16); else if (polls < 16) __builtin_amdgcn_s_sleep(64); else __builtin_amdgcn_s_sleep(127);
-                if (polls > (1 << 21)) return false;
-            }
-        }
-        tile = (uint32_t)e;
-#pragma unroll
-        for (int q = 1; q < BHRAY_MAX_SPEC_LEVELS; q++) if (q < Z.nl && tile >= Z.lv[q].tile_base) l = q;
-        enqueue_all = false;
-    }
-    fused_process_tile<COUNT>(P, Z, l, tile, enqueue_all, lane, processed, finals);
-    if (++unflushed >= 8u) { fused_flush(Z, processed, finals, lane); unflushed = 0u; }
-    return true;
-}
 
 // Cold per-lane ray state: values the integrator step loop reads or writes only on its rare paths (sphere exit, an actual hit)
 // or not at all (the pixel id) — 8 words per lane.  The dense build (6 waves per SIMD = 80 VGPRs) keeps them in LDS, one word
@@ -1107,9 +850,6 @@ template <> struct ColdState<true> {
     __device__ __forceinline__ void set_hit(bool v) { b[8 * S] = v ? 1.0f : 0.0f; }
 };
 
-#ifdef BHRAY_EXP_PROFILE
-__device__ long long xp_dump[8192 * 16];
-#endif
 template <int METHOD, bool MODELS, bool COUNT, bool DENSE, int EVAL = 0, bool FUSED = false>
 __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHRAY_TRACE_WAVES_DENSE : BHRAY_TRACE_WAVES)) void trace_kernel(const FrameParams* __restrict__ Pb, const FrameLaunch* __restrict__ Fb, const int nb, int* __restrict__ err_flag) {
     const int lane = threadIdx.x & 63;
@@ -1123,91 +863,26 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
 #endif
     constexpr bool COLD_LDS = DENSE && !MODELS;
     __shared__ float cold_lds[COLD_LDS ? (8 + BHRAY_HIT_LDS) * BHRAY_TRACE_THREADS : 1];
-    // mesh variant: optional LDS staging of the top of the BVH and of the shallow part of the traversal stacks (trace_ray_model)
-    constexpr int BVH_TOP = MODELS ? BHRAY_BVH_LDS_TOP : 0;
+    // mesh variant: the short traversal stacks (trace_ray_model) live in LDS
     // (dynamic LDS: with a static array the compiler assumes 64 KB of LDS per CU - gfx950 has 160 KB -, concludes that occupancy is
     // LDS-limited and gives up the 64-VGPR budget of 8 waves per SIMD: 142-152 VGPRs, 3 waves)
     extern __shared__ float4 bvh_dyn_lds[];
-    float4* bvh_top = bvh_dyn_lds;
-    int2* bvh_stack = reinterpret_cast<int2*>(bvh_dyn_lds + 2 * BVH_TOP);
-    BvhLds bvh_lds; bvh_lds.nodes = bvh_top; bvh_lds.node_count = 0; bvh_lds.stack = bvh_stack + threadIdx.x;
-    if (BVH_TOP > 0) {
-        const ModelDev& M0 = Pb[0].models[0];                      // one model per ctx (BHRAY_MAX_MODELS), constant over a batch
-        const int n = (Pb[0].model_count > 0 && M0.node_count > 0) ? (M0.node_count < BVH_TOP ? M0.node_count : BVH_TOP) : 0;
-        for (int i = threadIdx.x; i < 2 * n; i += BHRAY_TRACE_THREADS) bvh_top[i] = M0.nodes[i];
-        bvh_lds.node_count = n;
-        __syncthreads();
-    }
-    // Drain merging (dense build).  Once a launch's queue has run dry its waves finish their rays at ever lower lane occupancy
-    // (16 % of the lane-steps of a 1080p frame).  A wave left with <= MB_T live rays parks them - the whole per-ray state, 36 words -
-    // in the block's LDS mailbox and exits; waves of the same block with empty lanes adopt parked rays at their next refill.  A ray is
-    // the same sequence of operations whichever lane runs it, so pixels do not change.  Protocol (LDS atomics by lane 0):
-    //   alive    waves of the block that have not left; a donor leaves only if somebody stays (it decrements alive and reverts if
-    //            it was the last), the last wave never parks and adopts whatever is still parked before it leaves;
-    //   pending  donors between their reservation and their publication - raised BEFORE alive is decremented, so the last wave,
-    //            which got there after the donor, sees it and waits;
-    //   reserved / ready / taken  slots handed to donors / published / claimed by adopters (each wave parks at most once: <= 3 x MB_T).
-    // Only in the last frame of a batch (waves of a block walk the frames in the same order, so the parked rays' frame is the frame
-    // every later wave ends on).
-    constexpr int MB_T = BHRAY_MAILBOX_T, MB_CAP = 3 * MB_T, MB_WORDS = 36;
-    constexpr bool MAILBOX = COLD_LDS && MB_T > 0 && BHRAY_TRACE_THREADS > 64;
-    __shared__ int mb_ctl[8];                                   // [0] alive [1] pending [2] reserved [3] ready [4] taken
-    __shared__ float mb_state[MAILBOX ? MB_WORDS * MB_CAP : 1]; // word w of slot k at [w * MB_CAP + k]
-    if (MAILBOX) {
-        if (threadIdx.x < 8) mb_ctl[threadIdx.x] = threadIdx.x == 0 ? (int)(blockDim.x >> 6) : 0;
-        __syncthreads();
-    }
+    BvhLds bvh_lds; bvh_lds.stack = reinterpret_cast<int2*>(bvh_dyn_lds) + threadIdx.x;
+    constexpr bool FZ = BHRAY_WITH_FUSED && FUSED;      // the fused ladder is a build option (make fused): bhray_fused.inc
+#if BHRAY_WITH_FUSED
+#define BHRAY_FUSED_PART 1
+#include "bhray_fused.inc"
+#undef BHRAY_FUSED_PART
+#endif
     // the frames of the batch, starting with this block's own: a block whose frame has run dry helps with the others
-    // FUSED, tile work.  ONE wave of every block (a different SIMD from block to block) is a CLASSIFIER: it serves the tile ring of one
-    // frame of the batch - a ticket per item (one unconditional atomicAdd), then it waits for THAT item and processes it: enqueue-all
-    // items of the all-traced levels first (ring positions below n_initial are implicit), then classify items as tile dependencies
-    // resolve.  The number of classifiers is fixed, so however far their tickets run ahead of what has been published, the other
-    // waves are there to trace the rays the items wait for; and an item on the critical path is served the moment it is published,
-    // by a wave that does nothing else.  When the ring's known total (n_items) is handed out the classifier becomes a tracer.
-    if (FUSED) {
-        const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform, and the compiler must know it
-        if (wave_in_block == (blockIdx.x & (BHRAY_TRACE_THREADS / 64 - 1))) {
-            const int fb = (int)(blockIdx.x % (unsigned)nb);
-            const FrameParams& P = Pb[fb];
-            const FusedFrame& Z = *Fb[fb].fz;
-#ifdef BHRAY_EXP_PROFILE
-            const long long xc_t0 = clock64(); long long xc_wait = 0; int xc_items = 0;
-#endif
-            uint32_t processed[BHRAY_MAX_SPEC_LEVELS] = {0u, 0u, 0u, 0u}, finals = 0u, unflushed = 0u;
-            uint32_t tk_next = 0u, tk_end = 0u;                  // tickets in hand: [tk_next, tk_end)
-            for (;;) {
-                if (tk_next == tk_end) {
-                    uint32_t t0 = 0;
-                    if (lane == 0) t0 = atomicAdd(&Z.ctl->cq_head.v, (uint32_t)BHRAY_FUSED_TICKETS);
-                    tk_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)t0); tk_end = tk_next + (uint32_t)BHRAY_FUSED_TICKETS;
-                }
-                const uint32_t tk = tk_next++;
-                if (tk >= Z.n_items) break;
-                if (!fused_serve<COUNT>(P, Z, tk, lane, processed, finals, unflushed)) { err = BHRAY_E_STATE; break; }
-#ifdef BHRAY_EXP_PROFILE
-                xc_items++;
-#endif
-            }
-            fused_flush(Z, processed, finals, lane);
-#ifdef BHRAY_EXP_PROFILE
-            if (lane == 0) {
-                long long* d = xp_dump + (size_t)(blockIdx.x * (BHRAY_TRACE_THREADS / 64) + (threadIdx.x >> 6)) * 16;
-                d[13] = clock64() - xc_t0; d[14] = xc_wait; d[15] = xc_items;
-            }
-#endif
-        }
-    }
-    // FUSED: a wave keeps cycling over the batch's frames until it has seen every one of them complete (FusedCtl::done); it leaves a
-    // frame in which it holds no ray and finds no work, and comes back later
-    uint32_t fused_done_mask = 0u;
-    int fused_idle = 0;                           // consecutive polls that found nothing (back-off; survives the hop to another frame)
-    for (int fi = 0; FUSED || fi < nb; fi++) {
+    for (int fi = 0; FZ || fi < nb; fi++) {
     const int fb = (int)((blockIdx.x + (unsigned)fi) % (unsigned)nb);
-    const bool last_frame = fi == nb - 1;
-    if (FUSED) {
+#if BHRAY_WITH_FUSED
+    if (FZ) {
         if (fused_done_mask == (nb >= 32 ? 0xffffffffu : ((1u << nb) - 1u))) break;
         if (fused_done_mask & (1u << fb)) continue;
     }
+#endif
     const FrameParams& P = Pb[fb];
     const FrameLaunch& F = Fb[fb];
     const LevelParams& L = F.L;
@@ -1259,163 +934,24 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
 #define HIT_SET(v) do { if (HIT_IN_LDS) cold.set_hit(v); else hit = (v); } while (0)
 #define HIT_GET() (HIT_IN_LDS ? cold.hit() : (bool)hit)
     bool exhausted = false;
-    const bool fused_tier1 = !BHRAY_FUSED_TIERS || (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == ((blockIdx.x + 1u) & (BHRAY_TRACE_THREADS / 64 - 1));
-    int fused_wait_round = 0, fused_lo = 0, fused_skip = 0, fused_backoff = 0;     // FUSED tracer: rounds waited on slots; first level still worth a look; rounds until the next look at the queues   // FUSED: this wave's outstanding ticket of the tile ring
-    uint32_t fused_tile = 0; int fused_lv = 0; bool fused_fin = false;      // FUSED: the tile the ray that has just finished belongs to
+#if BHRAY_WITH_FUSED
+    int fused_wait_round = 0, fused_lo = 0, fused_skip = 0, fused_backoff = 0;     // fused tracer: rounds waited on slots; first level still worth a look; rounds until the next look at the queues
+    uint32_t fused_tile = 0; int fused_lv = 0; bool fused_fin = false;      // fused: the tile the ray that has just finished belongs to
+#endif
     int flat_round = 0;
-    unsigned long long cnt[13];           // [0..9] = bhray_counters' frame counters, [10] wave steps (lane 0), [11] rays adopted, [12] longest ray
+    unsigned long long cnt[13];           // [0..9] = bhray_counters' frame counters, [10] wave steps (lane 0), [11] unused (rays adopted by the drain merging of round 2), [12] longest ray
     if (COUNT) { for (int k = 0; k < 13; k++) cnt[k] = 0; }
 
-#ifdef BHRAY_EXP_PROFILE                  // timing-only build: where does the time of one wave go? (profiles/r02_experiments.json: lone_wave_phases)
-    long long xp_t0 = clock64(), xp_last = xp_t0, xp_t[5] = {0, 0, 0, 0, 0}, xp_idle = 0; int xp_c[5] = {0, 0, 0, 0, 0}, xp_n = 0, xp_rounds = 0;
-#define XP(k, active) { const long long now_ = clock64(); xp_t[k] += now_ - xp_last; xp_last = now_; xp_c[k] += (active) ? 1 : 0; }
-#else
-#define XP(k, active)
-#endif
-#ifdef BHRAY_EXP_PROFILE_FINE
-    long long xf_prev = clock64(), xf_loop = 0, xf_step = 0, xf_cull = 0, xf_tail = 0;
-#endif
     for (;;) {
-#ifdef BHRAY_EXP_PROFILE
-        xp_rounds++;
-        const bool xp_refill = __any(mode == M_EMPTY);
-#endif
         // ---- refill finished lanes from the queue (wave ballot + prefix popcount)
-        if (FUSED) {
-            const FusedFrame& Z = *F.fz;
-            // Rays are handed out by TICKETS: one unconditional atomicAdd on the level's head for a few slots (a compare-and-swap bounded by
-            // the producers' counter turns into a storm of failing atomics when a thousand idle waves see the same new entries).  Waves
-            // that saw the same entries may take slots beyond what has been published; such a lane waits on ITS OWN slot (M_WAIT) - an
-            // address nobody else polls - while the wave's other rays keep stepping, and gives the slot up when the level has closed
-            // (every tile of it processed: rq.final) below its index, or when the slot lies beyond the level's pixel count.
-            const auto start_ray = [&](uint32_t pix) {      // create_ray, ray.wgsl:269-285 (right/up/fwd_ff hoisted to the host, bit-identical) - the plain refill's text
-                cold.set_pix(pix);
-                const int px = (int)(pix & 0x7fffu), py = (int)((pix >> 15) & 0x7fffu), lv = (int)(pix >> 30);
-                const int lw = Z.lv[lv].L.w, lh = Z.lv[lv].L.h;
-                const int sm = (lw - 1) < (lh - 1) ? (lw - 1) : (lh - 1);
-                const float increment = 1.0f / (float)sm;
-                const float posx = (2.0f * ((float)px - (float)(lw - 1) * 0.5f)) * increment;
-                const float posy = (2.0f * ((float)py - (float)(lh - 1) * 0.5f)) * increment;
-                const F3 cam = ld3(P.cam);
-                const F3 rdir = normalize((ld3(P.right) * posx + ld3(P.up) * posy) + ld3(P.fwd_ff));
-                cold.set_rdir(rdir);
-                cpos = cam; cdir = rdir; ppos = cam; pdir = rdir;
-                rkpos = cam; rkdir = rdir; rkh = P.step_size;
-                cold.set_color(f3(0, 0, 0)); amount = 1.0f; closest = H.ray_distance;
-                dist_c = P.ray_distance_f; cpos_dist = P.ray_distance_f; qrel = cam - bpos;
-                it = 0; HIT_SET(0);
-                mode = P.relativity0 ? M_REL : M_FLAT;
-                if (COUNT) cnt[3]++;
-            };
-            const unsigned long long need = __ballot(mode == M_EMPTY);
-            // (0) an idle tracer HELPS with the tile ring when items are published and untaken (the burst when a level's last tiles
-            //     become final: a thousand classifiers are too few for 32 000 last-level tiles).  It takes one ticket at a time and only
-            //     when it saw an item; a ticket that lost the race to another wave is waited for - the item it stands for comes with the
-            //     next tiles that resolve, and the waves that served the burst are free again to trace what it produced.
-            if (BHRAY_FUSED_HELPERS && need == ~0ull && fused_skip == 0) {
-                uint32_t processed[BHRAY_MAX_SPEC_LEVELS] = {0u, 0u, 0u, 0u}, finals = 0u, unflushed = 0u;
-                bool worked = false;
-                for (int guard = 0; guard < (1 << 16); guard++) {
-                    uint32_t tk = 0; int ok = 0;
-                    if (lane == 0) {
-                        const uint32_t h = ld_u32_agent(&Z.ctl->cq_head.v), t = ld_u32_agent(&Z.ctl->cq_tail.v);
-                        if (h < t && h < Z.n_items) { tk = atomicAdd(&Z.ctl->cq_head.v, 1u); ok = tk < Z.n_items ? 1 : 0; }
-                    }
-                    ok = __builtin_amdgcn_readfirstlane(ok); tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
-                    if (!ok) break;
-                    if (!fused_serve<COUNT>(P, Z, tk, lane, processed, finals, unflushed)) { err = BHRAY_E_STATE; break; }
-                    worked = true;
-                }
-                if (worked) {                                    // report, and cut the liveness of the (dead) ray state across the tile work
-                    fused_flush(Z, processed, finals, lane);
-                    cpos = f3(0, 0, 0); cdir = f3(0, 0, 1); ppos = f3(0, 0, 0); pdir = f3(0, 0, 1); rkpos = f3(0, 0, 0); rkdir = f3(0, 0, 1);
-                    rkh = 0.0f; amount = 1.0f; closest = H.ray_distance; dist_c = P.ray_distance_f; cpos_dist = P.ray_distance_f; qrel = f3(0, 0, 0);
-                    it = 0; HIT_SET(0); fused_idle = 0; fused_backoff = 0;
-                }
-            }
-            // (a) slots for the empty lanes, coarsest open level first (the coarse levels are the critical path).  Entries that are there
-            //     are dealt out a few per wave (a phase lasts as long as its longest ray, and what that ray pays per step is what its WAVE
-            //     executes); when nothing is there, idle lanes take slots AHEAD of the producers (a bounded number per level) and wait on
-            //     them: a ray is then picked up the moment it is published, by polling an address nobody else polls.  Levels that have
-            //     closed and handed out every entry are never looked at again (fused_lo).
-            if (need != 0ull && fused_skip == 0 && (__popcll(need) >= BHRAY_REFILL_MIN || !__any(mode == M_REL))) {
-                uint32_t first = 0, got = 0; int l = 0, lo = fused_lo;
-                const int src = (int)__builtin_ctzll(need);
-                if (lane == src) {
-                    const uint32_t n = (uint32_t)__popcll(need);
-                    const uint32_t waves = gridDim.x * (BHRAY_TRACE_THREADS / 64);
-                    for (int q = lo; q < BHRAY_MAX_SPEC_LEVELS; q++) {
-                        if (q >= Z.nl) break;
-                        const uint32_t r = ld_u32_agent(&Z.ctl->rq[q].reserve.v), h = ld_u32_agent(&Z.ctl->rq[q].head.v), f = ld_u32_agent(&Z.ctl->rq[q].final.v);
-                        if (f != 0u && h >= f - 1u) { if (q == lo) lo = q + 1; continue; }      // closed, every entry handed out
-                        if (h >= Z.lv[q].rq_cap) continue;
-                        const int avail = (int)(r - h);
-                        uint32_t cap = 0;
-                        const uint32_t cmin = q == Z.nl - 1 ? (uint32_t)BHRAY_FUSED_CLAIM_LAST : 4u;   // thin on the coarse levels, coarse on the last
-                        // Tiers: ONE tracer per block (a different SIMD from block to block) takes whatever there is and runs ahead; the
-                        // others join only when a level holds a bulk of entries.  A few rays are best traced by one wave per SIMD - a
-                        // phase lasts as long as its longest ray, and a wave that shares its SIMD with working waves steps slower.
-                        if (avail > 0 && (fused_tier1 || avail >= BHRAY_FUSED_BULK)) { cap = ((uint32_t)avail + waves - 1u) / waves; cap = cap < cmin ? cmin : cap; }
-                        else if (fused_tier1 && f == 0u && -avail < BHRAY_FUSED_RAYS_AHEAD) cap = 4u;
-                        if (cap == 0u) continue;
-                        got = n < cap ? n : cap;
-                        first = atomicAdd(&Z.ctl->rq[q].head.v, got);
-                        l = q;
-                        break;
-                    }
-                }
-                got = (uint32_t)__shfl((int)got, src); first = (uint32_t)__shfl((int)first, src); l = __shfl(l, src); fused_lo = __shfl(lo, src);
-                if (got != 0u) {
-                    fused_idle = 0; fused_backoff = 0;
-                    const uint32_t rank = lanes_below(need);
-                    if (mode == M_EMPTY && rank < got && first + rank < Z.lv[l].rq_cap) { mode = M_WAIT; cold.set_pix(first + rank); it = l; }
-                } else {                                         // nothing to take, nothing to wait for: look again after 1, 2, 4 ... 32 rounds
-                    fused_backoff = fused_backoff < 5 ? fused_backoff + 1 : 5;
-                    fused_skip = 1 << fused_backoff;
-                }
-            } else if (fused_skip > 0) {
-                fused_skip--;
-            }
-            // (b) lanes that hold a slot look at it
-            if (__any(mode == M_WAIT) && ((fused_wait_round & 1) == 0 || !__any(mode > M_EMPTY))) {
-                if (mode == M_WAIT) {
-                    const uint32_t idx = cold.pix();
-                    const int lw_ = it;
-                    const unsigned long long e = ld_u64_agent(&Z.lv[lw_].rq[idx]);
-                    if ((uint32_t)(e >> 32) == Z.stamp) {
-                        start_ray((uint32_t)e);
-                    } else if ((fused_wait_round & 6) == 0) {                            // (the closing word is one address for everybody: look rarely)
-                        const uint32_t f = ld_u32_agent(&Z.ctl->rq[lw_].final.v);
-                        if (f != 0u && idx >= f - 1u) { mode = M_EMPTY; it = 0; }     // the level closed below this slot: nothing will come
-                    }
-                }
-                if (fused_wait_round > (1 << 20)) { err = BHRAY_E_STATE; if (mode == M_WAIT) { mode = M_EMPTY; it = 0; } }     // a slot that never fills: a bug, not a hang
-                if (!__any(mode > M_EMPTY)) {                                        // only waiting lanes: every poll is a trip across the fabric - and steals issue slots from the SIMD's working waves
-#pragma unroll
-                    for (int z = 0; z < BHRAY_FUSED_SLOT_SLEEP; z++) __builtin_amdgcn_s_sleep(127);
-                }
-            }
-            if (__any(mode == M_WAIT)) fused_wait_round++;
-            if (!__any(mode != M_EMPTY)) {                       // this wave holds no ray, waits for none
-                if (__builtin_amdgcn_readfirstlane((int)ld_u32_agent(&Z.ctl->done.v)) != 0) {
-                    // every tile is classified and every coarse ray stored; the last level's rays are not counted: the frame is complete for
-                    // this wave once every entry of the last level's (closed) queue has been handed out - the waves holding them finish them
-                    const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld_u32_agent(&Z.ctl->rq[Z.nl - 1].final.v));
-                    const uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld_u32_agent(&Z.ctl->rq[Z.nl - 1].head.v));
-                    if (f != 0u && h >= f - 1u) { fused_done_mask |= 1u << fb; break; }
-                }
-                fused_idle++;
-                if (nb > 1 && fused_idle > 8) break;            // look at the batch's other frames; this one is revisited
-#ifdef BHRAY_EXP_PROFILE
-                { const long long now_ = clock64(); xp_idle += now_ - xp_last; xp_last = now_; }
+#if BHRAY_WITH_FUSED
+        if (FZ) {
+#define BHRAY_FUSED_PART 2
+#include "bhray_fused.inc"
+#undef BHRAY_FUSED_PART
+        } else
 #endif
-                fused_skip = 0;                                  // an idle wave looks at the queues every time it wakes: its sleep is the rate limit
-                if (fused_idle < 4) __builtin_amdgcn_s_sleep(8); else if (fused_idle < 16) __builtin_amdgcn_s_sleep(32);
-                else if (fused_idle < 64) __builtin_amdgcn_s_sleep(127); else { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
-                if (fused_idle > (1 << 19)) { err = BHRAY_E_STATE; fused_done_mask |= 1u << fb; break; }
-                continue;
-            }
-        } else {
+        {
             const unsigned long long need = __ballot(mode == M_EMPTY);
             if (need != 0ull && !exhausted && (BHRAY_REFILL_MIN <= 1 || __popcll(need) >= BHRAY_REFILL_MIN || !__any(mode == M_REL))) {
                 uint32_t n = (uint32_t)__popcll(need);
@@ -1461,119 +997,10 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                     if (COUNT) cnt[3]++;
                 }
             }
-            if (!(MAILBOX && MB_T > 0 && last_frame)) { if (!__any(mode != M_EMPTY)) break; }
+            if (!__any(mode != M_EMPTY)) break;
         }
-        // ---- drain merging through the block's LDS mailbox (see the declaration of mb_ctl)
-        if (MAILBOX && MB_T > 0 && last_frame) {
-            if (!exhausted) {
-                if (!__any(mode != M_EMPTY)) exhausted = true;      // cannot happen (an empty wave has just been refused by the queue)
-            }
-            if (exhausted) {
-#define BHRAY_RAY_FLOATS(X)                                                                                              \
-    X(0, cpos.x) X(1, cpos.y) X(2, cpos.z) X(3, cdir.x) X(4, cdir.y) X(5, cdir.z) X(6, ppos.x) X(7, ppos.y) X(8, ppos.z)     \
-    X(9, pdir.x) X(10, pdir.y) X(11, pdir.z) X(12, rkpos.x) X(13, rkpos.y) X(14, rkpos.z) X(15, rkdir.x) X(16, rkdir.y)     \
-    X(17, rkdir.z) X(18, qrel.x) X(19, qrel.y) X(20, qrel.z) X(21, rkh) X(22, amount) X(23, closest) X(24, dist_c) X(25, cpos_dist)
-                // (1) adopt parked rays into the empty lanes
-                const unsigned long long emptym = __ballot(mode == M_EMPTY);
-                if (emptym != 0ull) {
-                    int t0 = 0, n = 0;
-                    if (lane == 0) {
-                        const int want = __popcll(emptym);
-                        int old = __hip_atomic_load(&mb_ctl[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        for (;;) {
-                            const int av = __hip_atomic_load(&mb_ctl[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - old;
-                            if (av <= 0) { n = 0; break; }
-                            n = want < av ? want : av;
-                            const int seen = atomicCAS(&mb_ctl[4], old, old + n);
-                            if (seen == old) { t0 = old; break; }
-                            old = seen;
-                        }
-                    }
-                    t0 = __builtin_amdgcn_readfirstlane(t0); n = __builtin_amdgcn_readfirstlane(n);
-                    if (n > 0) {
-                        const int e = (int)lanes_below(emptym);
-                        if (mode == M_EMPTY && e < n) {
-                            const float* sp = mb_state + (t0 + e);
-#define X(w, v) v = sp[(w) * MB_CAP];
-                            BHRAY_RAY_FLOATS(X)
-#undef X
-                            cold.set_color(f3(sp[26 * MB_CAP], sp[27 * MB_CAP], sp[28 * MB_CAP]));
-                            cold.set_rdir(f3(sp[29 * MB_CAP], sp[30 * MB_CAP], sp[31 * MB_CAP]));
-                            cold.set_pend_t(sp[32 * MB_CAP]);
-                            cold.set_pix(__float_as_uint(sp[33 * MB_CAP]));
-                            const int mh = __float_as_int(sp[34 * MB_CAP]);
-                            mode = mh & 0xff; HIT_SET((mh >> 8) != 0 ? 1 : 0);
-                            it = __float_as_int(sp[35 * MB_CAP]);
-                            if (COUNT) cnt[11]++;
-                        }
-                    }
-                }
-                // (2) nothing left: leave (the last wave of the block first adopts what is still parked); few left: park them and leave
-                const unsigned long long livem = __ballot(mode != M_EMPTY);
-                const int live = __popcll(livem);
-                if (live == 0) {
-                    int r = 1;
-                    if (lane == 0) {
-                        const int old = atomicSub(&mb_ctl[0], 1);
-                        if (old <= 1) {                               // the last wave standing: parked rays are its responsibility
-                            int spins = 0;
-                            while (__hip_atomic_load(&mb_ctl[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0 && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(2); spins++; }
-                            if (spins >= (1 << 22)) r = 2;
-                            else if (__hip_atomic_load(&mb_ctl[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - __hip_atomic_load(&mb_ctl[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > 0) {
-                                atomicAdd(&mb_ctl[0], 1); r = 0;      // back in: adopt at the top of the loop
-                            }
-                        }
-                    }
-                    r = __builtin_amdgcn_readfirstlane(r);
-                    if (r == 2) err = BHRAY_E_STATE;
-                    if (r != 0) break;
-                    continue;
-                }
-                if (live <= MB_T) {
-                    int base = -1;
-                    if (lane == 0) {
-                        atomicAdd(&mb_ctl[1], 1);
-                        const int old = atomicSub(&mb_ctl[0], 1);
-                        if (old <= 1) { atomicAdd(&mb_ctl[0], 1); atomicSub(&mb_ctl[1], 1); }      // nobody would be left to adopt them: carry on
-                        else base = atomicAdd(&mb_ctl[2], live);
-                    }
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (base >= 0) {
-                        if (mode != M_EMPTY) {
-                            float* sp = mb_state + (base + (int)lanes_below(livem));
-#define X(w, v) sp[(w) * MB_CAP] = v;
-                            BHRAY_RAY_FLOATS(X)
-#undef X
-                            const F3 col = cold.color(), rd = cold.rdir();
-                            sp[26 * MB_CAP] = col.x; sp[27 * MB_CAP] = col.y; sp[28 * MB_CAP] = col.z;
-                            sp[29 * MB_CAP] = rd.x; sp[30 * MB_CAP] = rd.y; sp[31 * MB_CAP] = rd.z;
-                            sp[32 * MB_CAP] = cold.pend_t();
-                            sp[33 * MB_CAP] = __uint_as_float(cold.pix());
-                            sp[34 * MB_CAP] = __int_as_float(mode | (HIT_GET() ? 0x100 : 0));
-                            sp[35 * MB_CAP] = __int_as_float(it);
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        if (lane == 0) {
-                            __hip_atomic_fetch_add(&mb_ctl[3], live, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            atomicSub(&mb_ctl[1], 1);
-                        }
-                        mode = M_EMPTY;
-                        break;
-                    }
-                }
-#undef BHRAY_RAY_FLOATS
-            }
-        }
-
-        XP(0, xp_refill)
-#ifdef BHRAY_EXP_PROFILE
-        const bool xp_shade = __any(mode >= M_SHADE_REL), xp_flat = __any(mode == M_FLAT);
-#endif
         // ---- deferred disk shading (ray.wgsl:612-663 and the hit bookkeeping of 537-552) for lanes that paused on a disk hit
         if (__any(mode >= M_SHADE_REL)) {
-#if defined(BHRAY_EXP_POWSTAT) || defined(BHRAY_EXP_PHASESTAT)   /* counting-only build: wave-level invocations of the shade phase (triangles counter) */
-            if (COUNT && lane == (int)__builtin_ctzll(__ballot(true))) cnt[7]++;
-#endif
             if (mode >= M_SHADE_REL) {
                 const float pend_t = cold.pend_t();
                 Hit crs; crs.hit = true; crs.t = pend_t; crs.color = f3(0.0f, 0.0f, 0.0f); crs.opacity = 0.0f;
@@ -1590,7 +1017,6 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
             }
         }
 
-        XP(1, xp_shade)
         // ---- flat-space iterations (ray.wgsl:554-569), one per lane that is in flat space.
         // With meshes a flat iteration is a BVH traversal executed by the whole wave for the few lanes that need it,
         // so those lanes are batched: the phase runs when enough of them wait, when nobody is integrating, or at the
@@ -1603,9 +1029,6 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
             if (run_flat) flat_round = 0;
         }
         if (run_flat && __any(mode == M_FLAT)) {
-#ifdef BHRAY_EXP_PHASESTAT            /* counting-only build: wave-level invocations of the flat phase (node_pairs) and the epilogue (rays_adopted) */
-            if (COUNT && lane == (int)__builtin_ctzll(__ballot(true))) cnt[6]++;
-#endif
             if (mode == M_FLAT) {
                 if (it >= H.max_iter) {
                     mode = M_FINISH;
@@ -1668,14 +1091,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
         }
 
         // ---- epilogue (ray.wgsl:583-595) for lanes whose loop ended
-        XP(2, xp_flat)
-#ifdef BHRAY_EXP_PROFILE
-        const bool xp_fin = __any(mode == M_FINISH);
-#endif
         if (__any(mode == M_FINISH)) {
-#ifdef BHRAY_EXP_PHASESTAT
-            if (COUNT && lane == (int)__builtin_ctzll(__ballot(true))) cnt[11]++;
-#endif
             if (mode == M_FINISH) {
                 float4 o;
                 F3 color = cold.color();
@@ -1699,21 +1115,14 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                 } else {
                     o = make_float4(cdir.x, cdir.y, cdir.z, 0.0f);
                 }
-                if (FUSED) {
-                    const FusedFrame& Z = *F.fz;
-                    const int ox = (int)(pix & 0x7fffu), oy = (int)((pix >> 15) & 0x7fffu), lv = (int)(pix >> 30);
-                    const FusedLevel& V = Z.lv[lv];
-                    const int orow = V.ray_rowmap ? V.ray_rowmap[oy] : oy;
-                    float4* d = V.ray_out + ((size_t)orow * (size_t)V.ray_pitch + (size_t)(ox - V.ray_x0));
-                    if (lv == Z.nl - 1) {
-                        *d = o;                                                  // the frame: nobody reads it in this launch, nothing to report
-                    } else {
-                        st_px_agent(d, o);                                       // a coarser level's pixel is read by other workgroups in this launch
-                        fused_tile = V.tile_base + (uint32_t)(V.row_index[oy] >> 3) * V.tiles_x + (uint32_t)((ox - V.L.x0) >> 3);
-                        fused_lv = lv;
-                        fused_fin = true;
-                    }
-                } else {
+#if BHRAY_WITH_FUSED
+                if (FZ) {
+#define BHRAY_FUSED_PART 3
+#include "bhray_fused.inc"
+#undef BHRAY_FUSED_PART
+                } else
+#endif
+                {
                     const int ox = (int)(pix & 0x7fffu), oy = (int)((pix >> 15) & 0x7fffu);
                     if (SL.n > 0) {
                         const int lv = (int)(pix >> 30);
@@ -1722,6 +1131,12 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                         for (int q = 1; q < BHRAY_MAX_SPEC_LEVELS; q++) if (lv == q) { dst = SL.l[q].out; pitch = SL.l[q].out_pitch; x0 = SL.l[q].out_x0; rowmap = SL.l[q].rowmap; }
                         const int orow = rowmap ? rowmap[oy] : oy;
                         dst[(size_t)orow * (size_t)pitch + (size_t)(ox - x0)] = o;
+                        if (COUNT) {                                       // where the work lies (bhray_get_row_work)
+                            unsigned long long* rw = SL.l[0].row_work;
+#pragma unroll
+                            for (int q = 1; q < BHRAY_MAX_SPEC_LEVELS; q++) if (lv == q) rw = SL.l[q].row_work;
+                            if (rw) atomicAdd(&rw[oy], (unsigned long long)it);
+                        }
                         if (F.stamp_value != 0u) {                       // temporal speculation: this pixel of this level is done for this frame
                             uint32_t* st = SL.l[0].stamp; int sw = SL.l[0].w;
 #pragma unroll
@@ -1730,38 +1145,24 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                         }
                     } else {
                         L.out[out_index(L, ox, oy)] = o;
+                        if (COUNT && F.row_work) atomicAdd(&F.row_work[oy], (unsigned long long)it);
                     }
                 }
                 mode = M_EMPTY;
             }
-            if (FUSED) {
-                // the pixels are stored (write-through, complete): each finished ray leaves its tile; whoever takes a tile's last ray
-                // hands the tile on (its dependents' classification, or - speculative level - its own)
-                const FusedFrame& Z = *F.fz;
-                if (__any(fused_fin)) drain_vm();
-                bool last_of_tile = false;
-                if (fused_fin) last_of_tile = atomicSub(&Z.pending[fused_tile], 1u) == 1u;
-                unsigned long long fm = __ballot(last_of_tile);
-                while (fm != 0ull) {
-                    const int k = (int)__builtin_ctzll(fm);
-                    fm &= fm - 1ull;
-                    fused_rays_done(Z, __shfl(fused_lv, k), (uint32_t)__shfl((int)fused_tile, k), lane);
-                }
-                fused_fin = false;
+#if BHRAY_WITH_FUSED
+            if (FZ) {
+#define BHRAY_FUSED_PART 4
+#include "bhray_fused.inc"
+#undef BHRAY_FUSED_PART
             }
+#endif
         }
 
-        XP(3, xp_fin)
         // ---- a batch of integrator steps (ray.wgsl:522-553) for lanes inside the sphere
         for (int k = 0; k < BHRAY_REL_BATCH; k++) {       // (unrolled by 2 / 4 to let prev = curr become renaming: -1 % / 0 %, measured)
             if (!__any(mode == M_REL)) break;
             if (COUNT && lane == 0) cnt[10]++;
-#ifdef BHRAY_EXP_PROFILE
-            xp_n++;
-#ifdef BHRAY_EXP_PROFILE_FINE
-            const long long xf_a = clock64(); long long xf_b = xf_a, xf_c = xf_a; xf_loop += xf_a - xf_prev;
-#endif
-#endif
             if (DENSE || MODELS) {                    // see bhray_step.inc
 #define BHRAY_STEP_LEAN 0
 #include "bhray_step.inc"
@@ -1771,24 +1172,8 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
 #include "bhray_step.inc"
 #undef BHRAY_STEP_LEAN
             }
-#ifdef BHRAY_EXP_PROFILE_FINE
-            { const long long xf_d = clock64(); xf_step += xf_b - xf_a; xf_cull += xf_c - xf_b; xf_tail += xf_d - xf_c; xf_prev = xf_d; }
-#endif
         }
-        XP(4, true)
     }
-#ifdef BHRAY_EXP_PROFILE
-    if (lane == 0) {
-        long long* d = xp_dump + (size_t)(blockIdx.x * (BHRAY_TRACE_THREADS / 64) + (threadIdx.x >> 6)) * 16;
-        d[0] = clock64() - xp_t0; d[1] = xp_rounds; d[2] = xp_n;
-        for (int k = 0; k < 5; k++) { d[3 + k] = xp_t[k]; d[8 + k] = xp_c[k]; }
-        if (FUSED) d[12] = xp_idle;
-#ifdef BHRAY_EXP_PROFILE_FINE
-        d[8] = xf_loop; d[9] = xf_step; d[10] = xf_cull; d[11] = xf_tail;
-#endif
-    }
-#endif
-
     if (COUNT) {
         for (int k = 3; k < 12; k++) {
             unsigned long long v = cnt[k];
@@ -1962,7 +1347,7 @@ hipError_t launch_classify(const FrameParams* Pb, const FrameLaunch* Fb, int nb,
 template <int METHOD, bool MODELS, bool DENSE, int EVAL = 0>
 static hipError_t launch_trace_t(const FrameParams* Pb, const FrameLaunch* Fb, int nb, bool count, int* err_flag, int grid_blocks, hipStream_t s) {
     (void)hipGetLastError();
-    constexpr size_t dyn_lds = MODELS ? (size_t)BHRAY_BVH_LDS_TOP * 32 + (size_t)BHRAY_BVH_LDS_STACK * BHRAY_TRACE_THREADS * 8 : 0;   // trace_ray_model's LDS
+    constexpr size_t dyn_lds = MODELS ? (size_t)BHRAY_BVH_LDS_STACK * BHRAY_TRACE_THREADS * 8 : 0;   // trace_ray_model's LDS
     if (count) hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, true, DENSE, EVAL>), dim3((grid_blocks * 256 + BHRAY_TRACE_THREADS - 1) / BHRAY_TRACE_THREADS), dim3(BHRAY_TRACE_THREADS), dyn_lds, s, Pb, Fb, nb, err_flag);
     else hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, false, DENSE, EVAL>), dim3((grid_blocks * 256 + BHRAY_TRACE_THREADS - 1) / BHRAY_TRACE_THREADS), dim3(BHRAY_TRACE_THREADS), dyn_lds, s, Pb, Fb, nb, err_flag);
     return hipGetLastError();
@@ -1991,64 +1376,15 @@ hipError_t launch_trace(const FrameParams* Pb, const FrameLaunch* Fb, int nb, in
     return launch_trace_e<0>(Pb, Fb, nb, method, models, count, dense, err_flag, grid_blocks, s);
 }
 
-// ---- fused ladder launchers -----------------------------------------------------------------------
-// Reset of the batch's tile state: deps[tile] = (coarse tile columns read) x (coarse tile rows read) (+ 1 for a speculative level >= 1:
-// its own traced values), pending = 0, the control words.  blockIdx.y = frame.
-__global__ __launch_bounds__(256) void fused_reset_kernel(const FrameLaunch* __restrict__ Fb) {
-    const FusedFrame& Z = *Fb[blockIdx.y].fz;
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t == 0u) {
-        FusedCtl* c = Z.ctl;
-        c->cq_tail.v = Z.n_initial; c->cq_head.v = 0u; c->tiles_left.v = Z.total_tiles; c->done.v = 0u;
-        for (int q = 0; q < BHRAY_MAX_SPEC_LEVELS; q++) {
-            c->rq[q].reserve.v = 0u; c->rq[q].head.v = 0u; c->rq[q].final.v = 0u;
-            c->rq[q].unprocessed.v = q < Z.nl ? Z.lv[q].tiles_x * Z.lv[q].tiles_y : 0u;
-        }
-    }
-    if (t >= Z.total_tiles) return;
-    int l = 0;
-#pragma unroll
-    for (int q = 1; q < BHRAY_MAX_SPEC_LEVELS; q++) if (q < Z.nl && t >= Z.lv[q].tile_base) l = q;
-    const FusedLevel& V = Z.lv[l];
-    uint32_t d = 0;
-    if (l > 0) {
-        const uint32_t k = t - V.tile_base;
-        d = (uint32_t)V.xdep[k % V.tiles_x] * (uint32_t)V.ydep[k / V.tiles_x] + (V.all_traced ? 1u : 0u);
-    }
-    Z.deps[t] = d;
-    Z.pending[t] = 0u;
-}
-hipError_t launch_fused_reset(const FrameLaunch* Fb, int nb, int max_tiles, hipStream_t s) {
-    if (nb <= 0 || max_tiles <= 0) return hipSuccess;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(fused_reset_kernel, dim3((unsigned)((max_tiles + 255) / 256), (unsigned)nb), dim3(256), 0, s, Fb);
-    return hipGetLastError();
-}
-template <int EVAL>
-static const void* fused_kernel_ptr(int method, int has_models, int count) {
-#define PICK(M, MD, C) (const void*)trace_kernel<M, MD, C, false, EVAL, true>
-    if (has_models) return method == 0 ? (count ? PICK(0, true, true) : PICK(0, true, false)) : (count ? PICK(1, true, true) : PICK(1, true, false));
-    return method == 0 ? (count ? PICK(0, false, true) : PICK(0, false, false)) : (count ? PICK(1, false, true) : PICK(1, false, false));
-#undef PICK
-}
-static const void* fused_kernel(int method, int has_models, int count, int eval) {
-    return eval == 1 ? fused_kernel_ptr<1>(method, has_models, count) : eval == 2 ? fused_kernel_ptr<2>(method, has_models, count) : fused_kernel_ptr<0>(method, has_models, count);
-}
-hipError_t launch_fused(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int method, bool models, bool count, int eval, int* err_flag, int grid_blocks, hipStream_t s) {
-    if (nb <= 0) return hipSuccess;
-    (void)hipGetLastError();
-    const size_t dyn_lds = models ? (size_t)BHRAY_BVH_LDS_TOP * 32 + (size_t)BHRAY_BVH_LDS_STACK * BHRAY_TRACE_THREADS * 8 : 0;
-    void* args[] = {(void*)&Pb, (void*)&Fb, (void*)&nb, (void*)&err_flag};
-    return hipLaunchKernel(fused_kernel(method, models ? 1 : 0, count ? 1 : 0, eval), dim3((unsigned)((grid_blocks * 256 + BHRAY_TRACE_THREADS - 1) / BHRAY_TRACE_THREADS)),
-                           dim3(BHRAY_TRACE_THREADS), args, dyn_lds, s);
-}
-int fused_blocks_per_cu(int method, int has_models, int count, int eval) {
-    int n = 0;
-    const size_t dyn_lds = has_models ? (size_t)BHRAY_BVH_LDS_TOP * 32 + (size_t)BHRAY_BVH_LDS_STACK * BHRAY_TRACE_THREADS * 8 : 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fused_kernel(method, has_models, count, eval), BHRAY_TRACE_THREADS, dyn_lds) != hipSuccess || n < 1) n = 2;
-    n = n * BHRAY_TRACE_THREADS / 256;
-    return n < 1 ? 1 : n;
-}
+#if BHRAY_WITH_FUSED
+#define BHRAY_FUSED_PART 5
+#include "bhray_fused.inc"
+#undef BHRAY_FUSED_PART
+#else
+hipError_t launch_fused_reset(const FrameLaunch*, int, int, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_fused(const FrameParams*, const FrameLaunch*, int, int, bool, bool, int, int*, int, hipStream_t) { return hipErrorNotSupported; }
+int fused_blocks_per_cu(int, int, int, int) { return 0; }      // 0: this build has no fused ladder (bhray_create refuses BHRAY_F_FUSED)
+#endif
 
 template <int EVAL>
 static const void* trace_kernel_ptr(int method, int has_models, int count, int dense) {
@@ -2062,16 +1398,10 @@ int trace_blocks_per_cu(int method, int has_models, int count, int dense, int ev
     int n = 0;
     const void* f = eval == 1 ? trace_kernel_ptr<1>(method, has_models, count, dense)
                   : eval == 2 ? trace_kernel_ptr<2>(method, has_models, count, dense) : trace_kernel_ptr<0>(method, has_models, count, dense);
-    const size_t dyn_lds = has_models ? (size_t)BHRAY_BVH_LDS_TOP * 32 + (size_t)BHRAY_BVH_LDS_STACK * BHRAY_TRACE_THREADS * 8 : 0;
+    const size_t dyn_lds = has_models ? (size_t)BHRAY_BVH_LDS_STACK * BHRAY_TRACE_THREADS * 8 : 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, BHRAY_TRACE_THREADS, dyn_lds) != hipSuccess || n < 1) n = 2;
     n = n * BHRAY_TRACE_THREADS / 256;            // in units of 256 threads (the grid is sized in those)
     return n < 1 ? 1 : n;
 }
 
 }  // namespace bhray
-
-#ifdef BHRAY_EXP_PROFILE
-extern "C" int bhray_debug_read_profile(long long* out, size_t n) {      // timing-only build: per-wave phase clocks of the last trace launch
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bhray::xp_dump), n * sizeof(long long));
-}
-#endif

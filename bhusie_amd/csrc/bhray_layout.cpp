@@ -61,4 +61,6 @@ OFF(bhray_config, device_count, 12 + 8 * BHRAY_MAX_LEVELS + 48);
 OFF(bhray_config, devices, 12 + 8 * BHRAY_MAX_LEVELS + 52);
 OFF(bhray_config, gather, 12 + 8 * BHRAY_MAX_LEVELS + 52 + 4 * BHRAY_MAX_DEVICES);
 OFF(bhray_config, comm_id, 12 + 8 * BHRAY_MAX_LEVELS + 52 + 4 * BHRAY_MAX_DEVICES + 8);
-SZ(bhray_config, 12 + 8 * BHRAY_MAX_LEVELS + 52 + 4 * BHRAY_MAX_DEVICES + 8 + BHRAY_COMM_ID_BYTES);
+OFF(bhray_config, partition, 12 + 8 * BHRAY_MAX_LEVELS + 52 + 4 * BHRAY_MAX_DEVICES + 8 + BHRAY_COMM_ID_BYTES);
+OFF(bhray_config, slab_row0, 12 + 8 * BHRAY_MAX_LEVELS + 52 + 4 * BHRAY_MAX_DEVICES + 8 + BHRAY_COMM_ID_BYTES + 4);
+SZ(bhray_config, 12 + 8 * BHRAY_MAX_LEVELS + 52 + 4 * BHRAY_MAX_DEVICES + 8 + BHRAY_COMM_ID_BYTES + 4 + 4 * (BHRAY_MAX_DEVICES + 1));

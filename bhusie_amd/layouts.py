@@ -7,6 +7,7 @@ MAX_LEVELS = 8
 MAX_DEVICES = 16
 COMM_ID_BYTES = 128
 GATHER_NONE, GATHER_RCCL = 0, 1
+PARTITION_STRIPES, PARTITION_SLABS = 0, 1
 MAX_MODEL_VERTICES = 524288
 MODEL_UNIFORM_BYTES = 48234572
 F_COUNTERS = 1
@@ -72,7 +73,8 @@ class BhrayConfig(C.Structure):
                 ("row_rank", C.c_uint32), ("row_world", C.c_uint32), ("stripe_rows", C.c_uint32), ("flags", C.c_uint32),
                 ("frames_in_flight", C.c_uint32), ("speculative_levels", C.c_uint32), ("frames_per_batch", C.c_uint32),
                 ("superset_levels", C.c_uint32), ("device_count", C.c_uint32), ("devices", C.c_int32 * MAX_DEVICES), ("gather", C.c_uint32),
-                ("gather_root", C.c_uint32), ("comm_id", C.c_uint8 * COMM_ID_BYTES)]
+                ("gather_root", C.c_uint32), ("comm_id", C.c_uint8 * COMM_ID_BYTES),
+                ("partition", C.c_uint32), ("slab_row0", C.c_uint32 * (MAX_DEVICES + 1))]
 
     def sizes(self):
         return [(int(self.level_w[i]), int(self.level_h[i])) for i in range(self.levels)]
@@ -130,6 +132,9 @@ SYMBOLS = {
     "bhray_device_count": (C.c_int, []),
     "bhray_partition_rows": (u32, [u32, u32, u32, u32]),
     "bhray_partition_row_index": (C.c_int, [u32, u32, u32, u32, u32, P(u32)]),
+    "bhray_config_partition_rows": (u32, [P(BhrayConfig), u32]),
+    "bhray_config_partition_row_index": (C.c_int, [P(BhrayConfig), u32, u32, P(u32)]),
+    "bhray_balance_slabs": (C.c_int, [P(BhrayConfig), P(P(C.c_uint64)), u32, P(u32)]),
     "bhray_comm_unique_id": (C.c_int, [vp]),
     "bhray_get_gather_info": (C.c_int, [vp, P(BhrayGatherInfo)]),
     "bhray_set_materials": (C.c_int, [vp, vp, sz]),
@@ -162,6 +167,7 @@ SYMBOLS = {
     "bhray_next_stream": (C.c_int, [vp, P(vp)]),
     "bhray_get_counters": (C.c_int, [vp, P(BhrayCounters)]),
     "bhray_get_level_counters": (C.c_int, [vp, u32, P(BhrayCounters)]),
+    "bhray_get_row_work": (C.c_int, [vp, u32, P(C.c_uint64), u32]),
     "bhray_get_timing": (C.c_int, [vp, P(BhrayTiming)]),
     "bhray_selftest": (C.c_int, [vp, P(C.c_uint64)]),
     "bhray_camera_uniform_update": (None, [P(BhrayCameraUniform), P(C.c_float), P(C.c_float), C.c_float]),

@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 
 from ._lib import lib
-from .layouts import (F_COUNTERS, F_EVAL_FMA, F_FUSED, F_LITERAL, F_TEMPORAL, F_TIMING, F_TIMING_SPARSE, GATHER_RCCL, TEX_DISK, TEX_SKY, TEX_TEMP_LUT, BhrayConfig, BhrayCounters,
+from .layouts import (PARTITION_SLABS, F_COUNTERS, F_EVAL_FMA, F_FUSED, F_LITERAL, F_TEMPORAL, F_TIMING, F_TIMING_SPARSE, GATHER_RCCL, TEX_DISK, TEX_SKY, TEX_TEMP_LUT, BhrayConfig, BhrayCounters,
                       BhrayGatherInfo, BhrayTiming, check)
 from .model import Model
 from .scene import BlackHole, Camera, RayDetails
@@ -52,6 +52,34 @@ def partition_rows(frame_h: int, world: int, stripe_rows: int = 27):
     return out
 
 
+def config_partition_rows(cfg: BhrayConfig):
+    """rows[part] for the partition a config describes (stripes or slabs)."""
+    L = lib()
+    world = cfg.device_count if cfg.device_count >= 2 else max(1, cfg.row_world)
+    out, r = [], C.c_uint32()
+    for part in range(world):
+        n = int(L.bhray_config_partition_rows(C.byref(cfg), part))
+        rows = np.zeros(n, dtype=np.int64)
+        for i in range(n):
+            check(L.bhray_config_partition_row_index(C.byref(cfg), part, i, C.byref(r)))
+            rows[i] = r.value
+        out.append(rows)
+    return out
+
+
+def balance_slabs(cfg: BhrayConfig, row_work, world: int):
+    """slab_row0[0..world] that minimise the largest partition's work; row_work[l] = per-row work of ladder level l of a calibration
+    frame rendered whole (RayPass.row_work()) - bhray_balance_slabs, pure host arithmetic."""
+    assert len(row_work) == cfg.levels
+    arrs = [np.ascontiguousarray(a, dtype=np.uint64) for a in row_work]
+    for l, a in enumerate(arrs):
+        assert a.shape == (cfg.level_h[l],), (l, a.shape)
+    ptrs = (C.POINTER(C.c_uint64) * cfg.levels)(*[a.ctypes.data_as(C.POINTER(C.c_uint64)) for a in arrs])
+    out = (C.c_uint32 * (world + 1))()
+    check(lib().bhray_balance_slabs(C.byref(cfg), ptrs, world, out))
+    return [int(v) for v in out]
+
+
 class RayPass:
     """devices=[d0, d1, ...]: ONE ctx drives several GPUs (partition i on devices[i]); bhray_render then also gathers the row
     tiles to `gather_root`'s GPU over RCCL and de-interleaves them, and every output call refers to the whole frame.
@@ -59,7 +87,7 @@ class RayPass:
 
     def __init__(self, cfg: BhrayConfig, device=0, counters=False, timing=False, row_rank=0, row_world=1, stripe_rows=27,
                  frames_in_flight=0, speculative_levels=0, frames_per_batch=0, devices=None, gather_root=0, comm_id=None,
-                 literal=False, superset_levels=0, temporal=False, eval_fma=False, fused=False):
+                 literal=False, superset_levels=0, temporal=False, eval_fma=False, fused=False, slab_row0=None):
         cfg = BhrayConfig.from_buffer_copy(bytes(cfg))
         cfg.struct_size = C.sizeof(BhrayConfig)
         cfg.device = device
@@ -74,19 +102,24 @@ class RayPass:
             C.memmove(cfg.comm_id, bytes(comm_id), 128)
         cfg.flags = (F_COUNTERS if counters else 0) | (F_TIMING_SPARSE if timing == "sparse" else (F_TIMING if timing else 0)) | (F_LITERAL if literal else 0) | (F_TEMPORAL if temporal else 0) | (F_EVAL_FMA if eval_fma else 0) | (F_FUSED if fused else 0)
         cfg.row_rank, cfg.row_world, cfg.stripe_rows = row_rank, row_world, stripe_rows
+        if slab_row0 is not None:                                # contiguous slabs instead of interleaved stripes (bhray_config.partition)
+            cfg.partition = PARTITION_SLABS
+            for i, v in enumerate(list(slab_row0)[:len(cfg.slab_row0)]):
+                cfg.slab_row0[i] = int(v)
         cfg.frames_in_flight = frames_in_flight
         cfg.speculative_levels = speculative_levels
         cfg.frames_per_batch = frames_per_batch
         cfg.superset_levels = superset_levels
         self.cfg = cfg
         h = C.c_void_p()
-        check(lib().bhray_create(C.byref(cfg), C.byref(h)))
+        self._L = lib()                                          # the library this ctx belongs to (tests swap in libbhray_fused.so)
+        check(self._L.bhray_create(C.byref(cfg), C.byref(h)))
         self._h = h
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
-            lib().bhray_destroy(h)
+            self._L.bhray_destroy(h)
 
     def __del__(self):
         try:
@@ -113,6 +146,15 @@ class RayPass:
     def set_materials(self, blob: bytes = bytes(128)):
         """mod.rs:389 — accepted and ignored (the shader never reads the materials)."""
         check(lib().bhray_set_materials(self._h, blob, len(blob)), self._h)
+
+    def row_work(self):
+        """[per-row iterations of the last render, one uint64 array per ladder level] (needs counters=True) - the input of balance_slabs."""
+        out = []
+        for l in range(self.cfg.levels):
+            a = np.zeros(self.cfg.level_h[l], dtype=np.uint64)
+            check(lib().bhray_get_row_work(self._h, l, a.ctypes.data_as(C.POINTER(C.c_uint64)), a.size), self._h)
+            out.append(a)
+        return out
 
     def gather_info(self) -> dict:
         g = BhrayGatherInfo()

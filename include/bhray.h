@@ -207,9 +207,14 @@ enum {                                  /* bhray_config.flags */
  * small per-GPU frames (row-tiled multi-GPU, offline sequences); an interactive host keeps B = 1.  A consumer that
  * orders its own work after a frame through bhray_next_stream must call bhray_flush before enqueueing that work.
  *
- * Row partition (multi-GPU row tiling): frame row r belongs to partition
- * (r / stripe_rows) % row_world; this ctx renders only rows of partition row_rank and packs
- * them densely, in increasing r, into its output buffer.  row_world = 1 ⇒ the whole frame.
+ * Row partition (multi-GPU row tiling).  partition = BHRAY_PARTITION_STRIPES (default): frame row r belongs to partition
+ * (r / stripe_rows) % row_world - interleaved stripes, balanced whatever the scene, at the price of coarse ladder rows that
+ * several partitions compute (every stripe boundary costs two rows at each coarser level).  partition =
+ * BHRAY_PARTITION_SLABS: partition p owns the consecutive rows [slab_row0[p], slab_row0[p + 1]) - one boundary per partition;
+ * the bounds come from the host, which balances them by measured work (bhray_get_row_work of a calibration frame ->
+ * bhray_balance_slabs; 1920x1080, 8 partitions, default scene: 2 % of the ray-steps computed twice and 2 % imbalance against
+ * 7 % and 8.5 % for stripes of 27, profiles/partition_sim.py).  Either way this ctx renders only rows of partition row_rank
+ * and packs them densely, in increasing r, into its output buffer.  row_world = 1 ⇒ the whole frame.
  *
  * Multi-GPU.  The reference host is one process on one thread (app.rs:108-114, mod.rs:415-420), so the
  * row tiling lives behind this ABI:
@@ -226,6 +231,8 @@ enum {                                  /* bhray_config.flags */
  *     rank, distributed by the launcher's own means).  The gather is enqueued by bhray_render exactly as above; the frame
  *     exists on rank gather_root only (the other ranks' output calls succeed and deliver nothing).
  * RCCL is loaded (dlopen "librccl.so.1") when the first such ctx is created; a single-GPU host never loads it. */
+enum { BHRAY_PARTITION_STRIPES = 0,     /* interleaved stripes of stripe_rows rows                                   */
+       BHRAY_PARTITION_SLABS = 1 };     /* contiguous slabs bounded by slab_row0[0..row_world] (row_world <= BHRAY_MAX_DEVICES) */
 enum { BHRAY_GATHER_NONE = 0,           /* row_world > 1: this ctx delivers its packed rows, the caller moves them   */
        BHRAY_GATHER_RCCL = 1 };         /* the library gathers (always on when device_count >= 2)                    */
 
@@ -248,6 +255,9 @@ typedef struct bhray_config {
     uint32_t gather;                    /* BHRAY_GATHER_*: one process per GPU only (see above)                      */
     uint32_t gather_root;               /* partition whose GPU receives the frame (default 0)                        */
     uint8_t  comm_id[BHRAY_COMM_ID_BYTES]; /* one process per GPU: the communicator id shared by all ranks           */
+    uint32_t partition;                 /* BHRAY_PARTITION_*                                                         */
+    uint32_t slab_row0[BHRAY_MAX_DEVICES + 1]; /* BHRAY_PARTITION_SLABS: first frame row of every partition, then frame_h
+                                           (non-decreasing; a partition may own no rows)                            */
 } bhray_config;
 
 /* Reference ladder rule `r ← r·m − (m−1)` (mod.rs:177-205): fills level_w/h[0..levels).    */
@@ -275,6 +285,15 @@ int  bhray_device_count(void);                        /* usable gfx950 devices, 
  * bhray_partition_rows = rows of `part`; bhray_partition_row_index = frame row of the part's packed row i.        */
 uint32_t bhray_partition_rows(uint32_t frame_h, uint32_t world, uint32_t stripe_rows, uint32_t part);
 int bhray_partition_row_index(uint32_t frame_h, uint32_t world, uint32_t stripe_rows, uint32_t part, uint32_t i, uint32_t* frame_row);
+/* The same for the partition a bhray_config describes (stripes or slabs; world = device_count when >= 2, else row_world). */
+uint32_t bhray_config_partition_rows(const bhray_config* cfg, uint32_t part);
+int bhray_config_partition_row_index(const bhray_config* cfg, uint32_t part, uint32_t i, uint32_t* frame_row);
+/* Slab bounds balanced by measured work.  row_work[l] points to level_h[l] numbers: the work (ray-steps, bhray_get_row_work) of
+ * every row of ladder level l of a calibration frame rendered WHOLE with the speculative_levels the partitions will use.  A
+ * partition's work is the work of the level rows its frame rows depend on (every level: the ladder arithmetic of cfg, crop
+ * included); the bounds minimise the largest partition's work over all contiguous partitions.  Pure host arithmetic.
+ * Writes slab_row0[0..world] (slab_row0[0] = 0, slab_row0[world] = frame_h); the caller copies them into bhray_config.slab_row0. */
+int bhray_balance_slabs(const bhray_config* cfg, const uint64_t* const* row_work, uint32_t world, uint32_t* slab_row0);
 /* One process per GPU: a fresh communicator id (ncclGetUniqueId); call on ONE rank, hand the bytes to all ranks.  */
 int bhray_comm_unique_id(uint8_t id[BHRAY_COMM_ID_BYTES]);
 /* What a ctx gathers with.                                                                                          */
@@ -346,9 +365,13 @@ int bhray_bind_output(bhray_ctx* ctx, void* dev_ptr, size_t bytes);
  * (1) zero copy: the consumer exports the memory behind its texture / buffer as a file descriptor (Vulkan
  *     VK_KHR_external_memory_fd: an OPAQUE_FD or dma-buf of a linear VkBuffer, which the host then copies to or aliases with its
  *     Rgba32Float texture on its own queue); bhray_import_external_fd maps it into the address space of the GPU that delivers
- *     the frame (hipImportExternalMemory) and returns a device pointer for bhray_bind_output.  The fd stays owned by the caller
- *     (the import dup()s nothing: keep it open until bhray_release_external).  Ordering: bhray_sync, or an exported semaphore
- *     the host signals from a stream it ordered with bhray_signal_stream.
+ *     the frame (hipImportExternalMemory) and returns a device pointer for bhray_bind_output.  The library imports a dup() of the
+ *     descriptor: hipImportExternalMemory follows the CUDA rule that an imported fd belongs to the runtime afterwards, so the
+ *     CALLER'S fd stays the caller's - usable and closable at any time after the call returns - whatever the runtime does with the
+ *     duplicate (ROCm 7.2 does not say whether hipDestroyExternalMemory closes it; the library does not, so an import costs at most one
+ *     descriptor).  The handle type is the opaque-fd one also for dma-buf descriptors; where tests/test_gpu_handoff.py skips (export or
+ *     import refused by the driver) this path is unverified on that system.  Ordering: bhray_sync, or an exported semaphore the host
+ *     signals from a stream it ordered with bhray_signal_stream.
  * (2) asynchronous read-back: bhray_read_hdr_async enqueues the device->host copy of the most recently enqueued frame (SDMA: no CU
  *     time) in stream order behind that frame's kernels - on the frame's own slot stream, so the other slots' frames render while it
  *     runs - and returns at once with a ticket.  bhray_wait_read(ticket) blocks until that frame has landed.  `dst` must stay valid
@@ -419,6 +442,10 @@ typedef struct bhray_counters {        /* summed over all levels of the last ren
 } bhray_counters;
 int bhray_get_counters(bhray_ctx* ctx, bhray_counters* out);   /* needs BHRAY_F_COUNTERS     */
 int bhray_get_level_counters(bhray_ctx* ctx, uint32_t level, bhray_counters* out);
+/* Where the work of the last render lies: out[y] = iterations of all rays traced for row y of ladder level `level` (n = level_h[level]
+ * numbers; rows this ctx did not render are 0; a multi-partition ctx sums its local partitions).  Needs BHRAY_F_COUNTERS; not with
+ * BHRAY_F_FUSED.  The input of bhray_balance_slabs.                                                                                */
+int bhray_get_row_work(bhray_ctx* ctx, uint32_t level, uint64_t* out, uint32_t n);
 
 /* Device self-test of the properties two exact shortcuts rest on: (i) the integrator computes the correctly
  * rounded 1/x and sqrt(x) with short gfx950 sequences — run against the IEEE lowering on all 2^32 binary32 bit patterns;

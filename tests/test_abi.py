@@ -121,10 +121,10 @@ def _header_struct_fields(name):
         ctype, rest = m.group(1), m.group(2)
         for item in rest.split(","):
             item = item.strip()
-            a = re.match(r"([a-zA-Z0-9_]+)\[([A-Z0-9_]+)\]$", item)
-            if a:
-                n = a.group(2)
-                out.append((a.group(1), ctype, int(macros.get(n, n))))
+            a = re.match(r"([a-zA-Z0-9_]+)\[([A-Z0-9_ +]+)\]$", item)
+            if a:                                             # a length is a macro, a number, or a sum of those
+                n = sum(int(macros.get(t.strip(), t.strip())) for t in a.group(2).split("+"))
+                out.append((a.group(1), ctype, n))
             else:
                 out.append((item, ctype, None))
     return out

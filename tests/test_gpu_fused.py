@@ -12,6 +12,36 @@ from tests import common as T
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
 
 
+@pytest.fixture(scope="module", autouse=True)
+def fused_library():
+    """The fused ladder is a build option (`make -C bhusie_amd/csrc fused`, also run by __graft_entry__.build()): this module runs
+    against bhusie_amd/libbhray_fused.so - the same sources with -DBHRAY_WITH_FUSED=1 - for the fused AND the launch-per-level frames
+    it compares; the default library refuses BHRAY_F_FUSED (test_the_default_library_refuses_the_flag)."""
+    import ctypes as C
+    import os
+    from bhusie_amd import _lib, layouts
+    path = os.path.join(os.path.dirname(_lib.LIB_PATH), "libbhray_fused.so")
+    assert os.path.exists(path), f"{path} not built: make -C bhusie_amd/csrc fused"
+    saved = _lib.lib()
+    L = C.CDLL(path)
+    layouts.declare(L)
+    _lib._lib = L
+    yield saved
+    _lib._lib = saved
+
+
+def test_the_default_library_refuses_the_flag(fused_library):
+    import ctypes as C
+    from bhusie_amd import layouts
+    cfg = B.ladder_from_base((24, 14), 3, 3)
+    cfg.struct_size = C.sizeof(layouts.BhrayConfig)
+    cfg.flags = layouts.F_FUSED
+    h = C.c_void_p()
+    rc = fused_library.bhray_create(C.byref(cfg), C.byref(h))
+    assert rc == -1 and h.value is None                       # BHRAY_E_INVALID, with a message that names the build option
+    assert b"make" in fused_library.bhray_last_error(None)
+
+
 def _render(cfg, u, tex, model=None, **kw):
     rp = B.RayPass(cfg, device=0, **kw)
     rp.set_textures(*tex)

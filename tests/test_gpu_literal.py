@@ -231,7 +231,7 @@ def test_default_kernels_vs_the_literal_reading_at_the_bench_frame(method):
         _record(d)
         assert d["class_differences"] == 0, d
         assert d["median_rel_err"] < 1e-6, d
-        assert d["fraction_within_1e-4"] >= 0.995, d                    # 0.9973 measured; the meaningful bound is the relative one below
+        assert d["fraction_within_1e-4"] >= 0.997, d                    # 0.9973 (RK) / 0.9978 (Euler) measured; the meaningful bound is the relative one below
         assert d["per_pixel_norm"]["fraction_within_1e-4"] >= 0.999, d  # 0.9994 measured
 
 
@@ -309,7 +309,9 @@ def test_the_outliers_are_the_problems_not_the_kernels(method):
                                    "perturbed": int((per[..., 3] != lit[..., 3]).sum())}}
     _record(entry)
     # (a pixel whose CLASS differs - colour against direction, a hit decided in the last bit - counts as beyond; at most a handful)
-    assert entry["class_differences"]["contract"] <= 4 and entry["class_differences"]["fma"] <= 4 and entry["class_differences"]["perturbed"] <= 8, entry
+    # measured (profiles/r03_literal_distance.jsonl): contract 0 / 0, fma 0 (RK) / 1 (Euler), perturbed 0 / 0 - the contract kernel is held to
+    # what the other test of this frame demands of it (no class differs); a third evaluation and a perturbed input may flip a pixel or two
+    assert entry["class_differences"]["contract"] == 0 and entry["class_differences"]["fma"] <= 2 and entry["class_differences"]["perturbed"] <= 4, entry
     assert P.sum() > 0, "a one-ulp change of the camera position must move some pixel by more than 1e-4 - else the bar would be attainable"
     assert A.sum() <= 3 * P.sum() and Bm.sum() <= 3 * P.sum(), entry
     assert (A & Bm).sum() >= 0.7 * min(A.sum(), Bm.sum()), entry

@@ -1,0 +1,88 @@
+"""CPU: the row-partition arithmetic behind bhray_config.partition (stripes and slabs) and the slab balancer (bhray_balance_slabs) -
+pure host code of libbhray, no device.  The balancer is held against a brute-force restatement of the work model it optimises:
+a partition's work = at every ladder level, the work of the level rows its frame rows depend on (ray.wgsl:185-201)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import bhusie_amd as B
+from bhusie_amd import layouts
+
+
+def coarse_rows(fine, h, ph):
+    """rows of the coarser level that the level rows `fine` read - the shader's own binary32 arithmetic (ray.wgsl:185-201)"""
+    sf = (h - 1) // (ph - 1)
+    ry = np.float32(ph) / np.float32(h + (sf - 1))
+    tl = np.floor(np.asarray(fine, dtype=np.float32) * ry).astype(np.int64)
+    need = np.zeros(ph, dtype=bool)
+    need[np.clip(tl, 0, ph - 1)] = True
+    need[np.clip(tl + 1, 0, ph - 1)] = True
+    return np.nonzero(need)[0]
+
+
+def slab_work(cfg, work, a, b):
+    rows = np.arange(a, b) + cfg.crop_y
+    tot = 0.0
+    for l in range(cfg.levels - 1, -1, -1):
+        tot += float(work[l][rows].sum())
+        if l > 0:
+            rows = coarse_rows(rows, cfg.level_h[l], cfg.level_h[l - 1])
+    return tot
+
+
+def test_stripes_and_slabs_cover_the_frame_exactly_once():
+    cfg = B.ladder_for_frame((1920, 1080), 3, 4)
+    cfg.row_world, cfg.stripe_rows = 8, 27
+    rows = B.config_partition_rows(cfg)
+    old = B.partition_rows(1080, 8, 27)
+    assert all(np.array_equal(a, b) for a, b in zip(rows, old))
+    assert np.array_equal(np.sort(np.concatenate(rows)), np.arange(1080))
+    cfg.partition = layouts.PARTITION_SLABS
+    bounds = [0, 100, 100, 400, 555, 600, 900, 1079, 1080]          # an empty partition and a one-row partition are legal
+    for i, v in enumerate(bounds):
+        cfg.slab_row0[i] = v
+    rows = B.config_partition_rows(cfg)
+    assert [len(r) for r in rows] == [100, 0, 300, 155, 45, 300, 179, 1]
+    assert np.array_equal(np.concatenate(rows), np.arange(1080))
+    cfg.slab_row0[8] = 1081                                              # does not end at frame_h: no rows for anybody
+    assert all(len(r) == 0 for r in B.config_partition_rows(cfg))
+    cfg.slab_row0[8] = 1080; cfg.slab_row0[3] = 50                      # decreasing
+    assert all(len(r) == 0 for r in B.config_partition_rows(cfg))
+
+
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
+def test_balanced_slabs_minimise_the_largest_partition(world):
+    cfg = B.ladder_for_frame((320, 200), 3, 3)
+    rng = np.random.default_rng(world)
+    work = []
+    for l in range(cfg.levels):
+        h = cfg.level_h[l]
+        y = np.arange(h) / (h - 1.0)
+        w = 200.0 * np.exp(-((y - 0.55) / 0.12) ** 2) + 3.0 + rng.random(h)           # a hole band over a sky floor
+        work.append((w * (40 if l < 2 else 10 * (l + 1))).astype(np.uint64))
+    bounds = B.balance_slabs(cfg, work, world)
+    assert bounds[0] == 0 and bounds[-1] == 200 and all(a <= b for a, b in zip(bounds, bounds[1:]))
+    got = max(slab_work(cfg, work, a, b) for a, b in zip(bounds, bounds[1:]) if b > a)
+    # brute force over contiguous partitions: dynamic programming on the same work model
+    H = 200
+    W = np.full((H + 1, H + 1), np.inf)
+    for a in range(H):
+        for b in range(a + 1, H + 1):
+            W[a, b] = slab_work(cfg, work, a, b)
+    best = W[0, :].copy()                        # best[b] = min over partitions of [0, b) into k slabs of the largest slab
+    for k in range(2, world + 1):
+        nxt = np.full(H + 1, np.inf)
+        for b in range(1, H + 1):
+            nxt[b] = min(max(best[a], W[a, b]) for a in range(0, b)) if b >= 1 else np.inf
+            nxt[b] = min(nxt[b], best[b])                                               # a partition may own no rows
+        best = nxt
+    assert got <= best[H] * (1 + 1e-9), (got, best[H])
+    equal = max(slab_work(cfg, work, round(H * p / world), round(H * (p + 1) / world)) for p in range(world))
+    assert got < equal                                                                    # and it beats equal rows on a peaked profile
+
+
+def test_balancer_without_measured_work_gives_equal_rows():
+    cfg = B.ladder_for_frame((320, 200), 3, 3)
+    work = [np.zeros(cfg.level_h[l], dtype=np.uint64) for l in range(cfg.levels)]
+    assert B.balance_slabs(cfg, work, 4) == [0, 50, 100, 150, 200]
