@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 #include <cmath>
 #include <string>
@@ -897,6 +898,10 @@ int launch_batch(bhray_dev* c) {
     // the batches IN FLIGHT when this one is launched (completed ones are retired oldest-first, one or two event queries per launch),
     // dense from 8 partitions' worth on (emulated ranks, 20-frame blocks: N = 8 0.1018 -> 0.0992 ms per frame, N = 4 0.1469 -> 0.1403;
     // 400-frame blocks unchanged; a whole frame per GPU loses 1-2 % with it: profiles/EXPERIMENTS.md R3.11).
+    // ... and what counts is rays, not frames: a partition of a 3840x2160 frame holds four times the rays of the same partition of a
+    // 1920x1080 one, so the frames in flight are weighted by the frame's pixels against 1920x1080 (the size the thresholds were measured
+    // at; 3840x2160 over 8 partitions, 20-frame blocks: the dense build 0.2499 / 0.2407 ms per frame at 4 / 7 frames per batch against
+    // 0.2614 / 0.2550 for the latency build - profiles/r04_emu_knobs.txt).
     const int dyn = c->dynamic_dense >= 0 ? c->dynamic_dense : (c->cfg.row_world >= 4 ? 8 : 0);
     size_t in_flight = c->slots.size();
     if (dyn > 0) {
@@ -907,8 +912,10 @@ int launch_batch(bhray_dev* c) {
         }
         in_flight = (size_t)(c->batch_counter - c->retired) + 1;
     }
+    // A launch that by itself holds 2.5 frames' worth of rays is dense whatever else is in flight (the first batches of a short block).
+    const double weight = std::max(1.0, (double)c->cfg.frame_w * (double)c->cfg.frame_h / (1920.0 * 1080.0)) / (double)c->cfg.row_world;   // 1920x1080 frames' worth per frame of this partition
     const bool dense = c->dense_override >= 0 ? c->dense_override != 0
-                                              : (in_flight * (size_t)c->batch >= (size_t)(dyn > 0 ? dyn : 4) * (size_t)c->cfg.row_world);
+                                              : ((double)nb * weight >= 2.5 || (double)(in_flight * (size_t)c->batch) * weight >= (double)(dyn > 0 ? dyn : 4));
     const int literal = (c->cfg.flags & BHRAY_F_LITERAL) ? 1 : ((c->cfg.flags & BHRAY_F_EVAL_FMA) ? 2 : 0);   // the integrator's evaluation (launch_trace's `eval`)
     int bpc = trace_blocks_per_cu(S.method, S.models, count, dense, literal);
     if (c->slots.size() > 1 && bpc > 1) bpc = bpc > 4 ? 2 : (bpc / 2 > 1 ? bpc / 2 : 1);     // measured: 2 blocks per CU is best at 8-16 slots

@@ -273,7 +273,10 @@ __device__ __forceinline__ bool hit_triangle(F3 pos, F3 dir, float t_min, float 
 #define BHRAY_BVH_LDS_STACK 8      // entries of the short traversal stack in LDS (16 KB per 256-thread block: 8 blocks per CU fit in 160 KB)
 #endif
 #ifndef BHRAY_MODEL_INLINE
-#define BHRAY_MODEL_INLINE __noinline__      // the traversal as a call (measured against __forceinline__: profiles/EXPERIMENTS.md R3.6)
+#define BHRAY_MODEL_INLINE __forceinline__   // the traversal inline, in a kernel budgeted for 5 waves per SIMD (96 VGPRs): the step loop stays free of spills and what is
+                                             // parked around a flat phase is 116-156 bytes per lane once per phase.  As a __noinline__ call (rounds 2-3, 8 waves, 64 VGPRs)
+                                             // the calling convention saved 360 bytes per lane around EVERY call: 43 MB of scratch writes per 1080p launch.  Inline at 6 or 8
+                                             // waves the spills move into the step loop (2 819 / 1 610 Mrays/s, R3.6).  profiles/EXPERIMENTS.md R4.3
 #endif
 struct BvhLds { int2* stack; };     // stack: this lane's column (entry k at stack[k * BHRAY_TRACE_THREADS])
 
@@ -785,7 +788,8 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #define BHRAY_FLAT_DEFER 64        // ... or after this many rounds at the latest (measured 12/4: 2735, 48/64: 2890 Mrays/s)
 #endif
 #ifndef BHRAY_TRACE_WAVES_MESH
-#define BHRAY_TRACE_WAVES_MESH 8 // mesh variant (BVH traversal + stack): 64 VGPRs, the callee spills around the rare traversal calls; measured on the mesh workload 4 -> 3340, 6 -> 3810, 8 -> 4030 Mrays/s (lone-wave latency +5 %)
+#define BHRAY_TRACE_WAVES_MESH 5 // mesh variant (BVH traversal inline + short stack in LDS): 96 VGPRs.  Round 4, mesh workload, 20- / 200-frame blocks / one frame at a
+                                 // time: call + 8 waves 3 747 / 4 323 Mrays/s / 3.05 ms; inline + 5 waves 3 937 / 4 359 / 2.60; inline + 4 waves 3 660 / 3 995 / 2.58
 #endif
 #ifndef BHRAY_TRACE_WAVES
 #define BHRAY_TRACE_WAVES 4      // waves per SIMD the trace kernel is register-budgeted for (<=128 VGPRs): the latency build
@@ -800,6 +804,9 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #ifndef BHRAY_REFILL_MIN
 #define BHRAY_REFILL_MIN 16      // refill from the queue (one atomic on its head + a dependent load) only when this many lanes are empty, or nobody is
                                  // stepping: measured 1 / 8 / 16 / 24 / 32 / 48 -> 5 357 / 5 428 / 5 435 / 5 414 / 5 387 / 5 254 Mrays/s (Euler 8 009 -> 8 148 at 16)
+#endif
+#ifndef BHRAY_MESH_COLD_LDS
+#define BHRAY_MESH_COLD_LDS 0    // mesh variant: the cold per-lane state in LDS as in the dense build
 #endif
 #ifndef BHRAY_WITH_FUSED
 #define BHRAY_WITH_FUSED 0       // 1 (make fused -> libbhray_fused.so): the fused ladder, BHRAY_F_FUSED - measured slower than the launch-per-level ladder, a tested option
@@ -861,7 +868,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
 #ifndef BHRAY_NO_SPAN
     if (Fb[0].span && threadIdx.x == 0) atomicMax(&Fb[0].span[0], ~(unsigned long long)wall_clock64());
 #endif
-    constexpr bool COLD_LDS = DENSE && !MODELS;
+    constexpr bool COLD_LDS = (DENSE && !MODELS) || (MODELS && BHRAY_MESH_COLD_LDS != 0);
     __shared__ float cold_lds[COLD_LDS ? (8 + BHRAY_HIT_LDS) * BHRAY_TRACE_THREADS : 1];
     // mesh variant: the short traversal stacks (trace_ray_model) live in LDS
     // (dynamic LDS: with a static array the compiler assumes 64 KB of LDS per CU - gfx950 has 160 KB -, concludes that occupancy is

@@ -60,6 +60,14 @@ private:
     bhray_model* m_ = nullptr;
 };
 
+// How a frame reaches a consumer that is not a HIP client of this GPU (the reference's SkyPipeline samples the ray output as a wgpu
+// texture, ray_pipeline.rs:297-299, mod.rs:215) - the three forms of the drop-in shim of INTEGRATION.md §3:
+enum class Handoff {
+    Sync,        // finish() = bhray_read_hdr of the frame just rendered: the naive binding, one frame at a time
+    AsyncHdr,    // pass() also enqueues the RGBA32F copy into pinned memory (bhray_read_hdr_async); finish() hands over the OLDEST frame in flight
+    AsyncSky     // pass() also runs the sky pass in the library (sky.wgsl) and enqueues the copy of its RGBA16F image: half the bytes
+};
+
 // The chain of RayPipelines of one frame (mod.rs:181-207) as one object.
 class RayPipeline {
 public:
@@ -86,8 +94,55 @@ public:
         cfg_.frames_in_flight = frames_in_flight; cfg_.frames_per_batch = frames_per_batch;
         check(bhray_create(&cfg_, &ctx_));
     }
+    // The reference host's own configuration: the shipped 72x41 x3 x4 ladder, `frames_in_flight` = the swap chain's
+    // desired_maximum_frame_latency (2, mod.rs:108), optionally BHRAY_F_TEMPORAL (consecutive frames of an interactive host are similar)
+    RayPipeline(std::pair<uint32_t, uint32_t> base, uint32_t multiplier, uint32_t levels, int device, uint32_t frames_in_flight, uint32_t flags,
+                uint32_t speculative_levels) {
+        std::memset(&cfg_, 0, sizeof cfg_);
+        check(bhray_ladder_from_base(base.first, base.second, multiplier, levels, &cfg_));
+        cfg_.device = device; cfg_.frames_in_flight = frames_in_flight; cfg_.flags = flags; cfg_.speculative_levels = speculative_levels;
+        check(bhray_create(&cfg_, &ctx_));
+    }
     RayPipeline(const RayPipeline&) = delete;
-    ~RayPipeline() { bhray_destroy(ctx_); }
+    ~RayPipeline() {
+        if (ctx_) (void)bhray_sync(ctx_);
+        for (void* p : staging_) (void)bhray_host_free(p);
+        bhray_destroy(ctx_);
+    }
+    // ---- the drop-in shim's per-frame pair: pass_handoff() where the reference dispatches its ray pipelines
+    // (mod.rs:415-417), finish() where the host needs the pixels (before sky_pipeline.pass(), mod.rs:419)
+    void enable_handoff(Handoff h, uint32_t frames_in_flight) {
+        handoff_ = h; ring_ = frames_in_flight < 1 ? 1 : frames_in_flight;
+        const size_t bytes = (size_t)cfg_.frame_w * cfg_.frame_h * (h == Handoff::AsyncSky ? 8 : 16);
+        for (uint32_t i = 0; i < ring_; i++) { void* p = nullptr; check(bhray_host_alloc(bytes, &p)); staging_.push_back(p); }
+        tickets_.assign(ring_, 0); pending_.assign(ring_, false);
+    }
+    void pass_handoff() {
+        const uint32_t k = (uint32_t)(frame_ % ring_);
+        if (pending_[k]) { check(bhray_wait_read(ctx_, tickets_[k]), ctx_); pending_[k] = false; }   // (finish() already took it unless the host skipped a frame)
+        pass();
+        if (handoff_ == Handoff::AsyncHdr) {
+            check(bhray_read_hdr_async(ctx_, (float*)staging_[k], (size_t)cfg_.frame_w * 16, &tickets_[k]), ctx_); pending_[k] = true;
+        } else if (handoff_ == Handoff::AsyncSky) {
+            resolve_sky();
+            check(bhray_read_sky_async(ctx_, (uint16_t*)staging_[k], (size_t)cfg_.frame_w * 8, &tickets_[k]), ctx_); pending_[k] = true;
+        }
+        frame_++;
+    }
+    // The pixels the host uploads into its texture (queue.write_texture): Sync - the frame just rendered (RGBA32F); Async* - the OLDEST
+    // frame in flight, i.e. the frame enqueued ring-1 passes ago (nullptr while the pipeline fills): with a ring of 2 the host shows frame
+    // k-1 while frame k renders, which is what its swap chain's frame latency of 2 does to every frame anyway.
+    const void* finish() {
+        if (handoff_ == Handoff::Sync) {
+            check(bhray_read_hdr(ctx_, (float*)staging_[0], (size_t)cfg_.frame_w * 16), ctx_);
+            return staging_[0];
+        }
+        if (frame_ < ring_) return nullptr;
+        const uint32_t k = (uint32_t)(frame_ % ring_);             // the slot the NEXT pass reuses = the oldest frame in flight
+        if (pending_[k]) { check(bhray_wait_read(ctx_, tickets_[k]), ctx_); pending_[k] = false; }
+        return staging_[k];
+    }
+    void drain() { for (uint32_t k = 0; k < ring_; k++) if (pending_.size() > k && pending_[k]) { check(bhray_wait_read(ctx_, tickets_[k]), ctx_); pending_[k] = false; } }
     std::pair<uint32_t, uint32_t> resolution() const { return {cfg_.frame_w, cfg_.frame_h}; }
     void set_texture(int slot, const uint8_t* rgba8, uint32_t w, uint32_t h) { check(bhray_set_texture(ctx_, slot, rgba8, w, h), ctx_); }
     void upload_model(const Model& m) { bhray_model_desc d = m.desc(); check(bhray_upload_model(ctx_, 0, &d), ctx_); }
@@ -105,6 +160,12 @@ public:
 private:
     bhray_config cfg_;
     bhray_ctx* ctx_ = nullptr;
+    Handoff handoff_ = Handoff::Sync;
+    uint32_t ring_ = 1;
+    uint64_t frame_ = 0;
+    std::vector<void*> staging_;
+    std::vector<uint64_t> tickets_;
+    std::vector<bool> pending_;
 };
 
 // Renderer::{new, render} restricted to the ray pass.
@@ -116,6 +177,11 @@ public:
     explicit Renderer(int device = 0) : ray_pipeline_({72, 41}, 3, 4, device) {}               // mod.rs:177-179
     Renderer(std::pair<uint32_t, uint32_t> base, uint32_t multiplier, uint32_t levels, int device = 0) : ray_pipeline_(base, multiplier, levels, device) {}
     Renderer(std::pair<uint32_t, uint32_t> base, uint32_t multiplier, uint32_t levels, const std::vector<int>& devices) : ray_pipeline_(base, multiplier, levels, devices) {}
+    // the drop-in host: frames_in_flight = the swap chain's frame latency, a hand-off form, optionally temporal speculation
+    Renderer(std::pair<uint32_t, uint32_t> base, uint32_t multiplier, uint32_t levels, int device, uint32_t frames_in_flight, Handoff h, bool temporal)
+        : ray_pipeline_(base, multiplier, levels, device, frames_in_flight, temporal ? (uint32_t)BHRAY_F_TEMPORAL : 0u, temporal ? 0u : (levels >= 4 ? 3u : (levels >= 3 ? 2u : 0u))) {       // a host that shows every frame wants the shortest chain: 3 speculative levels (1.08 against 1.21 ms with 2)
+        ray_pipeline_.enable_handoff(h, frames_in_flight);
+    }
     RayPipeline& ray_pipeline() { return ray_pipeline_; }
     void set_model(const Model& m) { ray_pipeline_.upload_model(m); ray_details.model_count = 1; }   // mod.rs:384
     void render(float dt) {                                                                     // mod.rs:378-420
@@ -124,6 +190,15 @@ public:
         const float materials[32] = {0};
         ray_pipeline_.set_materials(materials);                                                 // mod.rs:389
         ray_pipeline_.pass();
+    }
+    // the same frame through the drop-in shim: update + pass_handoff (mod.rs:378-417), then finish() where the sky pass would start
+    const void* render_handoff(float dt) {
+        ray_details.time += dt;
+        ray_pipeline_.set_uniforms(camera.uniform(), black_hole.uniform(), ray_details);
+        const float materials[32] = {0};
+        ray_pipeline_.set_materials(materials);
+        ray_pipeline_.pass_handoff();
+        return ray_pipeline_.finish();
     }
 private:
     RayPipeline ray_pipeline_;

@@ -11,7 +11,7 @@ the frames can be compared bit for bit:
     every operator one IEEE binary32 operation in source order (numpy.float32 scalars); AbstractFloat constant expressions in
     binary64, rounded once when they meet an f32 (numpy's weak-scalar rule is exactly WGSL's); dot = (x*x + y*y) + z*z;
     vector / scalar = vector * (1 / scalar); pow(x, 2 | 4 | 5) by multiplication, pow(x, -0.001) / acos / atan2 / sin / cos / tan by
-    the portable forms (taken from oracle/np_ray.py), pow(x, 1.3) by glibc powf; min / max / clamp by compare-select; textures RGBA8 unorm,
+    the portable forms (oracle/wgsl_builtins.py: a transcription of its own, shared with no restatement), pow(x, 1.3) by glibc powf; min / max / clamp by compare-select; textures RGBA8 unorm,
     bilinear, clamp-to-edge (src/renderer/texture.rs:16-69); float % = truncated remainder; out-of-range textureLoad clamped.
 Deviation D1 (the Runge-Kutta retry loop of ray.wgsl:425-451 cannot terminate once e_max > 1, because it cannot change h): a `while` loop
 whose variables are bit-identical at the top of two successive passes is left there - which yields exactly what one pass computed.
@@ -29,7 +29,7 @@ import struct
 
 import numpy as np
 
-from . import np_ray as N
+from . import wgsl_builtins as WB       # the portable forms of N4, written separately from the restatements this module pins (see its header)
 
 F = np.float32
 _LIBM = ctypes.CDLL("libm.so.6")
@@ -555,11 +555,11 @@ def bi_smoothstep(e0, e1, x):
 
 
 def bi_all(v): return all(v.c) if isinstance(v, Vec) else bool(v)
-def bi_sin(x): return N.bh_sin(_arr1(x))[0]
-def bi_cos(x): return N.bh_cos(_arr1(x))[0]
-def bi_tan(x): return N.bh_sin(_arr1(x))[0] / N.bh_cos(_arr1(x))[0]
-def bi_acos(x): return N.bh_acos(_arr1(x))[0]
-def bi_atan2(y, x): return N.bh_atan2(_arr1(y), _arr1(x))[0]
+def bi_sin(x): return WB.sin(F(x))
+def bi_cos(x): return WB.cos(F(x))
+def bi_tan(x): return WB.tan(F(x))
+def bi_acos(x): return WB.acos(F(x))
+def bi_atan2(y, x): return WB.atan2(F(y), F(x))
 def bi_i32(x): return int(x)
 def bi_f32(x): return F(x)
 def bi_u32(x): return int(x)
@@ -575,7 +575,7 @@ def _pow1(x, y):
     if y == 5.0:
         return ((x * x) * (x * x)) * x
     if y == float(F(-0.001)):
-        return N.bh_pow_m001(_arr1(x))[0]
+        return WB.pow_m001(x)
     return F(_LIBM.powf(float(x), float(F(y))))              # pow(., 1.3): glibc's powf, as oracle/ray_oracle.c calls it (N4; numpy's
                                                              # float32 power is a vectorised approximation that differs from it in the last place)
 
@@ -605,7 +605,8 @@ def bi_textureLoad(t, p, lvl):
 
 
 def bi_textureSampleLevel(t, s, uv, lvl):
-    return Vec(F(v) for v in N.sample_bilinear(t.rgba8, _arr1(uv.c[0]), _arr1(uv.c[1]))[0])
+    with np.errstate(all="ignore"):
+        return Vec(WB.sample_bilinear(t.rgba8, uv.c[0], uv.c[1]))
 
 
 class StoreTarget:
@@ -922,6 +923,24 @@ def render_level(ns, size, prev=None, rows=None):
     out = np.full((h, w, 4), np.nan, dtype=np.float32)
     for (x, y), v in target.out.items():
         out[y, x] = v
+    return out
+
+
+def render_pixels(ns, size, prev, pixels):
+    """`main` for the listed (x, y) pixels of a (W, H) level only (samples of a frame too large to execute whole): returns an
+    (n, 4) float32 array in the order of `pixels`; prev as in render_level."""
+    w, h = size
+    target = StoreTarget(w, h)
+    ns["G_color_buffer"] = target
+    ns["G_t_prev"] = Texture(f32img=np.zeros((1, 1, 4), np.float32) if prev is None else np.ascontiguousarray(prev, dtype=np.float32))
+    main = ns["fn_main"]
+    out = np.full((len(pixels), 4), np.nan, dtype=np.float32)
+    with np.errstate(all="ignore"):
+        for i, (x, y) in enumerate(pixels):
+            main(Vec((int(x), int(y), 0)))
+            v = target.out.get((int(x), int(y)))
+            if v is not None:
+                out[i] = v
     return out
 
 

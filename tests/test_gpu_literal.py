@@ -317,3 +317,46 @@ def test_the_outliers_are_the_problems_not_the_kernels(method):
     assert (A & Bm).sum() >= 0.7 * min(A.sum(), Bm.sum()), entry
     assert An.sum() * 3 <= A.sum() and Bn.sum() * 3 <= Bm.sum(), entry
     assert An.sum() <= 1e-3 * n and Bn.sum() <= 1e-3 * n and An.sum() <= 3 * max(1, Pn.sum()) + 0.0002 * n, entry
+
+
+# ---- the executed-shader pin at the METRIC'S OWN FRAME (tests/golden/wgsl_exec_native_samples.npz: 6 000 seeded pixels of the last level of
+# the reference-native 72x41 -> 1918x1081 adaptive-RK ladder, each the result of running the reference's `main` on that pixel)
+def _native():
+    n = np.load(os.path.join(GOLD, "wgsl_exec_native_samples.npz"))
+    u = tuple(n[k].tobytes() for k in ("camera", "black_hole", "details"))
+    tex = (n["t_temp"], n["t_disk"], n["t_sky"])
+    cfg = B.ladder_from_base((72, 41), 3, 4)
+    assert cfg.sizes() == [tuple(int(v) for v in s) for s in n["sizes"]] and (cfg.crop_x, cfg.crop_y) == (0, 0)
+    return n, u, tex, cfg
+
+
+def test_literal_kernel_reproduces_the_executed_shader_at_the_native_frame():
+    n, u, tex, cfg = _native()
+    frame = _gpu(cfg, u, tex, literal=True).read_hdr()
+    px = n["pixels"]
+    got, want = frame[px[:, 1], px[:, 0]], n["values"]
+    assert np.array_equal(got[:, 3], want[:, 3]), "pixel classes differ from the executed shader"
+    d = want[:, 3] == 0
+    assert d.sum() >= 2500
+    assert np.array_equal(got[d].view(np.uint32), want[d].view(np.uint32)), f"{int((got[d].view(np.uint32) != want[d].view(np.uint32)).any(axis=1).sum())} direction pixels are not bit-identical"
+    e = np.abs(got[~d] - want[~d]) / np.maximum(np.abs(want[~d]), T.ABS_FLOOR)
+    assert float(e.max()) <= 2e-5, float(e.max())                                   # colours: device powf against glibc's (<= 1.2e-5 measured)
+    lvl2 = _gpu(cfg, u, tex, literal=True).read_level(2)
+    cp = n["coarse_pixels"]
+    gc, wc = lvl2[cp[:, 1], cp[:, 0]], n["coarse_values"]
+    dc = wc[:, 3] == 0
+    assert np.array_equal(gc[:, 3], wc[:, 3]) and np.array_equal(gc[dc].view(np.uint32), wc[dc].view(np.uint32))
+
+
+def test_default_kernel_against_the_executed_shader_at_the_native_frame():
+    from tests.test_wgsl_pin import native_distance_by_kind
+    n, u, tex, cfg = _native()
+    frame = _gpu(cfg, u, tex, speculative_levels=2).read_hdr()
+    px = n["pixels"]
+    got, want = frame[px[:, 1], px[:, 0]], n["values"]
+    assert np.array_equal(got[:, 3], want[:, 3]), "pixel classes differ from the executed shader"
+    rows = native_distance_by_kind(n, got)
+    _record({"config": "reference-native 1918x1081 adaptive RK, 6000 executed-shader sample pixels", "default_kernels_vs": "ray.wgsl as executed (oracle/wgsl_exec.py)",
+             "by_kind": {name: {"fraction_within_1e-4_per_channel": round(a, 4), "fraction_within_1e-4_of_the_norm": round(b, 4)} for name, a, b in rows}})
+    for name, f_ch, f_norm in rows:                                                  # the bounds of tests/test_wgsl_pin.py (the contract oracle = these kernels, bit for bit)
+        assert f_ch >= {"traced_escaped": 0.90, "border": 0.88}.get(name, 0.995) and f_norm >= 0.99, (name, f_ch, f_norm)

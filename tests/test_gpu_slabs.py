@@ -35,12 +35,24 @@ def test_row_work_is_the_oracles_iteration_count_per_level_row(method, spec):
     sc = T.oracle_scene(*u, tex)
     sizes = cfg.sizes()
     imgs = O.render_ladder(sc, sizes)
+    # only the level rows a frame row depends on are rendered (the frame is a window of the last level): ray.wgsl:185-201, top down
+    needed = [None] * len(sizes)
+    rows = np.arange(cfg.crop_y, cfg.crop_y + cfg.frame_h)
+    for l in range(len(sizes) - 1, -1, -1):
+        needed[l] = np.zeros(sizes[l][1], dtype=bool)
+        needed[l][rows] = True
+        if l > 0:
+            h, ph = sizes[l][1], sizes[l - 1][1]
+            ry = np.float32(ph) / np.float32(h + ((h - 1) // (ph - 1) - 1))
+            tl = np.floor(rows.astype(np.float32) * ry).astype(np.int64)
+            rows = np.unique(np.concatenate([np.clip(tl, 0, ph - 1), np.clip(tl + 1, 0, ph - 1)]))
     for l, (w, h) in enumerate(sizes):
         its = O.render_aux(sc, (w, h))[..., 1].astype(np.int64)
         traced = np.ones((h, w), dtype=bool) if l < max(spec, 1) else O.classify_level(sc, (w, h), imgs[l - 1]) == 2
+        traced &= needed[l][:, None]
         if l == len(sizes) - 1:                                           # the frame window of the last level
             win = np.zeros((h, w), dtype=bool)
-            win[cfg.crop_y:cfg.crop_y + cfg.frame_h, cfg.crop_x:cfg.crop_x + cfg.frame_w] = True
+            win[:, cfg.crop_x:cfg.crop_x + cfg.frame_w] = True
             traced &= win
         want = (its * traced).sum(axis=1)
         assert np.array_equal(got[l].astype(np.int64), want), (l, np.nonzero(got[l].astype(np.int64) != want)[0][:8])

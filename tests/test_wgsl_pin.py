@@ -157,3 +157,84 @@ def test_executor_parses_the_whole_shader_and_nothing_is_left_out():
     assert all(("fn_" + f) in ns for f in fns)
     # AbstractFloat constants stay binary64 until they meet an f32 (b_1 - b_a_1 is one rounding, not three)
     assert isinstance(ns["C_b_1"], float) and ns["C_b_1"] == 37.0 / 378.0 and isinstance(ns["C_PI"], np.float32)
+
+
+# ---- the pin at the METRIC'S OWN FRAME: 6 000 seeded pixels of the last level of the reference-native 72x41 -> 1918x1081 adaptive-RK
+# ladder, each produced by running the reference's `main` on that pixel (tests/golden/make_golden_wgsl_native.py)
+@pytest.fixture(scope="module")
+def native():
+    return np.load(os.path.join(GOLD, "wgsl_exec_native_samples.npz"))
+
+
+@pytest.fixture(scope="module")
+def native_literal_ladder(native):
+    u = tuple(native[k].tobytes() for k in ("camera", "black_hole", "details"))
+    tex = (native["t_temp"], native["t_disk"], native["t_sky"])
+    sizes = [tuple(int(v) for v in s) for s in native["sizes"]]
+    O.set_literal(True)
+    try:
+        return O.render_ladder(O.OracleScene(*u, *tex), sizes)
+    finally:
+        O.set_literal(False)
+
+
+def test_native_samples_cover_every_kind_of_pixel(native):
+    kinds = [k.decode() for k in native["kinds"]]
+    assert kinds == ["copied", "interpolated", "traced_escaped", "traced_disk", "traced_captured", "border"]
+    assert [tuple(s) for s in native["sizes"]] == [(72, 41), (214, 121), (640, 361), (1918, 1081)]       # mod.rs:177-205
+    n = np.bincount(native["kind"], minlength=6)
+    assert native["pixels"].shape == (6000, 2) and (n == 1000).all()
+    v = native["values"]
+    assert not np.isnan(v[..., 3]).any() and set(np.unique(v[:, 3])) == {0.0, 1.0}
+    k = native["kind"]
+    assert (v[k == 2][:, 3] == 0).all() and (v[k == 3][:, 3] == 1).all() and (v[k == 4][:, :3] == 0).all()
+    assert int(np.frombuffer(native["details"].tobytes(), dtype=np.int32)[3]) == 1                         # adaptive RK
+
+
+def test_c_oracle_literal_reproduces_every_word_of_the_native_samples(native, native_literal_ladder):
+    px = native["pixels"]
+    got = native_literal_ladder[3][px[:, 1], px[:, 0]]
+    want = native["values"]
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"{int((got.view(np.uint32) != want.view(np.uint32)).any(axis=1).sum())} of 6000 sample pixels differ"
+    cp = native["coarse_pixels"]
+    gc, wc = native_literal_ladder[2][cp[:, 1], cp[:, 0]], native["coarse_values"]
+    assert np.array_equal(gc.view(np.uint32), wc.view(np.uint32))
+
+
+def test_contract_oracle_against_the_native_samples(native):
+    """The shipped evaluation (the contract: fused multiply-add + reassociation in the integrator) at the metric's frame, against the
+    executed shader: no pixel class differs; population bounds as in tests/test_gpu_literal.py (the GPU kernels equal this oracle bit for bit)."""
+    u = tuple(native[k].tobytes() for k in ("camera", "black_hole", "details"))
+    tex = (native["t_temp"], native["t_disk"], native["t_sky"])
+    sizes = [tuple(int(v) for v in s) for s in native["sizes"]]
+    img = O.render_ladder(O.OracleScene(*u, *tex), sizes)[3]
+    px = native["pixels"]
+    got, want = img[px[:, 1], px[:, 0]], native["values"]
+    assert np.array_equal(got[:, 3], want[:, 3]), "pixel classes differ from the executed shader"
+    for name, f_ch, f_norm in native_distance_by_kind(native, got):
+        # measured (CPU contract oracle = the default kernels bit for bit), per channel / against the pixel's norm:
+        #   copied 1.000 / 1.000   interpolated 0.999 / 1.000   traced_escaped 0.925 / 0.998   traced_disk 0.997 / 0.998   traced_captured 1 / 1   border 0.901 / 0.994
+        # The traced-and-escaped rays of the LAST level are the 0.5 % of a frame's pixels that pass closest to the hole and still escape (everything
+        # easier was interpolated): unit vectors carrying ~1e-6 of accumulated rounding, more than 1e-4 RELATIVE in a channel near zero (DESIGN.md §2).
+        lo_ch = {"traced_escaped": 0.90, "border": 0.88}.get(name, 0.995)
+        assert f_ch >= lo_ch and f_norm >= 0.99, (name, f_ch, f_norm)
+
+
+def native_distance_by_kind(native, got):
+    """[(kind, fraction within 1e-4 per channel, fraction within 1e-4 of the pixel's norm)] of `got` against the executed-shader samples"""
+    want, k = native["values"], native["kind"]
+    err = np.abs(got[:, :3] - want[:, :3]) / np.maximum(np.abs(want[:, :3]), 1e-3)
+    per_px = err.max(axis=1)
+    nrm = np.linalg.norm(got[:, :3] - want[:, :3], axis=1) / np.maximum(np.linalg.norm(want[:, :3], axis=1), 1e-3)
+    return [(name.decode(), float((per_px[k == i] <= 1e-4).mean()), float((nrm[k == i] <= 1e-4).mean())) for i, name in enumerate(native["kinds"])]
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/renderer/shaders/ray.wgsl"), reason="the reference is not on this machine")
+def test_native_fixture_is_what_executing_the_shader_text_gives(native, native_literal_ladder):
+    from oracle import wgsl_exec as W
+    ns = W.compile_shader()
+    u = tuple(native[k].tobytes() for k in ("camera", "black_hole", "details"))
+    W.bind_scene(ns, *u, native["t_temp"], native["t_disk"], native["t_sky"])
+    pick = np.concatenate([np.nonzero(native["kind"] == k)[0][:6] for k in range(6)])
+    got = W.render_pixels(ns, (1918, 1081), native_literal_ladder[2], [tuple(int(v) for v in native["pixels"][i]) for i in pick])
+    assert np.array_equal(got.view(np.uint32), native["values"][pick].view(np.uint32))
