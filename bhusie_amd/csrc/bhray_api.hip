@@ -857,71 +857,32 @@ int dev_set_uniforms(bhray_dev* c, const void* cam32, const void* bh132, const v
     return BHRAY_OK;
 }
 
-// Enqueues every launch of the batch staged in the current slot: one argument block (FrameParams + per-launch FrameLaunch
-// arrays) copied to the device, then the same launch sequence a single frame needs, each launch covering all staged frames.
+// ------------------------------------------------------------------------------------------
+// One batch = the frames staged in a slot.  BatchPlan lays out the argument block (FrameParams[B], then one FrameLaunch[nb] array per
+// launch, in the slot's pinned staging) and the launch sequence, one method per ladder mode; launch_batch enqueues it.
+// ------------------------------------------------------------------------------------------
 namespace {
-int launch_batch(bhray_dev* c) {
-    Slot& S = c->slots[(size_t)(c->batch_counter % c->slots.size())];
-    const uint32_t nb = S.pending;
-    if (nb == 0) return BHRAY_OK;
-    HIPCHK(c, hipSetDevice(c->device));
-    const uint32_t nl = c->cfg.levels;
-    // BHRAY_F_TIMING_SPARSE: events around the launches of every 4th batch only (every recorded event is a packet in the stream's
-    // queue: 12 per frame cost a saturated device 1.6 %)
-    const bool sparse = (c->cfg.flags & BHRAY_F_TIMING_SPARSE) != 0;
-    const bool count = (c->cfg.flags & BHRAY_F_COUNTERS) != 0;
-    const bool timing = (c->cfg.flags & (BHRAY_F_TIMING | BHRAY_F_TIMING_SPARSE)) != 0 && (!sparse || (c->batch_counter & 3u) == 0);
-    if ((c->cfg.flags & (BHRAY_F_TIMING | BHRAY_F_TIMING_SPARSE)) != 0 && !timing) {
-        const size_t ring0 = (size_t)(c->batch_counter % BHRAY_TIMING_RING);
-        c->ring_frames[ring0] = 0; c->sky_recorded[ring0] = 0;          // this batch carries no events
-    }
-    hipStream_t st = S.stream;
-    const uint32_t B = c->batch;
-    const FrameParams* dP = (const FrameParams*)S.d_args;
-    size_t args_used = (size_t)B * sizeof(FrameParams);
+struct Launch { int kind; const FrameLaunch* d; int blocks; bool count; std::vector<int> ev_before, ev_after; int build = -1; bool fixup = false; int levels = 1; FrameLaunch* h = nullptr; };   // kind 0 classify, 1 trace; timing events recorded around it; build: -1 the ctx's trace build, 0 latency, 1 dense
+
+struct BatchPlan {
+    bhray_dev* c;
+    Slot& S;
+    const uint32_t nb, nl;             // frames staged, ladder levels
+    const bool count;                  // BHRAY_F_COUNTERS
+    const int literal;                 // the integrator's evaluation (launch_trace's `eval`)
+    const int grid;                    // persistent trace blocks of the ctx's trace build
+    hipStream_t st;
+    size_t args_used;
+    std::vector<Launch> seq;
+    uint32_t first_normal = 0;         // first level that still needs its own classify + trace pair
+
     // argument block of the next launch: nb FrameLaunch entries on the host, and their device address
-    auto next_launch = [&](FrameLaunch*& h, const FrameLaunch*& d) {
+    void next_launch(FrameLaunch*& h, const FrameLaunch*& d) {
         h = (FrameLaunch*)(S.h_args + args_used); d = (const FrameLaunch*)(S.d_args + args_used);
         args_used += (size_t)nb * sizeof(FrameLaunch);
         memset(h, 0, (size_t)nb * sizeof(FrameLaunch));
-    };
-    struct Launch { int kind; const FrameLaunch* d; int blocks; bool count; std::vector<int> ev_before, ev_after; int build = -1; bool fixup = false; int levels = 1; FrameLaunch* h = nullptr; };   // kind 0 classify, 1 trace; timing events recorded around it; build: -1 the ctx's trace build, 0 latency, 1 dense
-    std::vector<Launch> seq;
-    // Persistent trace grid: (resident blocks per CU) x CUs.  With several batches in flight each launch takes only
-    // half of the block slots: the kernels of the other batches fill the rest, and a wave of a half-size grid pulls
-    // more than one load of rays, so the refill keeps its lanes busy (+4 % at 16 slots).
-    // Register budget of the no-mesh trace kernel (bhray_kernels.hip): the dense build when the device is saturated with
-    // rays - at least ~4 whole frames' worth in flight (slots x frames per batch / row partitions) - otherwise the latency
-    // build (measured on MI355X: 1920x1080, 16 slots: 4830 vs 4160 Mrays/s; 1/8 row tile, 16 slots x 8 frames: 0.070 vs
-    // 0.080 ms per frame; one slot: the latency build is 7-15 % faster per launch).
-    // ... with four or more row partitions a rank's launches are small and a timed block may hold only a few batches: there the count is
-    // the batches IN FLIGHT when this one is launched (completed ones are retired oldest-first, one or two event queries per launch),
-    // dense from 8 partitions' worth on (emulated ranks, 20-frame blocks: N = 8 0.1018 -> 0.0992 ms per frame, N = 4 0.1469 -> 0.1403;
-    // 400-frame blocks unchanged; a whole frame per GPU loses 1-2 % with it: profiles/EXPERIMENTS.md R3.11).
-    // ... and what counts is rays, not frames: a partition of a 3840x2160 frame holds four times the rays of the same partition of a
-    // 1920x1080 one, so the frames in flight are weighted by the frame's pixels against 1920x1080 (the size the thresholds were measured
-    // at; 3840x2160 over 8 partitions, 20-frame blocks: the dense build 0.2499 / 0.2407 ms per frame at 4 / 7 frames per batch against
-    // 0.2614 / 0.2550 for the latency build - profiles/r04_emu_knobs.txt).
-    const int dyn = c->dynamic_dense >= 0 ? c->dynamic_dense : (c->cfg.row_world >= 4 ? 8 : 0);
-    size_t in_flight = c->slots.size();
-    if (dyn > 0) {
-        while (c->retired < c->batch_counter) {
-            const Slot& O = c->slots[(size_t)(c->retired % c->slots.size())];
-            if (O.batch_id == c->retired && hipEventQuery(O.done) != hipSuccess) break;
-            c->retired++;
-        }
-        in_flight = (size_t)(c->batch_counter - c->retired) + 1;
     }
-    // A launch that by itself holds 2.5 frames' worth of rays is dense whatever else is in flight (the first batches of a short block).
-    const double weight = std::max(1.0, (double)c->cfg.frame_w * (double)c->cfg.frame_h / (1920.0 * 1080.0)) / (double)c->cfg.row_world;   // 1920x1080 frames' worth per frame of this partition
-    const bool dense = c->dense_override >= 0 ? c->dense_override != 0
-                                              : ((double)nb * weight >= 2.5 || (double)(in_flight * (size_t)c->batch) * weight >= (double)(dyn > 0 ? dyn : 4));
-    const int literal = (c->cfg.flags & BHRAY_F_LITERAL) ? 1 : ((c->cfg.flags & BHRAY_F_EVAL_FMA) ? 2 : 0);   // the integrator's evaluation (launch_trace's `eval`)
-    int bpc = trace_blocks_per_cu(S.method, S.models, count, dense, literal);
-    if (c->slots.size() > 1 && bpc > 1) bpc = bpc > 4 ? 2 : (bpc / 2 > 1 ? bpc / 2 : 1);     // measured: 2 blocks per CU is best at 8-16 slots
-    if (c->bpc_override > 0) bpc = c->bpc_override;
-    const int grid = c->grid_override > 0 ? c->grid_override : c->num_cus * bpc;
-    auto level_params = [&](const FrameRes& R, uint32_t l, LevelParams& L) {
+    void level_params(const FrameRes& R, uint32_t l, LevelParams& L) const {
         const Level& Lv = c->levels[l];
         const bool last = (l == nl - 1);
         memset(&L, 0, sizeof L);
@@ -940,18 +901,16 @@ int launch_batch(bhray_dev* c) {
             L.out = R.level_out[l]; L.out_pitch = Lv.w; L.out_x0 = 0; L.rowmap = nullptr; L.x0 = 0; L.x1 = Lv.w;
         }
         L.rows = Lv.d_rows; L.nrows = (int)Lv.rows.size();
-    };
-    auto classify_blocks = [&](uint32_t l) {
+    }
+    int classify_blocks(uint32_t l) const {
         const Level& Lv = c->levels[l];
         const int span = (l == nl - 1) ? (int)c->cfg.frame_w : Lv.w;
         const int tiles_x = (span + 7) / 8, tiles_y = ((int)Lv.rows.size() + 7) / 8;
         return ((tiles_x + BHRAY_CLASSIFY_BX - 1) / BHRAY_CLASSIFY_BX) * ((tiles_y + BHRAY_CLASSIFY_BY - 1) / BHRAY_CLASSIFY_BY);
-    };
-    const uint32_t ns = c->cfg.speculative_levels;
-    uint32_t first_normal = 0;
-    const bool any_rows = !c->levels[nl - 1].rows.empty();    // a partition without rows has nothing to launch (then no level has rows)
-    const bool fused = c->fz.on && any_rows;
-    if (fused) {
+    }
+
+    // BHRAY_F_FUSED: one persistent launch runs every level (bhray_fused.inc; a build option)
+    int fused(uint32_t ns) {
         // ONE launch for the whole ladder of the batch's frames (bhray_internal.h: fused ladder): the tile state is reset, then the
         // persistent kernel classifies tiles and traces rays as their dependencies resolve.
         const FusedTables& Z = c->fz;
@@ -998,8 +957,11 @@ int launch_batch(bhray_dev* c) {
         fb_ = fb_ > 2 ? 2 : fb_;
         if (c->bpc_override > 0) fb_ = c->bpc_override;
         seq.push_back({4, d, (c->grid_override > 0 ? c->grid_override : c->num_cus * fb_), count, {}, after});
+        return BHRAY_OK;
     }
-    if (ns && any_rows && !fused) {
+
+    // speculative_levels = ns: every needed pixel of levels 0..ns-1 traced in ONE launch, then classified
+    int speculative(uint32_t ns) {
         // (1) every needed pixel of levels 0..ns-1 into ONE level-tagged queue, (2) one trace launch over it,
         // (3) classify levels 1..ns-1 against the traced images.  Queue control words of level 0 serve the merged queue.
         for (uint32_t l = 0; l < ns; l++) {
@@ -1040,9 +1002,11 @@ int launch_batch(bhray_dev* c) {
             seq.push_back({0, d, classify_blocks(l), count, {(int)(3 * l)}, {(int)(3 * l + 1), (int)(3 * l + 2)}});   // no trace launch of its own
         }
         first_normal = ns;
+        return BHRAY_OK;
     }
-    const bool temporal = (c->cfg.flags & BHRAY_F_TEMPORAL) != 0;
-    if (temporal && any_rows && !fused) {
+
+    // BHRAY_F_TEMPORAL: the previous frame's traced set in ONE launch, then the ladder fixes up what that prediction missed
+    int temporal() {
         // Temporal speculation: ONE launch traces, for every level, the pixels the previous frame held in this slot position had
         // to trace (its exact classification recorded them); then the ladder runs as usual, except that a pixel that needs tracing
         // and was delivered by the predicted launch (stamp) is not traced again.  With a perfect prediction the per-level trace
@@ -1105,21 +1069,27 @@ int launch_batch(bhray_dev* c) {
             seq.push_back({1, d, c->num_cus * trace_blocks_per_cu(S.method, S.models, count, 0, literal), count, {}, {(int)(3 * l + 2)}, 0});
         }
         first_normal = nl;
+        return BHRAY_OK;
     }
-    const uint32_t nu = temporal ? 0 : c->cfg.superset_levels;
-    const uint32_t u0 = nu ? nl - nu : nl;                     // first level of the superset group
-    for (uint32_t l = first_normal; l < u0 && any_rows && !fused; l++) {
-        FrameLaunch* h; const FrameLaunch* d; next_launch(h, d);
-        for (uint32_t k = 0; k < nb; k++) {
-            const FrameRes& R = S.fr[k];
-            level_params(R, l, h[k].L);
-            h[k].queue = R.queue[l]; h[k].qctl = R.d_qctl + 2 * l; h[k].counters = count ? R.d_counters + l : nullptr;
-            h[k].row_work = (count && R.d_row_work) ? R.d_row_work + c->row_work_off[l] : nullptr;
+
+    // the plain ladder: levels [first_normal, u0), one classify + one trace launch each
+    int levels(uint32_t u0) {
+        for (uint32_t l = first_normal; l < u0; l++) {
+            FrameLaunch* h; const FrameLaunch* d; next_launch(h, d);
+            for (uint32_t k = 0; k < nb; k++) {
+                const FrameRes& R = S.fr[k];
+                level_params(R, l, h[k].L);
+                h[k].queue = R.queue[l]; h[k].qctl = R.d_qctl + 2 * l; h[k].counters = count ? R.d_counters + l : nullptr;
+                h[k].row_work = (count && R.d_row_work) ? R.d_row_work + c->row_work_off[l] : nullptr;
+            }
+            seq.push_back({0, d, classify_blocks(l), count, {(int)(3 * l)}, {(int)(3 * l + 1)}});
+            seq.push_back({1, d, grid, count, {}, {(int)(3 * l + 2)}});
         }
-        seq.push_back({0, d, classify_blocks(l), count, {(int)(3 * l)}, {(int)(3 * l + 1)}});
-        seq.push_back({1, d, grid, count, {}, {(int)(3 * l + 2)}});
+        return BHRAY_OK;
     }
-    if (nu && any_rows && !fused) {
+
+    // superset_levels = nu: the last nu levels traced in ONE launch over a conservative superset
+    int superset(uint32_t nu, uint32_t u0) {
         // Superset speculation over the last nu levels: ONE trace launch instead of nu dependent ones.
         //  (1) tentative classification of levels u0..nl-1 in order: a pixel whose coarser inputs are known is classified exactly,
         //      a pixel with an input that is itself queued (PENDING) is queued conservatively -> one level-tagged queue;
@@ -1167,7 +1137,85 @@ int launch_batch(bhray_dev* c) {
             if (l == u0) seq.push_back({0, d, classify_blocks(l), count, {}, {}});      // inside level u0's trace interval
             else seq.push_back({0, d, classify_blocks(l), count, {(int)(3 * l)}, {(int)(3 * l + 1), (int)(3 * l + 2)}});
         }
+        return BHRAY_OK;
     }
+};
+}  // namespace
+
+// Enqueues every launch of the batch staged in the current slot: one argument block (FrameParams + per-launch FrameLaunch
+// arrays) copied to the device, then the same launch sequence a single frame needs, each launch covering all staged frames.
+namespace {
+int launch_batch(bhray_dev* c) {
+    Slot& S = c->slots[(size_t)(c->batch_counter % c->slots.size())];
+    const uint32_t nb = S.pending;
+    if (nb == 0) return BHRAY_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t nl = c->cfg.levels;
+    // BHRAY_F_TIMING_SPARSE: events around the launches of every 4th batch only (every recorded event is a packet in the stream's
+    // queue: 12 per frame cost a saturated device 1.6 %)
+    const bool sparse = (c->cfg.flags & BHRAY_F_TIMING_SPARSE) != 0;
+    const bool count = (c->cfg.flags & BHRAY_F_COUNTERS) != 0;
+    const bool timing = (c->cfg.flags & (BHRAY_F_TIMING | BHRAY_F_TIMING_SPARSE)) != 0 && (!sparse || (c->batch_counter & 3u) == 0);
+    if ((c->cfg.flags & (BHRAY_F_TIMING | BHRAY_F_TIMING_SPARSE)) != 0 && !timing) {
+        const size_t ring0 = (size_t)(c->batch_counter % BHRAY_TIMING_RING);
+        c->ring_frames[ring0] = 0; c->sky_recorded[ring0] = 0;          // this batch carries no events
+    }
+    hipStream_t st = S.stream;
+    const uint32_t B = c->batch;
+    const FrameParams* dP = (const FrameParams*)S.d_args;
+    // Persistent trace grid: (resident blocks per CU) x CUs.  With several batches in flight each launch takes only
+    // half of the block slots: the kernels of the other batches fill the rest, and a wave of a half-size grid pulls
+    // more than one load of rays, so the refill keeps its lanes busy (+4 % at 16 slots).
+    // Register budget of the no-mesh trace kernel (bhray_kernels.hip): the dense build when the device is saturated with
+    // rays - at least ~4 whole frames' worth in flight (slots x frames per batch / row partitions) - otherwise the latency
+    // build (measured on MI355X: 1920x1080, 16 slots: 4830 vs 4160 Mrays/s; 1/8 row tile, 16 slots x 8 frames: 0.070 vs
+    // 0.080 ms per frame; one slot: the latency build is 7-15 % faster per launch).
+    // ... with four or more row partitions a rank's launches are small and a timed block may hold only a few batches: there the count is
+    // the batches IN FLIGHT when this one is launched (completed ones are retired oldest-first, one or two event queries per launch),
+    // dense from 8 partitions' worth on (emulated ranks, 20-frame blocks: N = 8 0.1018 -> 0.0992 ms per frame, N = 4 0.1469 -> 0.1403;
+    // 400-frame blocks unchanged; a whole frame per GPU loses 1-2 % with it: profiles/EXPERIMENTS.md R3.11).
+    // ... and what counts is rays, not frames: a partition of a 3840x2160 frame holds four times the rays of the same partition of a
+    // 1920x1080 one, so the frames in flight are weighted by the frame's pixels against 1920x1080 (the size the thresholds were measured
+    // at; 3840x2160 over 8 partitions, 20-frame blocks: the dense build 0.2499 / 0.2407 ms per frame at 4 / 7 frames per batch against
+    // 0.2614 / 0.2550 for the latency build - profiles/r04_emu_knobs.txt).
+    const int dyn = c->dynamic_dense >= 0 ? c->dynamic_dense : (c->cfg.row_world >= 4 ? 8 : 0);
+    size_t in_flight = c->slots.size();
+    if (dyn > 0) {
+        while (c->retired < c->batch_counter) {
+            const Slot& O = c->slots[(size_t)(c->retired % c->slots.size())];
+            if (O.batch_id == c->retired && hipEventQuery(O.done) != hipSuccess) break;
+            c->retired++;
+        }
+        in_flight = (size_t)(c->batch_counter - c->retired) + 1;
+    }
+    // A launch that by itself holds 2.5 frames' worth of rays is dense whatever else is in flight (the first batches of a short block).
+    const double weight = std::max(1.0, (double)c->cfg.frame_w * (double)c->cfg.frame_h / (1920.0 * 1080.0)) / (double)c->cfg.row_world;   // 1920x1080 frames' worth per frame of this partition
+    const bool dense = c->dense_override >= 0 ? c->dense_override != 0
+                                              : ((double)nb * weight >= 2.5 || (double)(in_flight * (size_t)c->batch) * weight >= (double)(dyn > 0 ? dyn : 4));
+    const int literal = (c->cfg.flags & BHRAY_F_LITERAL) ? 1 : ((c->cfg.flags & BHRAY_F_EVAL_FMA) ? 2 : 0);   // the integrator's evaluation (launch_trace's `eval`)
+    int bpc = trace_blocks_per_cu(S.method, S.models, count, dense, literal);
+    if (c->slots.size() > 1 && bpc > 1) bpc = bpc > 4 ? 2 : (bpc / 2 > 1 ? bpc / 2 : 1);     // measured: 2 blocks per CU is best at 8-16 slots
+    if (c->bpc_override > 0) bpc = c->bpc_override;
+    const int grid = c->grid_override > 0 ? c->grid_override : c->num_cus * bpc;
+    BatchPlan plan{c, S, nb, nl, count, literal, grid, st, (size_t)B * sizeof(FrameParams)};
+    const uint32_t ns = c->cfg.speculative_levels;
+    const bool any_rows = !c->levels[nl - 1].rows.empty();    // a partition without rows has nothing to launch (then no level has rows)
+    const bool temporal = (c->cfg.flags & BHRAY_F_TEMPORAL) != 0;
+    const uint32_t nu = temporal ? 0 : c->cfg.superset_levels;
+    const uint32_t u0 = nu ? nl - nu : nl;                     // first level of the superset group
+    if (any_rows) {
+        int rc = BHRAY_OK;
+        if (c->fz.on) rc = plan.fused(ns);
+        else {
+            if (ns) rc = plan.speculative(ns);
+            if (!rc && temporal) rc = plan.temporal();
+            if (!rc) rc = plan.levels(u0);
+            if (!rc && nu) rc = plan.superset(nu, u0);
+        }
+        if (rc) return rc;
+    }
+    std::vector<Launch>& seq = plan.seq;
+    const size_t args_used = plan.args_used;
     if (args_used > S.args_cap) return fail(c, BHRAY_E_STATE, "internal: argument block overflow");
     const size_t ring = (size_t)(c->batch_counter % BHRAY_TIMING_RING);
     if (timing && c->d_span) {                 // execution spans of this batch's trace launches (entry 0 of each launch's FrameLaunch array)

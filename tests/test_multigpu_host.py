@@ -62,11 +62,28 @@ def test_launcher_plumbing_world2_gloo(tmp_path):
         blob = bytes(range(128)) if r == 0 else None
         got = L.broadcast_bytes(blob, 128)
         assert got == bytes(range(128)), got
+        # the balanced partition's calibration as bench.py --gpus N runs it under a launcher: the same work tables on every rank, every
+        # rank's OWN probe time summed into one vector, the re-weighted bounds balanced by the library (host arithmetic) and rank 0's shared
+        import numpy as np
+        import bhusie_amd as B
+        cfg = B.ladder_for_frame((320, 200), 3, 3)
+        work = []
+        for l in range(cfg.levels):
+            y = np.arange(cfg.level_h[l]) / (cfg.level_h[l] - 1.0)
+            work.append((1000.0 * np.exp(-((y - 0.5) / 0.1) ** 2) + 20.0).astype(np.uint64))
+        b = bench.share_bounds(L, B.balance_slabs(cfg, work, 2) if r == 0 else [0, 1, 200], 2)       # rank 1's own (wrong) bounds lose
+        assert b[0] == 0 and b[2] == 200 and 80 < b[1] < 120, b
+        mine = [0.0, 0.0]; mine[r] = 1.0 + 0.5 * r                                                   # partition 1 measured 50 % slower than the model says
+        probe = L.reduce(mine, op="sum")
+        assert probe == [1.0, 1.5]
+        b2 = bench.share_bounds(L, B.balance_slabs(cfg, bench.reweigh_by_probe(cfg, work, b, probe, 200), 2), 2)
+        assert b2[1] > b[1], (b, b2)                                                                 # the slow partition gives rows away
         L.close()
-        open(os.path.join({str(tmp_path)!r}, "ok%d" % r), "w").write("ok")
+        open(os.path.join({str(tmp_path)!r}, "ok%d" % r), "w").write(",".join(str(v) for v in b2))
     """))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_port()), str(script)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+    assert (tmp_path / "ok0").read_text() == (tmp_path / "ok1").read_text()          # both ranks ended with the same bounds
