@@ -140,6 +140,8 @@ struct GroupSlot {                 // per batch slot (same index as the devices'
     hipEvent_t frame_done = nullptr;          // root: recorded behind the de-interleave
     float4* dst[BHRAY_MAX_FRAMES_PER_BATCH];  // root: destination of each frame of the batch staged here (own or caller-bound)
     uint2* sky[BHRAY_MAX_FRAMES_PER_BATCH];   // root: RGBA16F images of bhray_resolve_sky (allocated on first use)
+    uint64_t frame_no[BHRAY_MAX_FRAMES_PER_BATCH] = {};       // serial of the frame staged in each place (1-based), and of the frame its sky
+    uint64_t sky_frame_no[BHRAY_MAX_FRAMES_PER_BATCH] = {};   // image was resolved from: a sky image is current only while the two agree
     hipEvent_t tev[3] = {nullptr, nullptr, nullptr};   // timing: before receive, after receive, after de-interleave
     bool timed = false;
 };
@@ -166,6 +168,7 @@ struct bhray_ctx {
     std::vector<void*> external;           // bhray_import_external_fd: hipExternalMemory_t handles, by mapped pointer (pairs: ptr, handle)
     std::vector<WaitEvent> wait_pool;      // bhray_wait_stream: one event per call until the next render has consumed them
     int last_slot = 0; uint32_t last_sub = 0;
+    uint64_t frames_staged = 0;
     bool rendered = false;
     bool failed = false;                   // a collective failed half way: the communicator's state is unknown, every later gather is refused
     float gather_ms = 0, deint_ms = 0; uint32_t gathers = 0;
@@ -737,6 +740,7 @@ int bhray_render(bhray_ctx* c) {
     for (Part& p : c->parts) if (p.dev) DEV(c, p.dev, dev_render(p.dev));
     for (WaitEvent& w : c->wait_pool) w.in_use = false;
     c->last_slot = si; c->last_sub = sub; c->rendered = true;
+    c->gslots[(size_t)si].frame_no[sub] = ++c->frames_staged;
     return after_launch(c);
 }
 
@@ -875,8 +879,9 @@ int bhray_read_sky_async(bhray_ctx* c, uint16_t* dst, size_t pitch, uint64_t* ti
     if (!c->root_local) { *ticket = t; c->read_tickets = t + 1; return BHRAY_OK; }
     const size_t rowb = (size_t)c->cfg.frame_w * sizeof(uint2);
     if (!dst || pitch < rowb) return gfail(c, BHRAY_E_INVALID, "bad destination / pitch");
-    uint2* src = c->gslots[(size_t)c->last_slot].sky[c->last_sub];
-    if (!src) return gfail(c, BHRAY_E_STATE, "bhray_resolve_sky has not been called for this frame");
+    const GroupSlot& GS = c->gslots[(size_t)c->last_slot];
+    uint2* src = GS.sky[c->last_sub];
+    if (!src || GS.sky_frame_no[c->last_sub] != GS.frame_no[c->last_sub]) return gfail(c, BHRAY_E_STATE, "bhray_resolve_sky has not been called for this frame");
     Part& rp = *root_part(c);
     CommRank* rr = rank_of(c, rp);
     GHIP(c, hipSetDevice(rp.device));
@@ -1013,6 +1018,7 @@ int bhray_resolve_sky(bhray_ctx* c) {
     GHIP(c, hipSetDevice(rp.device));
     if (!G.sky[c->last_sub]) GHIP(c, hipMalloc(&G.sky[c->last_sub], frame_pixels(c) * sizeof(uint2)));
     DEV(c, rp.dev, dev_launch_sky(rp.dev, G.dst[c->last_sub], G.sky[c->last_sub], frame_pixels(c), rr->stream));   // behind the de-interleave
+    G.sky_frame_no[c->last_sub] = G.frame_no[c->last_sub];
     GHIP(c, hipEventRecord(G.frame_done, rr->stream));
     // the root's next render into this slot writes its own rows straight into the frame the sky pass is reading (the wait that
     // group_gather enqueued captured the EARLIER record of frame_done, behind the de-interleave): order it behind this one
@@ -1027,8 +1033,9 @@ int bhray_read_sky(bhray_ctx* c, uint16_t* dst, size_t pitch) {
     if (!c->root_local) return BHRAY_OK;
     const size_t rowb = (size_t)c->cfg.frame_w * sizeof(uint2);
     if (!dst || pitch < rowb) return gfail(c, BHRAY_E_INVALID, "bad destination / pitch");
-    uint2* src = c->gslots[(size_t)c->last_slot].sky[c->last_sub];
-    if (!src) return gfail(c, BHRAY_E_STATE, "bhray_resolve_sky has not been called for this frame");
+    const GroupSlot& GS = c->gslots[(size_t)c->last_slot];
+    uint2* src = GS.sky[c->last_sub];
+    if (!src || GS.sky_frame_no[c->last_sub] != GS.frame_no[c->last_sub]) return gfail(c, BHRAY_E_STATE, "bhray_resolve_sky has not been called for this frame");
     GHIP(c, hipSetDevice(root_part(c)->device));
     GHIP(c, hipMemcpy2D(dst, pitch, src, rowb, rowb, c->cfg.frame_h, hipMemcpyDeviceToHost));
     return BHRAY_OK;

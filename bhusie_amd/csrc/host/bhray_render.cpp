@@ -3,7 +3,10 @@
 // as raw little-endian f32 RGBA (row 0 = top).  Usage:
 //   bhray_render OUT.f32 [--rk] [--base W H] [--levels N] [--disk-size S] [--obj mesh.obj] [--devices 0,1,2,...]
 // --devices: row-tile the frame over several GPUs from this one process (RCCL gather to the first one, inside libbhray).
+//   bhray_render --handoff sync|hdr|sky|sky1|sky-temporal FRAMES OUT.bin [--rk] [--base W H] [--levels N]
 //   bhray_render --dropin FRAMES [--rk] [--base W H] [--levels N]
+// --handoff: FRAMES frames of the same scene (time += 1/60 per frame) through Renderer::render_handoff in the given form, every DELIVERED frame
+// appended to OUT.bin in delivery order (RGBA32F for sync / hdr, RGBA16F for sky) - the tests compare them with the frames the Python host renders.
 // --dropin: times the drop-in shim of INTEGRATION.md §3 the way the reference host drives it - one thread, `time += dt` every frame
 // (mod.rs:382), every frame handed to host memory - in its three hand-off forms, and prints one JSON object (bench.py embeds it as `dropin`).
 // Textures: the disk texture comes from the reference's own generator (bhray_generate_disk_texture); the LUT and the sky
@@ -65,6 +68,41 @@ double run_leg(const Leg& L, uint32_t bw, uint32_t bh, uint32_t levels, bool rk,
 }  // namespace
 
 int main(int argc, char** argv) {
+    if (argc >= 5 && !std::strcmp(argv[1], "--handoff")) {
+        const char* form = argv[2]; const int frames = std::atoi(argv[3]); const char* out_path = argv[4];
+        uint32_t bw = 24, bh = 14, levels = 3; bool rk = false;
+        for (int i = 5; i < argc; i++) {
+            if (!std::strcmp(argv[i], "--rk")) rk = true;
+            else if (!std::strcmp(argv[i], "--base") && i + 2 < argc) { bw = (uint32_t)std::atoi(argv[++i]); bh = (uint32_t)std::atoi(argv[++i]); }
+            else if (!std::strcmp(argv[i], "--levels") && i + 1 < argc) levels = (uint32_t)std::atoi(argv[++i]);
+        }
+        try {
+            const bool sky = !std::strncmp(form, "sky", 3), temporal = !std::strcmp(form, "sky-temporal");
+            const bhusie::Handoff h = !std::strcmp(form, "sync") ? bhusie::Handoff::Sync : (sky ? bhusie::Handoff::AsyncSky : bhusie::Handoff::AsyncHdr);
+            const uint32_t in_flight = (h == bhusie::Handoff::Sync || !std::strcmp(form, "sky1")) ? 1u : 2u;   // sky1: the sky form, one frame in flight
+            bhusie::Renderer r({bw, bh}, 3, levels, 0, in_flight, h, temporal);
+            fill_textures(r.ray_pipeline(), 128);
+            r.ray_details.integration_method = rk ? 1 : 0;
+            auto res = r.ray_pipeline().resolution();
+            const size_t bytes = (size_t)res.first * res.second * (sky ? 8 : 16);
+            FILE* f = std::fopen(out_path, "wb");
+            if (!f) { std::perror(out_path); return 1; }
+            int delivered = 0;
+            for (int i = 0; i < frames; i++) {
+                const void* px = r.render_handoff(1.0f / 60.0f);
+                if (px) { std::fwrite(px, 1, bytes, f); delivered++; }
+            }
+            // the frames still in flight: one more finish() per frame (the host would show them on its next frames)
+            for (uint32_t k = 1; k < in_flight; k++) {
+                r.ray_pipeline().drain();
+                const void* px = r.ray_pipeline().finish_pending(k);
+                if (px) { std::fwrite(px, 1, bytes, f); delivered++; }
+            }
+            std::fclose(f);
+            std::printf("%ux%u %d\n", res.first, res.second, delivered);
+        } catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return 1; }
+        return 0;
+    }
     if (argc >= 3 && !std::strcmp(argv[1], "--dropin")) {
         const int frames = std::atoi(argv[2]);
         uint32_t bw = 72, bh = 41, levels = 4; bool rk = false;

@@ -142,6 +142,11 @@ public:
         if (pending_[k]) { check(bhray_wait_read(ctx_, tickets_[k]), ctx_); pending_[k] = false; }
         return staging_[k];
     }
+    // after the last pass: the k-th oldest frame still in flight (k = 1 .. ring-1), already drained - what the next finish() calls would hand over
+    const void* finish_pending(uint32_t k) {
+        if (handoff_ == Handoff::Sync || frame_ < k || k >= ring_) return nullptr;
+        return staging_[(size_t)((frame_ + k) % ring_)];
+    }
     void drain() { for (uint32_t k = 0; k < ring_; k++) if (pending_.size() > k && pending_[k]) { check(bhray_wait_read(ctx_, tickets_[k]), ctx_); pending_[k] = false; } }
     std::pair<uint32_t, uint32_t> resolution() const { return {cfg_.frame_w, cfg_.frame_h}; }
     void set_texture(int slot, const uint8_t* rgba8, uint32_t w, uint32_t h) { check(bhray_set_texture(ctx_, slot, rgba8, w, h), ctx_); }

@@ -414,7 +414,9 @@ int bhray_next_stream(bhray_ctx* ctx, void** hip_stream);
  * pipelines/sky_pipeline.rs:17-148, dispatched right after the ray levels at mod.rs:419): alpha == 0 pixels carry
  * an escape direction and become sky^4 (alpha 1), other pixels pass through; target format rgba16float.
  * bhray_resolve_sky enqueues it behind the most recently enqueued frame (same slot, same stream) into that slot's
- * RGBA16F image: local_rows x frame_w x 4 binary16, round-to-nearest-even.                                       */
+ * RGBA16F image: local_rows x frame_w x 4 binary16, round-to-nearest-even.  The image belongs to that frame: after the
+ * next bhray_render the reads below return BHRAY_E_STATE until bhray_resolve_sky has run for the new frame (a copy
+ * enqueued with bhray_read_sky_async BEFORE that render still delivers the earlier frame's image).                  */
 int bhray_resolve_sky(bhray_ctx* ctx);
 int bhray_read_sky(bhray_ctx* ctx, uint16_t* dst_rgba16f, size_t row_pitch_bytes);
 int bhray_sky_device_ptr(bhray_ctx* ctx, void** dev_ptr, size_t* bytes);

@@ -144,7 +144,7 @@ def test_async_read_of_a_gathered_frame():
 def test_sky_pass_of_a_gathered_frame_is_not_torn_by_the_next_render():
     """in gather mode the sky pass runs on the root's communication stream; the root's next render into the same slot
     writes its own rows straight into the frame the sky pass is reading.  Render A, resolve its sky, render B (different camera)
-    at once, then read A's sky: it must be sky(A), not a mixture."""
+    at once: A's sky image, whose copy to the host was enqueued before B, must be sky(A), not a mixture."""
     tex = T.textures(small=False)
     frames = _frames()
     cfg = B.ladder_for_frame((1920, 1080), 3, 4)
@@ -154,11 +154,17 @@ def test_sky_pass_of_a_gathered_frame_is_not_torn_by_the_next_render():
     one.close()
     rp = B.RayPass(cfg, devices=[0, 0], frames_in_flight=1)
     rp.set_textures(*tex)
+    buf = B.PinnedFrame(1080, 1920, channels16=True)
     for _ in range(3):
+        buf.array[...] = 0
         rp.set_uniforms(*frames[0]); rp.render(); rp.resolve_sky()
-        rp.set_uniforms(*frames[1]); rp.render()              # same slot, different frame, no wait in between
-        got = rp.read_sky()                                   # the sky image resolved from frame A
-        assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+        t = rp.read_sky_async(buf)                            # A's sky image, copy enqueued - nothing waited for
+        rp.set_uniforms(*frames[1]); rp.render()              # same slot, different frame
+        with pytest.raises(B.BhrayError):
+            rp.read_sky()                                     # the image on hand is A's, the current frame is B: refused (as on one GPU)
+        rp.wait_read(t)
+        assert np.array_equal(buf.array.view(np.uint16), want.view(np.uint16))
+    buf.free()
     rp.close()
 
 
@@ -242,3 +248,111 @@ def test_external_memory_import_is_a_zero_copy_output():
         rp.release_external(p)
     os.close(fd.value)
     rp.close(); buf.free()
+
+
+def test_a_stale_sky_image_is_refused_until_the_sky_pass_runs_again():
+    """the sky image belongs to the frame it was resolved from.  After the NEXT render the image is stale: reading it
+    (either read) is a state error, not the previous frame's pixels; resolve_sky() makes it current again."""
+    tex = T.textures()
+    frames = _frames()
+    cfg = B.ladder_for_frame((200, 110), 3, 3)
+    want = []
+    for u in frames[:2]:
+        rp = B.RayPass(cfg, device=0); rp.set_textures(*tex); rp.set_uniforms(*u); rp.render(); rp.resolve_sky(); want.append(rp.read_sky()); rp.close()
+    for kw in (dict(device=0), dict(device=0, frames_in_flight=3, frames_per_batch=2)):
+        rp = B.RayPass(cfg, **kw)
+        rp.set_textures(*tex)
+        buf = B.PinnedFrame(110, 200, channels16=True)
+        rp.set_uniforms(*frames[0]); rp.render(); rp.resolve_sky()
+        assert np.array_equal(rp.read_sky().view(np.uint16), want[0].view(np.uint16))
+        rp.set_uniforms(*frames[1]); rp.render()                  # a new frame: the sky image on hand is frame 0's
+        with pytest.raises(B.BhrayError) as e:
+            rp.read_sky_async(buf)
+        assert e.value.code == -5                                 # BHRAY_E_STATE
+        with pytest.raises(B.BhrayError):
+            rp.read_sky()
+        rp.resolve_sky()
+        rp.wait_read(rp.read_sky_async(buf))
+        assert np.array_equal(buf.array.view(np.uint16), want[1].view(np.uint16)), kw
+        buf.free(); rp.close()
+
+
+def test_a_refused_async_read_of_a_gathered_frame_consumes_no_ticket():
+    """multi-partition ctx, bhray_read_hdr_async with a pitch narrower than a row is refused BEFORE a ticket is taken: the
+    next valid call gets the ticket the refused one would have had, and waiting on it delivers the frame."""
+    tex = T.textures()
+    u = _frames()[0]
+    cfg = B.ladder_for_frame((200, 110), 3, 3)
+    want = _want(cfg, tex, [u])[0]
+    L = B.lib()
+    for kw in (dict(device=0), dict(devices=[0, 0], stripe_rows=9)):
+        rp = B.RayPass(cfg, **kw)
+        rp.set_textures(*tex); rp.set_uniforms(*u); rp.render()
+        buf = B.PinnedFrame(110, 200)
+        buf.array[...] = -3.0
+        first = rp.read_hdr_async(buf)
+        rp.wait_read(first)
+        t = C.c_uint64(12345)
+        rc = L.bhray_read_hdr_async(rp._h, buf.array.ctypes.data_as(C.POINTER(C.c_float)), 200 * 16 - 16, C.byref(t))
+        assert rc != 0, kw
+        rc = L.bhray_read_hdr_async(rp._h, None, 200 * 16, C.byref(t))
+        assert rc != 0, kw
+        buf.array[...] = -3.0
+        second = rp.read_hdr_async(buf)
+        assert second == first + 1, (kw, first, second)           # the two refused calls took none
+        rp.wait_read(second)
+        assert np.array_equal(buf.array.view(np.uint32), want.view(np.uint32)), kw
+        buf.free(); rp.close()
+
+
+def _handoff_frames(tmp_path, form, frames, pixel_bytes):
+    import subprocess
+    exe = os.path.join(os.path.dirname(B.LIB_PATH), "bhray_render")
+    out = tmp_path / f"{form}.bin"
+    r = subprocess.run([exe, "--handoff", form, str(frames), str(out), "--rk", "--base", "24", "14", "--levels", "3"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    size, delivered = r.stdout.split()
+    w, h = (int(v) for v in size.split("x"))
+    assert int(delivered) == frames, (form, r.stdout)             # every frame reaches the host, the last ones after the drain
+    data = np.fromfile(out, dtype=np.uint8)
+    assert data.size == frames * w * h * pixel_bytes
+    return data.reshape(frames, h, w, pixel_bytes)
+
+
+def test_the_shim_hands_the_host_the_same_frames_in_every_form(tmp_path):
+    """INTEGRATION.md §3's shim as the C++ program runs it (host/renderer.hpp, Renderer::render_handoff; time advances 1/60 per frame):
+    the asynchronous forms - two frames in flight, the host shown frame k-1 while k renders - deliver, in order, exactly the frames the
+    synchronous form delivers; the temporal flag changes when pixels are computed, not their values."""
+    n = 7
+    sync = _handoff_frames(tmp_path, "sync", n, 16)
+    hdr = _handoff_frames(tmp_path, "hdr", n, 16)
+    assert np.array_equal(sync, hdr)
+    assert not np.array_equal(sync[0], sync[1])                   # the scene does move (disk rotation), so frame order is tested
+    sky1 = _handoff_frames(tmp_path, "sky1", n, 8)
+    sky = _handoff_frames(tmp_path, "sky", n, 8)
+    skyt = _handoff_frames(tmp_path, "sky-temporal", n, 8)
+    assert np.array_equal(sky1, sky)
+    assert np.array_equal(sky1, skyt)
+    assert not np.array_equal(sky1[0], sky1[1])
+    # the sky image is the sky pass over the same HDR frame: where the HDR pixel already carries its colour (alpha 1: disk, horizon) the
+    # two agree to half precision
+    hdr_f = sync.view(np.float32).reshape(n, sync.shape[1], sync.shape[2], 4)
+    sky_f = sky1.view(np.float16).reshape(n, sky1.shape[1], sky1.shape[2], 4).astype(np.float32)
+    direct = hdr_f[..., 3] == 1.0
+    assert direct.any()
+    assert np.allclose(sky_f[direct][:, :3], hdr_f[direct][:, :3], rtol=2e-3, atol=1e-4)
+
+
+def test_the_dropin_measurement_mode_reports_every_leg(tmp_path):
+    """bench.py's `dropin` object comes from `bhray_render --dropin`: a tiny run must finish and name the six hand-off legs."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(B.LIB_PATH), "bhray_render")
+    r = subprocess.run([exe, "--dropin", "4", "--rk", "--base", "24", "14", "--levels", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    legs = rep["legs"] if "legs" in rep else rep
+    names = [l["name"] for l in legs] if isinstance(legs, list) else list(legs)
+    for want in ("sync_read_hdr", "async_sky_rgba16f"):
+        assert any(want in x for x in names), names
+    assert len(names) >= 6
