@@ -808,6 +808,9 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #ifndef BHRAY_MESH_COLD_LDS
 #define BHRAY_MESH_COLD_LDS 0    // mesh variant: the cold per-lane state in LDS as in the dense build
 #endif
+#ifndef BHRAY_WITH_PAIR
+#define BHRAY_WITH_PAIR 0        // 1 (make pair -> libbhray_pair.so): the dense RK kernel without meshes marches TWO rays per lane on packed FP32 (bhray_pair.inc)
+#endif
 #ifndef BHRAY_WITH_FUSED
 #define BHRAY_WITH_FUSED 0       // 1 (make fused -> libbhray_fused.so): the fused ladder, BHRAY_F_FUSED - measured slower than the launch-per-level ladder, a tested option
 #endif
@@ -1200,6 +1203,8 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
     if (err) *err_flag = err;
 }
 
+#include "bhray_pair.inc"
+
 // ------------------------------------------------------------------------------------------
 // sky resolve: sky.wgsl:1-38 (the pass after the ray levels, mod.rs:419)
 // ------------------------------------------------------------------------------------------
@@ -1378,6 +1383,15 @@ static hipError_t launch_trace_e(const FrameParams* Pb, const FrameLaunch* Fb, i
 hipError_t launch_trace(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int method, bool models, bool count, bool dense, int eval, int* err_flag,
                         int grid_blocks, hipStream_t s) {
     if (nb <= 0) return hipSuccess;
+#if BHRAY_WITH_PAIR
+    if (eval == 0 && method == 1 && !models && dense) {
+        (void)hipGetLastError();
+        const dim3 grid((grid_blocks * 256 + BHRAY_TRACE_THREADS - 1) / BHRAY_TRACE_THREADS);
+        if (count) hipLaunchKernelGGL((trace_pair_kernel<true>), grid, dim3(BHRAY_TRACE_THREADS), pair_dyn_lds_bytes, s, Pb, Fb, nb, err_flag);
+        else hipLaunchKernelGGL((trace_pair_kernel<false>), grid, dim3(BHRAY_TRACE_THREADS), pair_dyn_lds_bytes, s, Pb, Fb, nb, err_flag);
+        return hipGetLastError();
+    }
+#endif
     if (eval == 1) return launch_trace_e<1>(Pb, Fb, nb, method, models, count, dense, err_flag, grid_blocks, s);
     if (eval == 2) return launch_trace_e<2>(Pb, Fb, nb, method, models, count, dense, err_flag, grid_blocks, s);
     return launch_trace_e<0>(Pb, Fb, nb, method, models, count, dense, err_flag, grid_blocks, s);
@@ -1403,6 +1417,14 @@ static const void* trace_kernel_ptr(int method, int has_models, int count, int d
 }
 int trace_blocks_per_cu(int method, int has_models, int count, int dense, int eval) {
     int n = 0;
+#if BHRAY_WITH_PAIR
+    if (eval == 0 && method == 1 && !has_models && dense) {
+        const void* fp = count ? (const void*)trace_pair_kernel<true> : (const void*)trace_pair_kernel<false>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fp, BHRAY_TRACE_THREADS, pair_dyn_lds_bytes) != hipSuccess || n < 1) n = 2;
+        n = n * BHRAY_TRACE_THREADS / 256;
+        return n < 1 ? 1 : n;
+    }
+#endif
     const void* f = eval == 1 ? trace_kernel_ptr<1>(method, has_models, count, dense)
                   : eval == 2 ? trace_kernel_ptr<2>(method, has_models, count, dense) : trace_kernel_ptr<0>(method, has_models, count, dense);
     const size_t dyn_lds = has_models ? (size_t)BHRAY_BVH_LDS_STACK * BHRAY_TRACE_THREADS * 8 : 0;

@@ -57,3 +57,43 @@ def test_default_build_instantiates_no_fused_ladder_and_no_experiment_macros():
         assert before.rfind("#if BHRAY_WITH_FUSED") > before.rfind("#endif"), "bhray_fused.inc included outside an #if BHRAY_WITH_FUSED block"
     mk = open(os.path.join(ROOT, "bhusie_amd", "csrc", "Makefile")).read()
     assert "-DBHRAY_WITH_FUSED=1" in mk and "fused:" in mk
+
+
+def test_default_build_has_no_pair_march_and_the_pair_step_is_next_ray_rk_on_2_vectors():
+    """bhray_pair.inc is a build option (make pair).  Its integrator step must be next_ray_rk line for line with the scalar helpers
+    replaced by their 2-vector counterparts - the GPU tests compare frames byte for byte, this catches a drift between the two texts
+    at review time."""
+    src = open(os.path.join(ROOT, "bhusie_amd", "csrc", "bhray_kernels.hip")).read()
+    assert "#define BHRAY_WITH_PAIR 0" in src
+    inc = open(os.path.join(ROOT, "bhusie_amd", "csrc", "bhray_pair.inc")).read()
+    assert inc.lstrip().startswith("//") and "#if BHRAY_WITH_PAIR" in inc and inc.rstrip().endswith("#endif  // BHRAY_WITH_PAIR")
+    code = inc[inc.index("#if BHRAY_WITH_PAIR"):]
+    assert "__global__" in code                                   # the kernel lives entirely inside the #if
+
+    def body(text, name):
+        i = text.index(name)
+        i = text.index("{", i)
+        depth, j = 0, i
+        while True:
+            depth += {"{": 1, "}": -1}.get(text[j], 0)
+            if depth == 0:
+                return text[i + 1:j]
+            j += 1
+
+    def stage_lines(b):
+        out = []
+        for line in b.splitlines():
+            line = line.split("//")[0].strip()
+            if re.match(r"const (F3|P3) (K[1-6]|e|ds|cr) =", line):
+                out.append(line)
+        return out
+
+    scalar = stage_lines(body(src, "void next_ray_rk(F3 q0"))
+    packed = stage_lines(body(inc, "void next_ray_rk_pair(P3 q0"))
+    assert len(scalar) == len(packed) == 9
+    for a, b in zip(scalar, packed):
+        b = b.replace("P3", "F3").replace("pmadd3", "fmadd3").replace("pcross", "fcross")
+        b = re.sub(r"sp\(([A-Z0-9]+)\)", r"\1", b)
+        assert a == b, (a, b)
+    mk = open(os.path.join(ROOT, "bhusie_amd", "csrc", "Makefile")).read()
+    assert "-DBHRAY_WITH_PAIR=1" in mk and "pair:" in mk
