@@ -114,6 +114,24 @@ __global__ __launch_bounds__(256) void deinterleave_kernel(const float4* __restr
     for (int x = threadIdx.x; x < width; x += 256) dst[x] = __builtin_nontemporal_load(src + x);   // staging is read once
 }
 
+// The same for the RGBA16F tiles of BHRAY_F_GATHER_SKY (8 B read + 8 B written per pixel).
+struct SkyPtrs { uint2* p[BHRAY_MAX_FRAMES_PER_BATCH]; };
+__global__ __launch_bounds__(256) void deinterleave16_kernel(const uint2* __restrict__ staging, const SkyPtrs frames,
+                                                             const RowDesc* __restrict__ table, const int width) {
+    const RowDesc t = table[blockIdx.x];
+    const int k = blockIdx.y;
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    const u2v* __restrict__ src = (const u2v*)(staging + ((size_t)t.src_row0 + (size_t)k * t.part_rows) * (size_t)width);
+    u2v* __restrict__ dst = (u2v*)(frames.p[k] + (size_t)t.frame_row * (size_t)width);
+    if ((width & 1) == 0) {                    // an even row: every row starts on 16 bytes, two pixels per lane and access
+        const u4v* __restrict__ s4 = (const u4v*)src; u4v* __restrict__ d4 = (u4v*)dst;
+        for (int x = threadIdx.x; x < width / 2; x += 256) d4[x] = __builtin_nontemporal_load(s4 + x);
+    } else {
+        for (int x = threadIdx.x; x < width; x += 256) dst[x] = __builtin_nontemporal_load(src + x);
+    }
+}
+
 struct Part {                      // one row partition of the frame
     bhray_dev* dev = nullptr;      // non-null: rendered by this ctx
     int device = -1;
@@ -136,6 +154,8 @@ struct GroupSlot {                 // per batch slot (same index as the devices'
     float4* frames = nullptr;                 // root: B assembled frames
     float4* staging = nullptr;                // root: tiles of the other partitions, [part][frame of batch][row][x]
     std::vector<float4*> send;                // per partition: packed rows of the batch's frames (local non-root partitions)
+    std::vector<uint2*> send16;               // BHRAY_F_GATHER_SKY: the same rows after the partition's own sky pass (what is sent)
+    uint2* staging16 = nullptr;               // BHRAY_F_GATHER_SKY, root: RGBA16F tiles of the other partitions (layout of `staging`)
     std::vector<hipEvent_t> sent;             // per partition: recorded behind its send
     hipEvent_t frame_done = nullptr;          // root: recorded behind the de-interleave
     float4* dst[BHRAY_MAX_FRAMES_PER_BATCH];  // root: destination of each frame of the batch staged here (own or caller-bound)
@@ -154,6 +174,7 @@ struct bhray_ctx {
     std::vector<CommRank> ranks;           // local ranks
     bool single = true;                    // one partition, no gather: every call goes straight to parts[0].dev
     bool gather = false;
+    bool gather_sky = false;               // BHRAY_F_GATHER_SKY: the sky image is what travels
     uint32_t root = 0;
     bool root_local = false;
     uint32_t world = 1;                    // partitions
@@ -222,6 +243,29 @@ int group_gather(bhray_ctx* c, int si, uint32_t nb) {
     }
     Part& rp = *root_part(c);
     CommRank* rr = c->root_local ? rank_of(c, rp) : nullptr;
+    if (c->gather_sky) {
+        // every partition resolves the sky over its own rows (sky.wgsl is per pixel) behind its render, on its communication stream: the
+        // other partitions into their 8-byte send buffers, the root from its rows of the RGBA32F frames straight into the sky images
+        for (uint32_t q = 0; q < c->world; q++) {
+            Part& p = c->parts[q];
+            if (!p.dev || p.rows == 0) continue;
+            CommRank* cr = rank_of(c, p);
+            if (q != c->root) {
+                DEV(c, p.dev, dev_launch_sky(p.dev, G.send[q], G.send16[q], (size_t)nb * p.rows * W, cr->stream));
+            } else {
+                for (uint32_t k = 0; k < nb; k++) {
+                    for (size_t i = 0; i < p.row_list.size();) {            // runs of consecutive frame rows (a slab: one; stripes: one per stripe)
+                        size_t j = i + 1;
+                        while (j < p.row_list.size() && p.row_list[j] == p.row_list[j - 1] + 1) j++;
+                        const size_t off = (size_t)p.row_list[i] * W;
+                        DEV(c, p.dev, dev_launch_sky(p.dev, G.dst[k] + off, G.sky[k] + off, (j - i) * W, cr->stream));
+                        i = j;
+                    }
+                }
+            }
+        }
+    }
+    const size_t words = c->gather_sky ? 2 : 4;          // 32-bit words per pixel on the wire
     if (rr && timing) { GHIP(c, hipSetDevice(rr->device)); GHIP(c, hipEventRecord(G.tev[0], rr->stream)); }
     // ONE group: every tile of the batch.  Sends and receives are issued in partition order, so the messages between
     // a pair of ranks (several partitions may share a rank) match in order.
@@ -236,14 +280,15 @@ int group_gather(bhray_ctx* c, int si, uint32_t nb) {
                 if (q == c->root || !p.dev || p.rows == 0) continue;
                 CommRank* cr = rank_of(c, p);
                 GHIP(c, hipSetDevice(p.device));
-                GNCCL(c, R, R->Send(G.send[q], (size_t)nb * p.rows * W * 4, ncclFloat32, rp.rank, cr->comm, cr->stream));
+                GNCCL(c, R, R->Send(c->gather_sky ? (const void*)G.send16[q] : (const void*)G.send[q], (size_t)nb * p.rows * W * words, ncclFloat32, rp.rank, cr->comm, cr->stream));
             }
             if (rr) {
                 GHIP(c, hipSetDevice(rr->device));
                 for (uint32_t q = 0; q < c->world; q++) {
                     const Part& p = c->parts[q];
                     if (q == c->root || p.rows == 0) continue;
-                    GNCCL(c, R, R->Recv(G.staging + p.stage_row0 * W, (size_t)nb * p.rows * W * 4, ncclFloat32, p.rank, rr->comm, rr->stream));
+                    void* into = c->gather_sky ? (void*)(G.staging16 + p.stage_row0 * W) : (void*)(G.staging + p.stage_row0 * W);
+                    GNCCL(c, R, R->Recv(into, (size_t)nb * p.rows * W * words, ncclFloat32, p.rank, rr->comm, rr->stream));
                 }
             }
             return BHRAY_OK;
@@ -264,13 +309,20 @@ int group_gather(bhray_ctx* c, int si, uint32_t nb) {
     if (rr) {
         GHIP(c, hipSetDevice(rr->device));
         if (timing) GHIP(c, hipEventRecord(G.tev[1], rr->stream));
-        if (c->table_rows) {
+        if (c->table_rows && c->gather_sky) {
+            SkyPtrs sp; memset(&sp, 0, sizeof sp);
+            for (uint32_t k = 0; k < nb; k++) sp.p[k] = G.sky[k];
+            (void)hipGetLastError();
+            hipLaunchKernelGGL(deinterleave16_kernel, dim3(c->table_rows, nb), dim3(256), 0, rr->stream, G.staging16, sp, c->d_table, (int)W);
+            GHIP(c, hipGetLastError());
+        } else if (c->table_rows) {
             FramePtrs fp; memset(&fp, 0, sizeof fp);
             for (uint32_t k = 0; k < nb; k++) fp.p[k] = G.dst[k];
             (void)hipGetLastError();          // a stale error of an unrelated earlier call must not be blamed on this launch
             hipLaunchKernelGGL(deinterleave_kernel, dim3(c->table_rows, nb), dim3(256), 0, rr->stream, G.staging, fp, c->d_table, (int)W);
             GHIP(c, hipGetLastError());
         }
+        if (c->gather_sky) for (uint32_t k = 0; k < nb; k++) G.sky_frame_no[k] = G.frame_no[k];      // the sky image of every frame of the batch is current
         if (timing) { GHIP(c, hipEventRecord(G.tev[2], rr->stream)); G.timed = true; }
         GHIP(c, hipEventRecord(G.frame_done, rr->stream));
         // the root's next render into this slot writes its own rows into the frames the de-interleave is filling: keep them ordered
@@ -329,6 +381,7 @@ void group_free(bhray_ctx* c) {
         (void)hipSetDevice(p.device);
         for (GroupSlot& G : c->gslots) {
             if (q < G.send.size() && G.send[q]) (void)hipFree(G.send[q]);
+            if (q < G.send16.size() && G.send16[q]) (void)hipFree(G.send16[q]);
             if (q < G.sent.size() && G.sent[q]) (void)hipEventDestroy(G.sent[q]);
         }
     }
@@ -337,6 +390,7 @@ void group_free(bhray_ctx* c) {
         for (GroupSlot& G : c->gslots) {
             if (G.frames) (void)hipFree(G.frames);
             if (G.staging) (void)hipFree(G.staging);
+            if (G.staging16) (void)hipFree(G.staging16);
             if (G.frame_done) (void)hipEventDestroy(G.frame_done);
             for (auto& e : G.tev) if (e) (void)hipEventDestroy(e);
             for (auto& s : G.sky) if (s) (void)hipFree(s);
@@ -520,6 +574,8 @@ int bhray_create(const bhray_config* cfg_in, bhray_ctx** out) {
     const bool multi_proc = !multi_dev && cfg->gather == BHRAY_GATHER_RCCL && cfg->row_world > 1;   // one process per GPU
     c->gather = multi_dev || multi_proc;
     c->single = !c->gather;
+    c->gather_sky = c->gather && (cfg->flags & BHRAY_F_GATHER_SKY) != 0;
+    if ((cfg->flags & BHRAY_F_GATHER_SKY) && !c->gather) { delete c; return gfail(nullptr, BHRAY_E_INVALID, "BHRAY_F_GATHER_SKY needs a multi-GPU ctx (device_count >= 2 or gather = BHRAY_GATHER_RCCL)"); }
 #define FAIL(code, ...) do { int rc_ = gfail(nullptr, code, __VA_ARGS__); bhray_destroy(c); return rc_; } while (0)
     if (c->single) {
         bhray_config one = *cfg;
@@ -623,19 +679,24 @@ int bhray_create(const bhray_config* cfg_in, bhray_ctx** out) {
     c->gslots.resize(c->nslots);
     for (GroupSlot& G : c->gslots) {
         memset(G.dst, 0, sizeof G.dst); memset(G.sky, 0, sizeof G.sky);
-        G.send.assign(c->world, nullptr); G.sent.assign(c->world, nullptr);
+        G.send.assign(c->world, nullptr); G.sent.assign(c->world, nullptr); G.send16.assign(c->world, nullptr);
         for (uint32_t q = 0; q < c->world; q++) {
             Part& p = c->parts[q];
             if (!p.dev || q == c->root) continue;
             CH(hipSetDevice(p.device));
             if (p.rows) { CH(hipMalloc(&G.send[q], (size_t)c->B * p.rows * W * sizeof(float4))); CH(hipMemset(G.send[q], 0xFF, (size_t)c->B * p.rows * W * sizeof(float4))); }
+            if (p.rows && c->gather_sky) CH(hipMalloc(&G.send16[q], (size_t)c->B * p.rows * W * sizeof(uint2)));
             CH(hipEventCreateWithFlags(&G.sent[q], hipEventDisableTiming));
         }
         if (c->root_local) {
             CH(hipSetDevice(c->parts[c->root].device));
             CH(hipMalloc(&G.frames, (size_t)c->B * frame_pixels(c) * sizeof(float4)));
             CH(hipMemset(G.frames, 0xFF, (size_t)c->B * frame_pixels(c) * sizeof(float4)));
-            if (c->staging_rows) CH(hipMalloc(&G.staging, c->staging_rows * W * sizeof(float4)));
+            if (c->staging_rows && !c->gather_sky) CH(hipMalloc(&G.staging, c->staging_rows * W * sizeof(float4)));
+            if (c->gather_sky) {
+                if (c->staging_rows) CH(hipMalloc(&G.staging16, c->staging_rows * W * sizeof(uint2)));
+                for (uint32_t k = 0; k < c->B; k++) { CH(hipMalloc(&G.sky[k], frame_pixels(c) * sizeof(uint2))); CH(hipMemset(G.sky[k], 0xFF, frame_pixels(c) * sizeof(uint2))); }
+            }
             CH(hipEventCreateWithFlags(&G.frame_done, hipEventDisableTiming));
             if (cfg->flags & (BHRAY_F_TIMING | BHRAY_F_TIMING_SPARSE)) for (auto& e : G.tev) CH(hipEventCreate(&e));
         }
@@ -660,7 +721,7 @@ int bhray_get_gather_info(const bhray_ctx* c, bhray_gather_info* out) {
     memset(out, 0, sizeof *out);
     out->partitions = c->world;
     out->root = c->root;
-    const uint64_t rowb = (uint64_t)c->cfg.frame_w * 16u;
+    const uint64_t rowb = (uint64_t)c->cfg.frame_w * (c->gather_sky ? 8u : 16u);
     for (uint32_t q = 0; q < c->parts.size(); q++) {
         const Part& p = c->parts[q];
         if (p.dev) out->local_partitions++;
@@ -774,6 +835,7 @@ int bhray_local_row_index(const bhray_ctx* c, uint32_t i, uint32_t* frame_row) {
 int bhray_read_hdr(bhray_ctx* c, float* dst, size_t pitch) {
     if (!c) return BHRAY_E_INVALID;
     if (c->single) { DEV(c, c->parts[0].dev, dev_read_hdr(c->parts[0].dev, dst, pitch)); return BHRAY_OK; }
+    if (c->gather_sky) return gfail(c, BHRAY_E_STATE, "BHRAY_F_GATHER_SKY: the RGBA32F frame is not assembled (read the sky image)");
     { int rc = group_sync(c); if (rc) return rc; }
     if (!c->root_local) return BHRAY_OK;                        // the frame lives on another rank
     if (!c->rendered) return gfail(c, BHRAY_E_STATE, "nothing rendered yet");
@@ -826,6 +888,7 @@ int bhray_read_level(bhray_ctx* c, uint32_t level, float* dst, size_t pitch) {
 int bhray_hdr_device_ptr(bhray_ctx* c, void** p, size_t* bytes) {
     if (!c || !p) return BHRAY_E_INVALID;
     if (c->single) { DEV(c, c->parts[0].dev, dev_hdr_device_ptr(c->parts[0].dev, p, bytes)); return BHRAY_OK; }
+    if (c->gather_sky) { *p = nullptr; return gfail(c, BHRAY_E_STATE, "BHRAY_F_GATHER_SKY: the RGBA32F frame is not assembled (read the sky image)"); }
     *p = c->root_local ? (void*)c->gslots[(size_t)c->last_slot].dst[c->last_sub] : nullptr;
     if (bytes) *bytes = c->root_local ? frame_pixels(c) * sizeof(float4) : 0;
     return BHRAY_OK;
@@ -834,6 +897,7 @@ int bhray_hdr_device_ptr(bhray_ctx* c, void** p, size_t* bytes) {
 int bhray_bind_output(bhray_ctx* c, void* p, size_t bytes) {
     if (!c) return BHRAY_E_INVALID;
     if (!p) { c->bound = nullptr; return BHRAY_OK; }
+    if (c->gather_sky) return gfail(c, BHRAY_E_STATE, "BHRAY_F_GATHER_SKY: the RGBA32F frame is not assembled (read the sky image)");
     size_t need;
     if (c->single) { void* q; DEV(c, c->parts[0].dev, dev_hdr_device_ptr(c->parts[0].dev, &q, &need)); }
     else need = c->root_local ? frame_pixels(c) * sizeof(float4) : 0;
@@ -847,6 +911,7 @@ int bhray_bind_output(bhray_ctx* c, void* p, size_t bytes) {
 int bhray_read_hdr_async(bhray_ctx* c, float* dst, size_t pitch, uint64_t* ticket) {
     if (!c || !ticket) return BHRAY_E_INVALID;
     if (c->single) { DEV(c, c->parts[0].dev, dev_read_hdr_async(c->parts[0].dev, dst, pitch, ticket)); return BHRAY_OK; }
+    if (c->gather_sky) return gfail(c, BHRAY_E_STATE, "BHRAY_F_GATHER_SKY: the RGBA32F frame is not assembled (read the sky image)");
     if (!c->rendered) return gfail(c, BHRAY_E_STATE, "nothing rendered yet");
     { int rc = group_flush(c); if (rc) return rc; }
     const uint64_t t = c->read_tickets;
@@ -875,6 +940,7 @@ int bhray_read_sky_async(bhray_ctx* c, uint16_t* dst, size_t pitch, uint64_t* ti
     if (!c || !ticket) return BHRAY_E_INVALID;
     if (c->single) { DEV(c, c->parts[0].dev, dev_read_sky_async(c->parts[0].dev, dst, pitch, ticket)); return BHRAY_OK; }
     if (!c->rendered) return gfail(c, BHRAY_E_STATE, "nothing rendered yet");
+    if (c->gather_sky) { int rc = group_flush(c); if (rc) return rc; }      // (the batch's gather produces the image)
     const uint64_t t = c->read_tickets;
     if (!c->root_local) { *ticket = t; c->read_tickets = t + 1; return BHRAY_OK; }
     const size_t rowb = (size_t)c->cfg.frame_w * sizeof(uint2);
@@ -1011,6 +1077,7 @@ int bhray_resolve_sky(bhray_ctx* c) {
     if (c->single) { DEV(c, c->parts[0].dev, dev_resolve_sky(c->parts[0].dev)); return BHRAY_OK; }
     if (!c->rendered) return gfail(c, BHRAY_E_STATE, "nothing rendered yet");
     { int rc = group_flush(c); if (rc) return rc; }
+    if (c->gather_sky) return BHRAY_OK;              // the partitions resolved their rows behind the render; the gather assembled the image
     if (!c->root_local) return BHRAY_OK;
     Part& rp = *root_part(c);
     CommRank* rr = rank_of(c, rp);

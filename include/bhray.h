@@ -172,6 +172,14 @@ enum {                                  /* bhray_config.flags */
                                            Like BHRAY_F_LITERAL it exists for measurement: the pixels on which it differs from the literal
                                            text by more than 1e-4 are the pixels on which the default evaluation does
                                            (tests/test_gpu_literal.py).  Ignored when BHRAY_F_LITERAL is set.                        */
+    BHRAY_F_GATHER_SKY = 1u << 7,       /* multi-GPU ctx only (device_count >= 2, or gather = BHRAY_GATHER_RCCL): gather the RGBA16F image of the
+                                           sky pass instead of the RGBA32F frame - HALF the bytes over xGMI.  Every partition runs the sky
+                                           pass (sky.wgsl, per pixel) over its own rows behind its render and sends 8-byte pixels; the root
+                                           assembles the sky image.  bhray_resolve_sky is then implied by bhray_render (calling it is
+                                           allowed and does nothing); bhray_read_sky / bhray_read_sky_async / bhray_sky_device_ptr deliver the
+                                           assembled image; the RGBA32F frame is NOT assembled: bhray_read_hdr, bhray_read_hdr_async,
+                                           bhray_hdr_device_ptr and bhray_bind_output return BHRAY_E_STATE.  For a host that lets the library
+                                           run the sky pass.  Same pixels as the sky pass over the assembled frame.  */
     BHRAY_F_LITERAL    = 1u << 2        /* the integrator (ray.wgsl:401-480, 533) operator by operator: one binary32 operation per
                                            WGSL operator in source order, no fused multiply-add, no reassociation.  Slower; exists
                                            to MEASURE how far the default evaluation (DESIGN.md §2, N3/N7/N9/N10 — permitted by

@@ -168,3 +168,62 @@ def test_bad_multi_device_configs_are_errors():
     with pytest.raises(B.BhrayError):
         rp.set_materials(bytes(64))                          # MaterialUniform x 8 = 128 bytes
     rp.close()
+
+
+@pytest.mark.parametrize("kw", [dict(devices=[0, 0, 0], stripe_rows=9), dict(devices=[0, 0, 0, 0], gather_root=2, slab_row0=[0, 20, 55, 55, 110]),
+                                dict(devices=[0, 0], stripe_rows=27, frames_per_batch=3, frames_in_flight=2)])
+def test_gather_of_the_sky_image_is_the_sky_pass_over_the_whole_frame(kw):
+    """BHRAY_F_GATHER_SKY: every partition runs the sky pass over its own rows and 8-byte pixels travel; the image the root assembles is
+    byte for byte the sky pass over the frame rendered whole - stripes, slabs (one empty), a root in the middle, batches, slot reuse,
+    the asynchronous read - and the RGBA32F outputs are refused."""
+    tex = T.textures()
+    frames = [T.uniforms(integration_method=1), T.uniforms(integration_method=1, time=0.7, camera=B.Camera(position=(1.0, 2.0, -17.0), forward=(0.0, -0.1, 1.0), fov=1.1)),
+              T.uniforms(integration_method=0, step_size=0.2)]
+    cfg = B.ladder_for_frame((200, 110), 3, 3)
+    want = []
+    for u in frames:
+        one = B.RayPass(cfg, device=0); one.set_textures(*tex); one.set_uniforms(*u); one.render(); one.resolve_sky(); want.append(one.read_sky()); one.close()
+    rp = B.RayPass(cfg, gather_sky=True, **kw)
+    rp.set_textures(*tex)
+    order = [0, 1, 2, 2, 1, 0, 1]
+    bufs = [B.PinnedFrame(110, 200, channels16=True) for _ in order]
+    tickets = []
+    for i, f in enumerate(order):
+        rp.set_uniforms(*frames[f]); rp.render()
+        if i % 2:
+            rp.resolve_sky()                                     # allowed, does nothing
+        tickets.append(rp.read_sky_async(bufs[i]))
+    for t in reversed(tickets):
+        rp.wait_read(t)
+    for i, f in enumerate(order):
+        assert np.array_equal(bufs[i].array.view(np.uint16), want[f].view(np.uint16)), f"{kw}: frame {i}"
+    assert np.array_equal(rp.read_sky().view(np.uint16), want[order[-1]].view(np.uint16))
+    for call in (rp.read_hdr, lambda: rp.read_hdr_async(B.PinnedFrame(110, 200))):
+        with pytest.raises(B.BhrayError) as e:
+            call()
+        assert e.value.code == -5
+    info = rp.gather_info()
+    rows_elsewhere = 110 - len(B.config_partition_rows(rp.cfg)[kw.get("gather_root", 0)])
+    assert info["bytes_received_per_frame"] == rows_elsewhere * 200 * 8, info          # 8 bytes per pixel travel, not 16
+    for b in bufs:
+        b.free()
+    rp.close()
+
+
+def test_gather_sky_needs_a_multi_gpu_ctx():
+    cfg = B.ladder_from_base((24, 14), 3, 2)
+    with pytest.raises(B.BhrayError) as e:
+        B.RayPass(cfg, device=0, gather_sky=True)
+    assert e.value.code == -1
+
+
+def test_gather_of_the_sky_image_with_an_odd_row_length():
+    """rows of an odd number of 8-byte pixels do not start on 16 bytes: the de-interleave's one-pixel path"""
+    tex = T.textures()
+    u = T.uniforms(integration_method=1)
+    cfg = B.ladder_for_frame((199, 111), 3, 3)
+    one = B.RayPass(cfg, device=0); one.set_textures(*tex); one.set_uniforms(*u); one.render(); one.resolve_sky(); want = one.read_sky(); one.close()
+    rp = B.RayPass(cfg, devices=[0, 0, 0], stripe_rows=5, gather_sky=True)
+    rp.set_textures(*tex); rp.set_uniforms(*u); rp.render()
+    assert np.array_equal(rp.read_sky().view(np.uint16), want.view(np.uint16))
+    rp.close()
