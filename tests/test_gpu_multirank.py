@@ -28,7 +28,7 @@ def _line(r):
     return json.loads(out[0])
 
 
-@pytest.mark.parametrize("n,extra", [(2, []), (4, ["--gather-root", "3", "--frames-per-batch", "3"]), (8, [])])
+@pytest.mark.parametrize("n,extra", [(2, []), (4, ["--gather-root", "3", "--frames-per-batch", "3"]), (8, []), (4, ["--gather-sky", "--gather-root", "1"])])
 def test_bench_gpus_n_without_a_launcher(n, extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--devices", ",".join(["0"] * n)] + COMMON + extra
     d = _line(subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT))
@@ -36,6 +36,8 @@ def test_bench_gpus_n_without_a_launcher(n, extra):
     assert d["config"]["verified_frames"] == 1
     g = d["gather"]
     assert g["batches_gathered"] >= 1 and g["bytes_received_per_frame"] > 0 and "RCCL" in g["transport"]
+    if "--gather-sky" in extra:                                   # the verification compared sky images; 8 bytes per pixel travelled
+        assert "RGBA16F" in g["gathered_image"] and g["bytes_received_per_frame"] < 960 * 540 * 8
 
 
 def test_bench_under_torchrun_single_process_model():
