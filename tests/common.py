@@ -68,3 +68,17 @@ class DeviceBuffer:
         if self.ptr:
             self.hip.hipFree(self.ptr)
             self.ptr = None
+
+
+def variant_library(target: str) -> str:
+    """Path of bhusie_amd/libbhray_<target>.so - another in-tree build of the SAME sources (`make -C bhusie_amd/csrc <target>`: fused, stack2,
+    pair; __graft_entry__.build() makes them all).  Built here if it is missing (a fresh checkout on a box with hipcc): never a fallback."""
+    import os
+    import subprocess
+    from bhusie_amd import _lib
+    root = os.path.dirname(os.path.abspath(_lib.__file__))
+    path = os.path.join(root, f"libbhray_{target}.so")
+    if not os.path.exists(path):
+        r = subprocess.run(["make", "-C", os.path.join(root, "csrc"), "-j4", target], capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0 and os.path.exists(path), f"{path} not built: make -C bhusie_amd/csrc {target}\n{r.stdout[-1500:]}{r.stderr[-1500:]}"
+    return path

@@ -92,8 +92,7 @@ def test_chain_deeper_than_the_trail_is_an_error_not_pixels():
 def stack2_library():
     """libbhray_stack2.so: the same sources with -DBHRAY_BVH_LDS_STACK=2"""
     from bhusie_amd import _lib, layouts
-    path = os.path.join(os.path.dirname(_lib.LIB_PATH), "libbhray_stack2.so")
-    assert os.path.exists(path), f"{path} not built: make -C bhusie_amd/csrc stack2"
+    path = T.variant_library("stack2")
     saved = _lib.lib()
     L = C.CDLL(path)
     layouts.declare(L)

@@ -20,8 +20,7 @@ def fused_library():
     import ctypes as C
     import os
     from bhusie_amd import _lib, layouts
-    path = os.path.join(os.path.dirname(_lib.LIB_PATH), "libbhray_fused.so")
-    assert os.path.exists(path), f"{path} not built: make -C bhusie_amd/csrc fused"
+    path = T.variant_library("fused")
     saved = _lib.lib()
     L = C.CDLL(path)
     layouts.declare(L)
