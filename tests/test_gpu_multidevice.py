@@ -227,3 +227,44 @@ def test_gather_of_the_sky_image_with_an_odd_row_length():
     rp.set_textures(*tex); rp.set_uniforms(*u); rp.render()
     assert np.array_equal(rp.read_sky().view(np.uint16), want.view(np.uint16))
     rp.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_random_partitions_batches_and_roots_assemble_the_single_ctx_frame(seed):
+    """Seeded random combinations of frame size, ladder depth, number of partitions, stripes or uneven slabs (empty ones included), root,
+    frames per batch, frame slots, integrator and gathered image (RGBA32F frame / RGBA16F sky image): frames in random order through the
+    multi-partition ctx equal the frames of a partition-less ctx byte for byte."""
+    rng = np.random.default_rng(1000 + seed)
+    w, h = int(rng.integers(40, 260)), int(rng.integers(30, 160))
+    levels = int(rng.integers(2, 5))
+    cfg = B.ladder_for_frame((w, h), 3, levels)
+    n = int(rng.integers(2, 6))
+    kw = dict(devices=[0] * n, gather_root=int(rng.integers(0, n)), frames_per_batch=int(rng.integers(1, 4)), frames_in_flight=int(rng.integers(1, 4)),
+              speculative_levels=int(rng.choice([0, 2])) if levels >= 3 else 0)
+    if rng.random() < 0.5:
+        kw["stripe_rows"] = int(rng.integers(1, 30))
+    else:
+        cuts = sorted(int(v) for v in rng.integers(0, h + 1, n - 1))
+        kw["slab_row0"] = [0] + cuts + [h]
+    sky = bool(rng.random() < 0.5)
+    method = int(rng.integers(0, 2))
+    tex = T.textures()
+    frames = [T.uniforms(integration_method=method, step_size=0.15 if method else 0.2, time=float(t)) for t in (0.0, 0.9, 2.3)]
+    want = []
+    for u in frames:
+        one = B.RayPass(cfg, device=0, speculative_levels=kw["speculative_levels"]); one.set_textures(*tex); one.set_uniforms(*u); one.render()
+        if sky:
+            one.resolve_sky(); want.append(one.read_sky())
+        else:
+            want.append(one.read_hdr())
+        one.close()
+    rp = B.RayPass(cfg, gather_sky=sky, **kw)
+    rp.set_textures(*tex)
+    order = [int(v) for v in rng.integers(0, 3, 7)]
+    word = np.uint16 if sky else np.uint32
+    for i, f in enumerate(order):
+        rp.set_uniforms(*frames[f]); rp.render()
+        if i % 3 == 2 or i == len(order) - 1:                   # read some frames (a read flushes a partial batch), let others pass unread
+            got = rp.read_sky() if sky else rp.read_hdr()
+            assert np.array_equal(got.view(word), want[f].view(word)), (seed, kw, sky, method, i)
+    rp.close()
