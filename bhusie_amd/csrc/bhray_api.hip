@@ -1007,6 +1007,7 @@ struct BatchPlan {
 
     // BHRAY_F_TEMPORAL: the previous frame's traced set in ONE launch, then the ladder fixes up what that prediction missed
     int temporal() {
+        const bool shared_device = c->slots.size() > 1;     // other frames' launches share the device with this batch's
         // Temporal speculation: ONE launch traces, for every level, the pixels the previous frame held in this slot position had
         // to trace (its exact classification recorded them); then the ladder runs as usual, except that a pixel that needs tracing
         // and was delivered by the predicted launch (stamp) is not traced again.  With a perfect prediction the per-level trace
@@ -1051,8 +1052,12 @@ struct BatchPlan {
                 h[k].stamp_value = R.stamp_value; h[k].probe_empty = 1;
             }
             // the predicted launch holds a whole frame's rays: the dense build (0.61 against 0.66 ms at 1080p); the fix-up launches are
-            // expected to be nearly empty: the latency build, which looks at the queue head before its first atomic
-            seq.push_back({1, d, c->num_cus * trace_blocks_per_cu(S.method, S.models, count, 1, literal), count, {}, {(int)(3 * nl + 3)}, 1});
+            // expected to be nearly empty: the latency build, which looks at the queue head before its first atomic.
+            // Grids: with ONE frame slot the device is this frame's - full-occupancy grids; with several slots the ctx's rule for every
+            // trace launch (2 persistent blocks per CU: `grid`) - a full-device persistent grid keeps the next batch's small kernels
+            // (its prediction, its fix-up classification) waiting until it has drained, and two batches then run one after the other
+            // (rank 3 of an 8-way 1080p partition, 20-frame blocks of a moving sequence: 0.0995 -> 0.0736 ms per frame, EXPERIMENTS R4.12)
+            seq.push_back({1, d, shared_device ? grid : c->num_cus * trace_blocks_per_cu(S.method, S.models, count, 1, literal), count, {}, {(int)(3 * nl + 3)}, 1});
         }
         for (uint32_t l = 0; l < nl; l++) {
             FrameLaunch* h; const FrameLaunch* d; next_launch(h, d);
@@ -1066,7 +1071,7 @@ struct BatchPlan {
                 h[k].row_work = (count && R.d_row_work) ? R.d_row_work + c->row_work_off[l] : nullptr;
             }
             seq.push_back({0, d, classify_blocks(l), count, {(int)(3 * l)}, {(int)(3 * l + 1)}, -1, true});
-            seq.push_back({1, d, c->num_cus * trace_blocks_per_cu(S.method, S.models, count, 0, literal), count, {}, {(int)(3 * l + 2)}, 0});
+            seq.push_back({1, d, shared_device ? grid : c->num_cus * trace_blocks_per_cu(S.method, S.models, count, 0, literal), count, {}, {(int)(3 * l + 2)}, 0});
         }
         first_normal = nl;
         return BHRAY_OK;
