@@ -914,12 +914,21 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
     // Such a launch lasts as long as its longest ray, and what that ray pays per iteration is what its wave executes: with 63
     // lane-mates nearly every iteration includes the step-size power and the hit tests (one lane of 64 suffices), with a few
     // lane-mates mostly only what the ray itself needs.  Scheduling only: every ray is the same sequence of operations.
-    uint32_t thin_share = 0;
-    if (!DENSE && nb == 1 && BHRAY_THIN_WAVES > 0) {      // (a batch: a wave would finish its share of one frame before it starts the next)
-        const uint32_t total = gridDim.x * (BHRAY_TRACE_THREADS / 64);
-        const uint32_t waves = total < (uint32_t)BHRAY_THIN_WAVES ? total : (uint32_t)BHRAY_THIN_WAVES;
-        const uint32_t share = (qcount + waves - 1) / waves;
-        if (share < 64u) thin_share = share > 0u ? share : 1u;
+    // A batch (nb > 1): the blocks whose OWN frame this is (blockIdx % nb == fb: every block starts with its own frame) deal the frame's
+    // rays out among themselves the same way, and the blocks that come by later to help (fi > 0) leave such a frame alone - it has no
+    // queue head to pull from.  (A rank of an 8-way partition renders its coarse levels in launches of ten frames x a few hundred rays.)
+    uint32_t thin_share = 0, thin_block = blockIdx.x;
+    if (!DENSE && !FZ && BHRAY_THIN_WAVES > 0) {          // (the fused ladder has its own queues and its own frame loop)
+        uint32_t own_blocks = gridDim.x;
+        if (nb > 1) { own_blocks = (gridDim.x - (uint32_t)fb + (uint32_t)nb - 1u) / (uint32_t)nb; thin_block = blockIdx.x / (uint32_t)nb; }
+        const uint32_t total = own_blocks * (BHRAY_TRACE_THREADS / 64);
+        const uint32_t cap = nb > 1 ? ((uint32_t)BHRAY_THIN_WAVES + (uint32_t)nb - 1u) / (uint32_t)nb : (uint32_t)BHRAY_THIN_WAVES;
+        const uint32_t waves = total < cap ? total : cap;
+        if (waves > 0u) {
+            const uint32_t share = (qcount + waves - 1) / waves;
+            if (share < 64u) thin_share = share > 0u ? share : 1u;
+        }
+        if (thin_share != 0u && fi != 0) continue;
     }
     const HotParams H = load_hot(P);
     const F3 bpos = H.bh;
@@ -968,7 +977,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                 uint32_t base = 0;
                 if (!DENSE && thin_share != 0u) {                 // this wave's share, once (all lanes are empty: n == 64 > share)
                     n = thin_share;
-                    base = (blockIdx.x * (BHRAY_TRACE_THREADS / 64) + (threadIdx.x >> 6)) * thin_share;
+                    base = (thin_block * (BHRAY_TRACE_THREADS / 64) + (threadIdx.x >> 6)) * thin_share;
                     exhausted = true;
                 } else {
                     // (the lane id recomputed here - two instructions - instead of held in a VGPR across the step loop: the dense build has none to spare)

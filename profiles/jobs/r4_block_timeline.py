@@ -6,7 +6,10 @@ from tests import common as T
 mode = sys.argv[1]
 cfg = B.ladder_for_frame((1920, 1080), 3, 4)
 kw = dict(temporal=True) if mode == "temporal" else dict(speculative_levels=2)
-rp = B.RayPass(cfg, device=0, row_rank=3, row_world=8, frames_in_flight=22, frames_per_batch=10, **kw)
+import os
+world = int(os.environ.get("TL_WORLD", "8")); fpb = int(os.environ.get("TL_FPB", "10"))
+part = dict(row_rank=3, row_world=world) if world > 1 else {}
+rp = B.RayPass(cfg, device=0, frames_in_flight=22, frames_per_batch=fpb, **part, **kw)
 rp.set_textures(*T.textures(small=False))
 us = [T.uniforms(integration_method=1, max_iterations=2000, time=i / 60.0) for i in range(300)]
 i = 0

@@ -13,7 +13,7 @@ for b in rows[1:]:
     groups[-1].append(b)
 g = groups[-1]
 t0 = int(g[0]["Start_Timestamp"])
-out = open("$R/gpurun_out/tl/r04_rank3_block_timeline_$mode.txt", "w")
+out = open("$R/gpurun_out/tl/r04_${TL_TAG:-rank3}_block_timeline_$mode.txt", "w")
 for r in g:
     line = "%8.1f %8.1f  %7.1f us  grid %7s  %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r["Grid_Size_X"], r["Kernel_Name"][:58])
     print(line); out.write(line + "\n")
