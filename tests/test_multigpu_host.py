@@ -90,8 +90,9 @@ def test_launcher_plumbing_world2_gloo(tmp_path):
 
 
 def test_frames_per_batch_rule_counts_pixels_and_divides_the_block():
-    """bench.py's batch size: about 2.5 frames' worth of 1920x1080 pixels per launch, never more than half a timed block, and a divisor of a
-    short block (batches of equal size) - the larger one on a tie (3840x2160 over 8 GPUs, 20-frame blocks: 4 batches of 5, measured best)."""
+    """bench.py's batch size: about 2.5 frames' worth of 1920x1080 pixels per launch, never more than a quarter of a timed block (several
+    batches must overlap: one's coarse launches with another's last level), and a divisor of a short block (batches of equal size) - the
+    larger one on a tie."""
     import argparse
     sys.path.insert(0, ROOT)
     import bench
@@ -99,11 +100,11 @@ def test_frames_per_batch_rule_counts_pixels_and_divides_the_block():
     def fpb(w, h, steps, world):
         return bench.auto_frames_per_batch(argparse.Namespace(width=w, height=h, steps=steps), world)
     assert fpb(1920, 1080, 20, 1) == 1 and fpb(3840, 2160, 20, 1) == 1          # a whole frame per GPU: no batching
-    assert fpb(1920, 1080, 20, 8) == 10 and fpb(1920, 1080, 2000, 8) == 16      # capped by half a block / by 16
+    assert fpb(1920, 1080, 20, 8) == 5 and fpb(1920, 1080, 2000, 8) == 16       # capped by a quarter of the block / by 16
     assert fpb(3840, 2160, 20, 8) == 5 and fpb(3840, 2160, 500, 8) == 5
     assert fpb(7680, 4320, 20, 8) == 1
-    assert fpb(1920, 1080, 20, 4) == 10 and fpb(1920, 1080, 1000, 4) == 10 and fpb(1920, 1080, 1000, 2) == 5
+    assert fpb(1920, 1080, 20, 4) == 5 and fpb(1920, 1080, 1000, 4) == 10 and fpb(1920, 1080, 1000, 2) == 5 and fpb(1920, 1080, 20, 2) == 5
     for steps in (7, 20, 21, 64):
         for world in (2, 4, 8):
             b = fpb(1920, 1080, steps, world)
-            assert 1 <= b <= max(1, (steps + 1) // 2) and (steps % b == 0 or b == (steps + 1) // 2)
+            assert 1 <= b <= max(1, steps // 4) and (steps % b == 0 or b == steps // 4)
