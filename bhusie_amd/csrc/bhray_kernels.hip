@@ -918,7 +918,14 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
     // rays out among themselves the same way, and the blocks that come by later to help (fi > 0) leave such a frame alone - it has no
     // queue head to pull from.  (A rank of an 8-way partition renders its coarse levels in launches of ten frames x a few hundred rays.)
     uint32_t thin_share = 0, thin_block = blockIdx.x;
-    if (!DENSE && !FZ && BHRAY_THIN_WAVES > 0) {          // (the fused ladder has its own queues and its own frame loop)
+    if (MODELS) {                                         // the mesh variant (96-VGPR budget: -2 % with the batch form below) keeps the single-frame form
+        if (!DENSE && nb == 1 && BHRAY_THIN_WAVES > 0) {
+            const uint32_t total = gridDim.x * (BHRAY_TRACE_THREADS / 64);
+            const uint32_t waves = total < (uint32_t)BHRAY_THIN_WAVES ? total : (uint32_t)BHRAY_THIN_WAVES;
+            const uint32_t share = (qcount + waves - 1) / waves;
+            if (share < 64u) thin_share = share > 0u ? share : 1u;
+        }
+    } else if (!DENSE && !FZ && BHRAY_THIN_WAVES > 0) {   // (the fused ladder has its own queues and its own frame loop)
         uint32_t own_blocks = gridDim.x;
         if (nb > 1) { own_blocks = (gridDim.x - (uint32_t)fb + (uint32_t)nb - 1u) / (uint32_t)nb; thin_block = blockIdx.x / (uint32_t)nb; }
         const uint32_t total = own_blocks * (BHRAY_TRACE_THREADS / 64);
