@@ -925,7 +925,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
             const uint32_t share = (qcount + waves - 1) / waves;
             if (share < 64u) thin_share = share > 0u ? share : 1u;
         }
-    } else if (!DENSE && !FZ && BHRAY_THIN_WAVES > 0) {   // (the fused ladder has its own queues and its own frame loop)
+    } else if (!DENSE && !FZ && BHRAY_THIN_WAVES > 0 && (nb == 1 || gridDim.x >= 4u * (uint32_t)nb)) {   // (the fused ladder has its own queues and its own frame loop; every frame of a batch needs blocks of its own)
         uint32_t own_blocks = gridDim.x;
         if (nb > 1) { own_blocks = (gridDim.x - (uint32_t)fb + (uint32_t)nb - 1u) / (uint32_t)nb; thin_block = blockIdx.x / (uint32_t)nb; }
         const uint32_t total = own_blocks * (BHRAY_TRACE_THREADS / 64);
