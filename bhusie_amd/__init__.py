@@ -21,4 +21,4 @@ from .layouts import (BhrayConfig, BhrayCounters, BhrayTiming, BhrayDetails, Bhr
                       BhrayError, check)
 from .scene import Camera, BlackHole, RayDetails  # noqa: F401
 from .model import Model, load_model  # noqa: F401
-from .renderer import RayPass, Renderer, PinnedFrame, ladder_from_base, ladder_for_frame, comm_unique_id, partition_rows, config_partition_rows, balance_slabs  # noqa: F401
+from .renderer import RayPass, Renderer, PinnedFrame, ladder_from_base, ladder_for_frame, comm_unique_id, partition_rows, config_partition_rows, balance_slabs, rebalance_slabs  # noqa: F401

@@ -42,7 +42,8 @@ struct Level {                      // geometry of one ladder level (shared by a
     int32_t* d_rows = nullptr;
     int32_t* d_rows_near = nullptr; // BHRAY_ROW_VARIANTS orderings of the same rows, tile rows nearest a centre row first (variant v: centre v / (N-1) of the level's height)
     int32_t* d_rowmap = nullptr;    // final level only
-    size_t queue_cap = 0;
+    size_t queue_cap = 0;           // entries the level's queue can need: its rows x its columns
+    size_t queue_alloc = 0;         // entries allocated per frame (>= queue_cap; grows when the partition changes: dev_set_partition)
 };
 
 // Resources of one frame: level images, work queues and output buffer.
@@ -134,6 +135,8 @@ struct bhray_dev {
     int launched_slot = -1;                // dev_take_launched
     uint32_t launched_frames = 0;
     size_t out_bytes = 0;
+    size_t out_alloc = 0;                  // bytes of every frame's own output buffer (>= out_bytes)
+    size_t spec_alloc = 0, pred_alloc = 0, super_alloc = 0;   // entries of the merged queues (speculative / temporal / superset modes)
     std::vector<uint32_t> local_rows;      // frame rows of this partition, increasing
     size_t row_work_off[BHRAY_MAX_LEVELS + 1] = {0};   // BHRAY_F_COUNTERS: offset of every level's rows in FrameRes::d_row_work; [levels] = total
     // scene
@@ -414,6 +417,121 @@ void dev_destroy(bhray_dev* c) {
     delete c;
 }
 
+namespace {
+// The partition's rows (bhray_config.partition of c->cfg), the level rows they depend on (top-down, ray.wgsl:185-201), and their
+// device tables.  The tables are allocated for a whole level, so a partition set later (dev_set_partition) rewrites them in place.
+int build_row_tables(bhray_dev* c) {
+    const bhray_config* cfg = &c->cfg;
+    const uint32_t nl = cfg->levels;
+    c->local_rows = partition_row_list(*cfg, cfg->row_world, cfg->row_rank);
+    for (uint32_t l = 0; l < nl; l++) c->levels[l].rows.clear();
+    {
+        Level& F = c->levels[nl - 1];
+        for (uint32_t r : c->local_rows) F.rows.push_back((int32_t)(cfg->crop_y + r));
+        for (int l = (int)nl - 1; l > 0; l--)
+            c->levels[l - 1].rows = coarse_rows_needed(c->levels[l].rows, c->levels[l].h, c->levels[l - 1].h);
+    }
+    for (uint32_t l = 0; l < nl; l++) {
+        Level& L = c->levels[l];
+        const bool last = (l == nl - 1);
+        const size_t nrows = L.rows.size();
+        if (!L.d_rows) HIPCHK(c, hipMalloc(&L.d_rows, (size_t)L.h * sizeof(int32_t)));
+        if (nrows) {
+            HIPCHK(c, hipMemcpy(L.d_rows, L.rows.data(), nrows * sizeof(int32_t), hipMemcpyHostToDevice));
+            if (BHRAY_ROW_VARIANTS >= 2 && !(cfg->flags & BHRAY_F_FUSED)) {
+                // The same rows with the tile rows (8 list entries) nearest a centre row first: the rays that pass closest to the hole are the
+                // longest, and a launch lasts as long as its last rays - classified first they enter the queue first and are traced first
+                // (every pixel is classified independently of the others: the order changes nothing else).  One ordering per centre row;
+                // a frame picks the one nearest the row the hole projects to (dev_render).
+                const size_t nch = nrows / 8;                         // whole tile rows; a short last one stays last
+                std::vector<int32_t> all((size_t)BHRAY_ROW_VARIANTS * nrows);
+                for (int v = 0; v < BHRAY_ROW_VARIANTS; v++) {
+                    const double centre = (double)v / (double)(BHRAY_ROW_VARIANTS - 1) * (double)(L.h - 1);
+                    std::vector<size_t> ch(nch);
+                    for (size_t k = 0; k < nch; k++) ch[k] = k;
+                    std::stable_sort(ch.begin(), ch.end(), [&](size_t a, size_t b) {
+                        return fabs((double)L.rows[a * 8 + 4] - centre) < fabs((double)L.rows[b * 8 + 4] - centre);
+                    });
+                    int32_t* o = all.data() + (size_t)v * nrows;
+                    size_t n = 0;
+                    for (size_t k : ch) for (size_t j = k * 8; j < k * 8 + 8; j++) o[n++] = L.rows[j];
+                    for (size_t j = nch * 8; j < nrows; j++) o[n++] = L.rows[j];
+                }
+                if (!L.d_rows_near) HIPCHK(c, hipMalloc(&L.d_rows_near, (size_t)BHRAY_ROW_VARIANTS * (size_t)L.h * sizeof(int32_t)));
+                HIPCHK(c, hipMemcpy(L.d_rows_near, all.data(), all.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            }
+        }
+        const size_t span = last ? cfg->frame_w : (size_t)L.w;
+        L.queue_cap = nrows * span;
+        if (last) {
+            std::vector<int32_t> map((size_t)L.h, -1);
+            for (size_t i = 0; i < c->local_rows.size(); i++) map[(size_t)(cfg->crop_y + c->local_rows[i])] = c->opt.frame_rowmap ? (int32_t)c->local_rows[i] : (int32_t)i;
+            if (!L.d_rowmap) HIPCHK(c, hipMalloc(&L.d_rowmap, (size_t)L.h * sizeof(int32_t)));
+            HIPCHK(c, hipMemcpy(L.d_rowmap, map.data(), (size_t)L.h * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+    }
+    c->out_bytes = (c->opt.frame_rowmap ? (size_t)cfg->frame_h : c->local_rows.size()) * (size_t)cfg->frame_w * sizeof(float4);
+    return BHRAY_OK;
+}
+
+// Every frame's ray queues and own output buffer, sized for the current partition.  `headroom` (a partition set at run time): a buffer
+// that has to grow grows by a quarter more than needed, so that bounds that keep moving a few rows do not reallocate every time.
+int ensure_frame_buffers(bhray_dev* c, bool headroom) {
+    const bhray_config* cfg = &c->cfg;
+    const uint32_t nl = cfg->levels;
+    auto want = [&](size_t need, size_t full) { size_t w = headroom ? need + need / 4 + 64 : need; return w > full ? std::max(full, need) : w; };
+    for (uint32_t l = 0; l < nl; l++) {
+        Level& L = c->levels[l];
+        if (L.queue_cap <= L.queue_alloc) continue;
+        const size_t full = (size_t)L.h * (size_t)(l == nl - 1 ? cfg->frame_w : (uint32_t)L.w);
+        const size_t n = want(L.queue_cap, full);
+        for (Slot& S : c->slots) for (FrameRes& R : S.fr) {
+            if (R.queue[l]) { HIPCHK(c, hipFree(R.queue[l])); R.queue[l] = nullptr; }
+            HIPCHK(c, hipMalloc(&R.queue[l], n * sizeof(uint32_t)));
+        }
+        L.queue_alloc = n;
+    }
+    auto merged = [&](size_t need, size_t& alloc, uint32_t* FrameRes::*member) -> int {
+        if (need <= alloc) return BHRAY_OK;
+        const size_t n = headroom ? need + need / 4 + 64 : need;
+        for (Slot& S : c->slots) for (FrameRes& R : S.fr) {
+            if (R.*member) { HIPCHK(c, hipFree(R.*member)); R.*member = nullptr; }
+            HIPCHK(c, hipMalloc(&(R.*member), n * sizeof(uint32_t)));
+        }
+        alloc = n;
+        return BHRAY_OK;
+    };
+    if (cfg->speculative_levels) {
+        size_t cap = 0;
+        for (uint32_t l = 0; l < cfg->speculative_levels; l++) cap += c->levels[l].queue_cap;
+        int rc = merged(cap, c->spec_alloc, &FrameRes::spec_queue); if (rc) return rc;
+    }
+    if (cfg->flags & BHRAY_F_TEMPORAL) {
+        size_t cap = 0;
+        for (uint32_t l = 0; l < nl; l++) cap += c->levels[l].queue_cap;
+        int rc = merged(cap, c->pred_alloc, &FrameRes::pred_queue); if (rc) return rc;
+    }
+    if (cfg->superset_levels) {
+        size_t cap = 0;
+        for (uint32_t l = nl - cfg->superset_levels; l < nl; l++) cap += c->levels[l].queue_cap;
+        int rc = merged(cap, c->super_alloc, &FrameRes::super_queue); if (rc) return rc;
+    }
+    if (!c->opt.external_out && c->out_bytes > c->out_alloc) {
+        const size_t full = (size_t)cfg->frame_h * (size_t)cfg->frame_w * sizeof(float4);
+        size_t n = headroom ? c->out_bytes + c->out_bytes / 4 : c->out_bytes;
+        if (n > full) n = std::max(full, c->out_bytes);
+        for (Slot& S : c->slots) for (FrameRes& R : S.fr) {
+            if (R.own_out) { HIPCHK(c, hipFree(R.own_out)); R.own_out = nullptr; }
+            HIPCHK(c, hipMalloc(&R.own_out, n));
+            HIPCHK(c, hipMemset(R.own_out, 0xFF, n));
+            R.out = R.own_out;
+        }
+        c->out_alloc = n;
+    }
+    return BHRAY_OK;
+}
+}  // namespace
+
 int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev** out) {
     if (!cfg || !out) return fail(nullptr, BHRAY_E_INVALID, "null argument");
     *out = nullptr;
@@ -482,59 +600,12 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
     c->batch = cfg->frames_per_batch ? cfg->frames_per_batch : 1;
     c->cfg.frames_per_batch = c->batch;
 
-    // rows of the frame owned by this partition
-    c->local_rows = partition_row_list(*cfg, cfg->row_world, cfg->row_rank);
-
     const uint32_t nl = cfg->levels;
     c->levels.resize(nl);
     for (uint32_t l = 0; l < nl; l++) { c->levels[l].w = (int)cfg->level_w[l]; c->levels[l].h = (int)cfg->level_h[l]; }
     for (uint32_t l = 0; l < nl; l++) c->row_work_off[l + 1] = c->row_work_off[l] + (size_t)cfg->level_h[l];
-    // top-down row dependency
-    {
-        Level& F = c->levels[nl - 1];
-        for (uint32_t r : c->local_rows) F.rows.push_back((int32_t)(cfg->crop_y + r));
-        for (int l = (int)nl - 1; l > 0; l--)
-            c->levels[l - 1].rows = coarse_rows_needed(c->levels[l].rows, c->levels[l].h, c->levels[l - 1].h);
-    }
-    for (uint32_t l = 0; l < nl; l++) {
-        Level& L = c->levels[l];
-        const bool last = (l == nl - 1);
-        const size_t nrows = L.rows.size();
-        if (nrows) {
-            CHK(hipMalloc(&L.d_rows, nrows * sizeof(int32_t)));
-            CHK(hipMemcpy(L.d_rows, L.rows.data(), nrows * sizeof(int32_t), hipMemcpyHostToDevice));
-            if (BHRAY_ROW_VARIANTS >= 2 && !(cfg->flags & BHRAY_F_FUSED)) {
-                // The same rows with the tile rows (8 list entries) nearest a centre row first: the rays that pass closest to the hole are the
-                // longest, and a launch lasts as long as its last rays - classified first they enter the queue first and are traced first
-                // (every pixel is classified independently of the others: the order changes nothing else).  One ordering per centre row;
-                // a frame picks the one nearest the row the hole projects to (dev_render).
-                const size_t nch = nrows / 8;                         // whole tile rows; a short last one stays last
-                std::vector<int32_t> all((size_t)BHRAY_ROW_VARIANTS * nrows);
-                for (int v = 0; v < BHRAY_ROW_VARIANTS; v++) {
-                    const double centre = (double)v / (double)(BHRAY_ROW_VARIANTS - 1) * (double)(L.h - 1);
-                    std::vector<size_t> ch(nch);
-                    for (size_t k = 0; k < nch; k++) ch[k] = k;
-                    std::stable_sort(ch.begin(), ch.end(), [&](size_t a, size_t b) {
-                        return fabs((double)L.rows[a * 8 + 4] - centre) < fabs((double)L.rows[b * 8 + 4] - centre);
-                    });
-                    int32_t* o = all.data() + (size_t)v * nrows;
-                    size_t n = 0;
-                    for (size_t k : ch) for (size_t j = k * 8; j < k * 8 + 8; j++) o[n++] = L.rows[j];
-                    for (size_t j = nch * 8; j < nrows; j++) o[n++] = L.rows[j];
-                }
-                CHK(hipMalloc(&L.d_rows_near, all.size() * sizeof(int32_t)));
-                CHK(hipMemcpy(L.d_rows_near, all.data(), all.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-            }
-        }
-        const size_t span = last ? cfg->frame_w : (size_t)L.w;
-        L.queue_cap = nrows * span;
-        if (last) {
-            std::vector<int32_t> map((size_t)L.h, -1);
-            for (size_t i = 0; i < c->local_rows.size(); i++) map[(size_t)(cfg->crop_y + c->local_rows[i])] = opt.frame_rowmap ? (int32_t)c->local_rows[i] : (int32_t)i;
-            CHK(hipMalloc(&L.d_rowmap, (size_t)L.h * sizeof(int32_t)));
-            CHK(hipMemcpy(L.d_rowmap, map.data(), (size_t)L.h * sizeof(int32_t), hipMemcpyHostToDevice));
-        }
-    }
+    // rows of the frame owned by this partition, the level rows they depend on, their device tables
+    { int rc_ = build_row_tables(c); if (rc_) { g_create_error = c->err; dev_destroy(c); return rc_; } }
     if ((cfg->flags & BHRAY_F_FUSED) && !c->levels[nl - 1].rows.empty()) {
         FusedTables& Z = c->fz;
         Z.on = true;
@@ -597,7 +668,6 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
             CHK(transpose(ys, Z.tiles_y[l - 1], Z.d_ny_off[l - 1], Z.d_ny_list[l - 1]));
         }
     }
-    c->out_bytes = (opt.frame_rowmap ? (size_t)cfg->frame_h : c->local_rows.size()) * (size_t)cfg->frame_w * sizeof(float4);
     const size_t nlaunch = 5 * (size_t)nl + 3;                            // upper bound of launches per batch
     // Streams beyond the hardware queues ROCm maps them onto (GPU_MAX_HW_QUEUES, default 4; two are left to the null stream and a
     // communication stream) do not add concurrency, they alias - and a device with MORE streams than queues collapses (24 slots on 24
@@ -605,6 +675,7 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
     // beyond the limit share the streams of the first ones (two frames on one stream are simply in order).
     size_t max_streams = 2;
     { const char* e = getenv("GPU_MAX_HW_QUEUES"); const int q = e ? atoi(e) : 4; max_streams = q > 3 ? (size_t)(q - 2) : 2; }
+    if (opt.max_streams && max_streams > opt.max_streams) max_streams = opt.max_streams;
     for (size_t si = 0; si < c->slots.size(); si++) {
         Slot& S = c->slots[si];
         if (si < max_streams) CHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
@@ -633,43 +704,31 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
                     CHK(hipMalloc(&R.level_out[l], npix * sizeof(float4)));
                     CHK(hipMemset(R.level_out[l], 0xFF, npix * sizeof(float4)));      // NaN: "never rendered"
                 }
-                if (L.queue_cap) CHK(hipMalloc(&R.queue[l], L.queue_cap * sizeof(uint32_t)));
             }
             if (cfg->speculative_levels) {
                 const uint32_t ns = cfg->speculative_levels;
                 R.spec_out.assign(ns, nullptr);
-                size_t cap = 0;
                 for (uint32_t l = 0; l < ns; l++) {
                     const Level& L = c->levels[l];
-                    cap += L.queue_cap;
                     if (l > 0) {
                         const size_t npix = (size_t)L.w * (size_t)L.h;
                         CHK(hipMalloc(&R.spec_out[l], npix * sizeof(float4)));
                         CHK(hipMemset(R.spec_out[l], 0xFF, npix * sizeof(float4)));
                     }
                 }
-                if (cap) CHK(hipMalloc(&R.spec_queue, cap * sizeof(uint32_t)));
             }
             if (cfg->flags & BHRAY_F_TEMPORAL) {
-                size_t cap = 0;
                 R.stamp.assign(nl, nullptr); R.need.assign(nl, nullptr);
                 for (uint32_t l = 0; l < nl; l++) {
                     const Level& L = c->levels[l];
-                    cap += L.queue_cap;
                     const size_t npix = (size_t)L.w * (size_t)L.h;
                     CHK(hipMalloc(&R.stamp[l], npix * sizeof(uint32_t)));
                     CHK(hipMemset(R.stamp[l], 0, npix * sizeof(uint32_t)));
                     CHK(hipMalloc(&R.need[l], npix));
                     CHK(hipMemset(R.need[l], 0, npix));
                 }
-                if (cap) CHK(hipMalloc(&R.pred_queue, cap * sizeof(uint32_t)));
                 static_assert(BHRAY_MAX_SPEC_LEVELS < BHRAY_MAX_LEVELS, "the predicted queue borrows the last level's control words");
                 R.pred_ctl = R.d_qctl + 2 * (BHRAY_MAX_LEVELS - 1);
-            }
-            if (cfg->superset_levels) {
-                size_t cap = 0;
-                for (uint32_t l = nl - cfg->superset_levels; l < nl; l++) cap += c->levels[l].queue_cap;
-                if (cap) CHK(hipMalloc(&R.super_queue, cap * sizeof(uint32_t)));
             }
             if (c->fz.on) {
                 const FusedTables& Z = c->fz;
@@ -688,13 +747,11 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
                 CHK(hipMalloc(&R.d_row_work, c->row_work_off[nl] * sizeof(unsigned long long)));
                 CHK(hipMemset(R.d_row_work, 0, c->row_work_off[nl] * sizeof(unsigned long long)));
             }
-            if (c->out_bytes && !opt.external_out) {
-                CHK(hipMalloc(&R.own_out, c->out_bytes));
-                CHK(hipMemset(R.own_out, 0xFF, c->out_bytes));
-            }
             R.out = R.own_out;
         }
     }
+    // ray queues and own output buffers of every frame, sized for the partition (grown by dev_set_partition when it changes)
+    { int rc_ = ensure_frame_buffers(c, false); if (rc_) { g_create_error = c->err; dev_destroy(c); return rc_; } }
     if (cfg->flags & (BHRAY_F_TIMING | BHRAY_F_TIMING_SPARSE)) {
         c->events.assign((size_t)BHRAY_TIMING_RING * (nl * 3 + 4), nullptr);
         for (auto& e : c->events) CHK(hipEventCreate(&e));
@@ -883,6 +940,30 @@ int dev_set_uniforms(bhray_dev* c, const void* cam32, const void* bh132, const v
     memcpy(&c->cam, cam32, 32); memcpy(&c->bh, bh132, 132); memcpy(&c->det, det32, 32);
     c->have_uniforms = true;
     return BHRAY_OK;
+}
+
+// Another row partition for this engine (bhray_set_partition): same frame, same ladder, other rows.  Everything enqueued so far is
+// waited for; the row tables are rewritten in place, the per-frame queues and output buffers grow if the new rows need more.  The level
+// images, textures, models and uniforms stay.  The temporal mode's per-pixel history stays too (rows that are new to this partition
+// have none: their first frame is the plain ladder's).
+int dev_set_partition(bhray_dev* c, uint32_t partition, uint32_t stripe_rows, const uint32_t* slab_row0, uint32_t row_rank, uint32_t row_world) {
+    if (!c) return BHRAY_E_INVALID;
+    if (c->cfg.flags & BHRAY_F_FUSED) return fail(c, BHRAY_E_STATE, "the partition of a BHRAY_F_FUSED ctx is fixed (its tile graph is built at bhray_create)");
+    bhray_config n = c->cfg;
+    n.partition = partition; n.row_rank = row_rank; n.row_world = row_world;
+    if (stripe_rows) n.stripe_rows = stripe_rows;
+    if (partition == BHRAY_PARTITION_SLABS) {
+        if (!slab_row0 || row_world > BHRAY_MAX_DEVICES) return fail(c, BHRAY_E_INVALID, "bad row partition");
+        for (uint32_t p = 0; p <= row_world; p++) n.slab_row0[p] = slab_row0[p];
+    }
+    if (row_world < 1 || row_rank >= row_world) return fail(c, BHRAY_E_INVALID, "bad row partition");
+    if (const char* why = partition_error(n, row_world)) return fail(c, BHRAY_E_INVALID, "bad row partition: %s", why);
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rc = launch_batch(c); if (rc) return rc; }
+    HIPCHK(c, sync_all(c));
+    c->cfg = n;
+    { int rc = build_row_tables(c); if (rc) return rc; }
+    return ensure_frame_buffers(c, true);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1561,6 +1642,11 @@ int dev_next_position(bhray_dev* c, int* slot, uint32_t* sub) {
     *slot = (int)(c->batch_counter % c->slots.size());
     *sub = c->slots[(size_t)*slot].pending;
     return BHRAY_OK;
+}
+
+void dev_peek_position(const bhray_dev* c, uint64_t* batch_counter, uint32_t* pending, int* method, bool* models) {
+    const Slot& S = c->slots[(size_t)(c->batch_counter % c->slots.size())];
+    *batch_counter = c->batch_counter; *pending = S.pending; *method = S.method; *models = S.models;
 }
 
 bool dev_take_launched(bhray_dev* c, int* slot, uint32_t* frames) {

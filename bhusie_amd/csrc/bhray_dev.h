@@ -44,6 +44,8 @@ std::vector<int32_t> coarse_rows_needed(const std::vector<int32_t>& fine, int h,
 struct DevOptions {
     bool external_out = false;   // the ctx binds every frame's destination (send buffer / assembled frame): no own output buffers
     bool frame_rowmap = false;   // the destination is a whole frame_h x frame_w frame: row r of the frame lands in row r (root partition of a gather)
+    uint32_t max_streams = 0;    // > 0: at most this many HIP streams for the frame slots (the slots beyond share them) - several engines on ONE physical GPU
+                                 // (functional tests of the multi-GPU path on a one-GPU box) must stay within the device's hardware queues TOGETHER
 };
 }  // namespace bhray
 
@@ -56,6 +58,8 @@ int  dev_upload_model_uniform(bhray_dev* c, uint32_t model_index, const void* by
 int  dev_upload_model(bhray_dev* c, uint32_t model_index, const bhray_model_desc* desc);
 int  dev_set_model_transform(bhray_dev* c, uint32_t model_index, const float position[3], int32_t visible);
 int  dev_set_uniforms(bhray_dev* c, const void* cam32, const void* bh132, const void* det32);
+// another row partition (bhray_config.partition / stripe_rows / slab_row0 / row_rank / row_world) for the same frame; synchronises the engine
+int  dev_set_partition(bhray_dev* c, uint32_t partition, uint32_t stripe_rows, const uint32_t* slab_row0, uint32_t row_rank, uint32_t row_world);
 int  dev_render(bhray_dev* c);
 int  dev_flush(bhray_dev* c);
 int  dev_sync(bhray_dev* c);
@@ -86,6 +90,9 @@ int  dev_device(const bhray_dev* c);
 // Position (slot, index in the batch) the next dev_render will stage its frame at.  A staged batch of another kernel variant
 // (integrator, mesh) than the current uniforms need is launched first, so the position is final.
 int  dev_next_position(bhray_dev* c, int* slot, uint32_t* sub);
+// The same state read without side effects: batches launched so far (the staging slot is that number modulo the slots), frames staged
+// in that slot and the kernel variant they were staged for.  For the caller's mirror of the staging position (issue threads).
+void dev_peek_position(const bhray_dev* c, uint64_t* batch_counter, uint32_t* pending, int* method, bool* models);
 // True when launches were enqueued since the last call; reports the slot and the number of frames of the (last) launched batch.
 bool dev_take_launched(bhray_dev* c, int* slot, uint32_t* frames);
 hipStream_t dev_slot_stream(bhray_dev* c, int slot);

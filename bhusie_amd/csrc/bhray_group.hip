@@ -19,6 +19,7 @@
 // one-GPU box: devices = {0,0,...}) share one RCCL rank and exchange their tiles as send/recv-to-self inside the same group
 // (RCCL refuses a communicator with a duplicated device; self send/recv inside a group is supported and matches in order).
 #include <dlfcn.h>
+#include <math.h>
 #include <rccl/rccl.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -26,9 +27,14 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bhray_dev.h"
@@ -52,6 +58,7 @@ struct Rccl {
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     int version = 0;
     std::string error;
@@ -75,7 +82,7 @@ Rccl* rccl() {
     } while (0)
     SYM(GetVersion, "ncclGetVersion"); SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitAll, "ncclCommInitAll");
     SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy"); SYM(GroupStart, "ncclGroupStart");
-    SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(GetErrorString, "ncclGetErrorString");
+    SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(AllGather, "ncclAllGather"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
     if (r.GetVersion(&r.version) != ncclSuccess) r.version = 0;
     g_rccl = r;
@@ -166,12 +173,50 @@ struct GroupSlot {                 // per batch slot (same index as the devices'
     bool timed = false;
 };
 
+// ------------------------------------------------------------------------------------------
+// Issue threads (one process, N GPUs).  The reference host is ONE thread (src/renderer/mod.rs:415-420); driving 8 engines from it
+// costs 80 us of host time per 1080p frame (8 x ~9 launches + events per batch, one RCCL group: profiles/r05_host_issue_n8.json)
+// against the 50 us a GPU needs for its eighth of the frame - the host would be the bottleneck.  So bhray_render of a multi-device
+// ctx only RECORDS the frame (uniform bytes, staging position, output binding) and hands it to one issue thread per GPU; each
+// thread stages the frame on its GPU's engines, enqueues the launches of a full batch and its own share of the gather (its sends;
+// on the root GPU the receives and the de-interleave) - the one-thread-per-device form of RCCL.  Every other call of the ABI first
+// waits until the threads are idle and then runs on the caller's thread as before, so the engines are only ever touched by one
+// thread at a time.  An error on an issue thread is reported by the next call of the ABI (and the ctx is failed).
+// BHRAY_ISSUE_THREADS=0 in the environment: the one-thread path of rounds 2-4.
+// ------------------------------------------------------------------------------------------
+struct RenderCmd {
+    uint8_t cam[32], bh[132], det[32];
+    float mpos[BHRAY_MAX_MODELS][3]; int32_t mvis[BHRAY_MAX_MODELS]; bool mset[BHRAY_MAX_MODELS];
+    int si; uint32_t sub;                  // where the caller's mirror of the staging position says this frame goes
+    float4* bound;                         // bhray_bind_output (root only)
+    uint64_t serial;                       // 1-based frame number
+};
+struct Worker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv, idle_cv;
+    std::deque<RenderCmd> q;
+    bool busy = false, stop = false;
+    int rc = 0; std::string err;           // first error of this thread
+    size_t rank_index = 0;                 // c->ranks[rank_index]
+};
+
 }  // namespace
 
 struct bhray_ctx {
     bhray_config cfg{};
     std::vector<Part> parts;
     std::vector<CommRank> ranks;           // local ranks
+    // issue threads (see above): one per local rank of a multi-device ctx
+    bool threaded = false;
+    std::vector<std::unique_ptr<Worker>> workers;
+    std::atomic<bool> async_failed{false};
+    int async_rc = 0;
+    // the caller's mirror of the engines' staging position (the engines themselves are only touched by their issue thread)
+    bool mirror_stale = true;
+    uint64_t st_counter = 0; uint32_t st_pending = 0; int st_method = 0; bool st_models = false;
+    uint8_t u_cam[32] = {0}, u_bh[132] = {0}, u_det[32] = {0}; bool have_uniforms = false;
+    float m_pos[BHRAY_MAX_MODELS][3] = {{0}}; int32_t m_vis[BHRAY_MAX_MODELS] = {0}; bool m_dirty[BHRAY_MAX_MODELS] = {false}, m_usable[BHRAY_MAX_MODELS] = {false};
     bool single = true;                    // one partition, no gather: every call goes straight to parts[0].dev
     bool gather = false;
     bool gather_sky = false;               // BHRAY_F_GATHER_SKY: the sky image is what travels
@@ -183,6 +228,15 @@ struct bhray_ctx {
     std::vector<GroupSlot> gslots;
     RowDesc* d_table = nullptr; uint32_t table_rows = 0;      // root GPU
     size_t staging_rows = 0;               // rows of one staging buffer (all non-root partitions, B frames)
+    size_t staging_alloc = 0, table_alloc = 0;                 // rows / entries allocated (grown by bhray_set_partition)
+    std::vector<size_t> send_alloc;        // per partition: rows (x B frames) its send buffers hold
+    // bhray_rebalance: what the frame rows cost, as far as the partitions' measured times tell (one weight per frame row; the bounds that
+    // equalise their sums are the next partition), and the root's extra work per frame (gather + de-interleave) in the same unit
+    std::vector<double> row_weight;
+    double root_extra_ms = 0.0;
+    uint32_t rebalances = 0, repartitions = 0;
+    double hole_row = 0.0, hole_row_prev = 0.0; bool hole_row_valid = false, hole_row_prev_valid = false;   // frame row the hole projects to: at the last render / at the last rebalance
+    float* d_xchg = nullptr;               // one process per GPU: 2 + 2 * partitions floats on this rank's GPU (the all-gather of bhray_rebalance)
     float4* bound = nullptr;               // bhray_bind_output: destination of the next frame (one-shot)
     hipEvent_t read_ev[64] = {nullptr};
     uint64_t read_tickets = 0;
@@ -198,14 +252,16 @@ struct bhray_ctx {
 
 namespace {
 
+// bhray_ctx::err belongs to the caller's thread; an issue thread collects its message in its own string (worker_main)
+thread_local std::string* tl_err = nullptr;
 int gfail(bhray_ctx* c, int code, const char* fmt, ...) {
     char buf[640];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
-    if (c) c->err = buf; else dev_set_create_error(buf);
+    if (tl_err) *tl_err = buf; else if (c) c->err = buf; else dev_set_create_error(buf);
     return code;
 }
 // error of a per-device call: carry the device's message
-int dfail(bhray_ctx* c, const bhray_dev* d, int rc) { if (rc) c->err = dev_last_error(d); return rc; }
+int dfail(bhray_ctx* c, const bhray_dev* d, int rc) { if (rc) { if (tl_err) *tl_err = dev_last_error(d); else c->err = dev_last_error(d); } return rc; }
 
 #define GHIP(c, call)                                                                                  \
     do {                                                                                               \
@@ -227,28 +283,31 @@ CommRank* rank_of(bhray_ctx* c, const Part& p) {
 size_t frame_pixels(const bhray_ctx* c) { return (size_t)c->cfg.frame_w * (size_t)c->cfg.frame_h; }
 
 // Gather of one launched batch (nb frames staged in slot si): sends, receives, de-interleave; see the file header.
-int group_gather(bhray_ctx* c, int si, uint32_t nb) {
+// only == nullptr: every local rank's share in ONE RCCL group (the caller's thread drives all GPUs: grouped, so that no call waits for
+// a peer this thread has not called yet); only != nullptr: the share of that rank alone, in a group of its own (its issue thread).
+int group_gather(bhray_ctx* c, int si, uint32_t nb, const CommRank* only = nullptr) {
     Rccl* R = rccl();
     if (!R) return gfail(c, BHRAY_E_COMM, "%s", g_rccl.error.c_str());
     if (c->failed) return gfail(c, BHRAY_E_COMM, "an earlier gather of this ctx failed inside its RCCL group; destroy the ctx");
     GroupSlot& G = c->gslots[(size_t)si];
     const size_t W = c->cfg.frame_w;
     const bool timing = (c->cfg.flags & (BHRAY_F_TIMING | BHRAY_F_TIMING_SPARSE)) != 0;
+    auto mine = [&](const Part& p) { return p.dev && (!only || p.rank == only->rank); };
     // the communication stream of every local rank waits for the renders whose rows it moves
     for (Part& p : c->parts) {
-        if (!p.dev) continue;
+        if (!mine(p)) continue;
         CommRank* cr = rank_of(c, p);
         GHIP(c, hipSetDevice(p.device));
         GHIP(c, hipStreamWaitEvent(cr->stream, dev_slot_done(p.dev, si), 0));
     }
     Part& rp = *root_part(c);
-    CommRank* rr = c->root_local ? rank_of(c, rp) : nullptr;
+    CommRank* rr = (c->root_local && mine(rp)) ? rank_of(c, rp) : nullptr;
     if (c->gather_sky) {
         // every partition resolves the sky over its own rows (sky.wgsl is per pixel) behind its render, on its communication stream: the
         // other partitions into their 8-byte send buffers, the root from its rows of the RGBA32F frames straight into the sky images
         for (uint32_t q = 0; q < c->world; q++) {
             Part& p = c->parts[q];
-            if (!p.dev || p.rows == 0) continue;
+            if (!mine(p) || p.rows == 0) continue;
             CommRank* cr = rank_of(c, p);
             if (q != c->root) {
                 DEV(c, p.dev, dev_launch_sky(p.dev, G.send[q], G.send16[q], (size_t)nb * p.rows * W, cr->stream));
@@ -277,7 +336,7 @@ int group_gather(bhray_ctx* c, int si, uint32_t nb) {
         auto in_group = [&]() -> int {
             for (uint32_t q = 0; q < c->world; q++) {
                 Part& p = c->parts[q];
-                if (q == c->root || !p.dev || p.rows == 0) continue;
+                if (q == c->root || !mine(p) || p.rows == 0) continue;
                 CommRank* cr = rank_of(c, p);
                 GHIP(c, hipSetDevice(p.device));
                 GNCCL(c, R, R->Send(c->gather_sky ? (const void*)G.send16[q] : (const void*)G.send[q], (size_t)nb * p.rows * W * words, ncclFloat32, rp.rank, cr->comm, cr->stream));
@@ -300,7 +359,7 @@ int group_gather(bhray_ctx* c, int si, uint32_t nb) {
     // a slot's next batch may overwrite its send buffer only after the send has read it
     for (uint32_t q = 0; q < c->world; q++) {
         Part& p = c->parts[q];
-        if (q == c->root || !p.dev) continue;
+        if (q == c->root || !mine(p)) continue;
         CommRank* cr = rank_of(c, p);
         GHIP(c, hipSetDevice(p.device));
         GHIP(c, hipEventRecord(G.sent[q], cr->stream));
@@ -327,28 +386,32 @@ int group_gather(bhray_ctx* c, int si, uint32_t nb) {
         GHIP(c, hipEventRecord(G.frame_done, rr->stream));
         // the root's next render into this slot writes its own rows into the frames the de-interleave is filling: keep them ordered
         GHIP(c, hipStreamWaitEvent(dev_slot_stream(rp.dev, si), G.frame_done, 0));
+        c->gathers++;
+    } else if (!c->root_local && !only) {
+        c->gathers++;
     }
-    c->gathers++;
     return BHRAY_OK;
 }
 
-// after a call that may have launched a batch on every local partition: enqueue its gather
-int after_launch(bhray_ctx* c) {
-    int slot = -1; uint32_t nb = 0; bool any = false;
+// after a call that may have launched a batch on every local partition (only != nullptr: on that rank's partitions): enqueue its gather
+int after_launch(bhray_ctx* c, const CommRank* only = nullptr) {
+    int slot = -1; uint32_t nb = 0; bool any = false, first = true;
     for (Part& p : c->parts) {
-        if (!p.dev) continue;
+        if (!p.dev || (only && p.rank != only->rank)) continue;
         int s; uint32_t n;
         if (dev_take_launched(p.dev, &s, &n)) {
-            if (any && (s != slot || n != nb)) return gfail(c, BHRAY_E_STATE, "internal: partitions out of step");
+            if (!first && (!any || s != slot || n != nb)) return gfail(c, BHRAY_E_STATE, "internal: partitions out of step");
             slot = s; nb = n; any = true;
         } else if (any) {
             return gfail(c, BHRAY_E_STATE, "internal: partitions out of step");
         }
+        first = false;
     }
     if (!any) return BHRAY_OK;
     // timing of an earlier gather held by this slot is folded in before its events are re-recorded
     GroupSlot& G = c->gslots[(size_t)slot];
-    if (G.timed && c->root_local) {
+    const bool root_here = c->root_local && (!only || root_part(c)->rank == only->rank);
+    if (G.timed && root_here) {
         CommRank* rr = rank_of(c, *root_part(c));
         GHIP(c, hipSetDevice(rr->device));
         GHIP(c, hipEventSynchronize(G.tev[2]));
@@ -356,7 +419,7 @@ int after_launch(bhray_ctx* c) {
         GHIP(c, hipEventElapsedTime(&a, G.tev[0], G.tev[1])); GHIP(c, hipEventElapsedTime(&b, G.tev[1], G.tev[2]));
         c->gather_ms += a; c->deint_ms += b; G.timed = false;
     }
-    return group_gather(c, slot, nb);
+    return group_gather(c, slot, nb, only);
 }
 
 int group_flush(bhray_ctx* c) {
@@ -403,27 +466,190 @@ void group_free(bhray_ctx* c) {
         if (r.stream) (void)hipStreamDestroy(r.stream);
     }
     for (auto& e : c->read_ev) if (e) (void)hipEventDestroy(e);
+    if (c->d_xchg && !c->ranks.empty()) { (void)hipSetDevice(c->ranks[0].device); (void)hipFree(c->d_xchg); }
     for (size_t i = 0; i + 1 < c->external.size(); i += 2) if (c->external[i + 1]) (void)hipDestroyExternalMemory((hipExternalMemory_t)c->external[i + 1]);
     for (WaitEvent& w : c->wait_pool) if (w.ev) { (void)hipSetDevice(w.device); (void)hipEventDestroy(w.ev); }
 }
 
-// destination of the frame about to be staged at (slot, sub): every local partition's output binding
-int bind_partitions(bhray_ctx* c, int si, uint32_t sub) {
+// destination of the frame about to be staged at (slot, sub): every local partition's output binding (only != nullptr: that rank's
+// partitions; `bound` = the caller's one-shot binding of the frame, root only)
+int bind_partitions(bhray_ctx* c, int si, uint32_t sub, float4* bound, uint64_t serial, const CommRank* only = nullptr) {
     GroupSlot& G = c->gslots[(size_t)si];
     const size_t W = c->cfg.frame_w;
     for (uint32_t q = 0; q < c->world; q++) {
         Part& p = c->parts[q];
-        if (!p.dev) continue;
+        if (!p.dev || (only && p.rank != only->rank)) continue;
         if (q == c->root) {
-            float4* dst = c->bound ? c->bound : G.frames + (size_t)sub * frame_pixels(c);
+            float4* dst = bound ? bound : G.frames + (size_t)sub * frame_pixels(c);
             G.dst[sub] = dst;
+            G.frame_no[sub] = serial;
             DEV(c, p.dev, dev_bind_output(p.dev, dst, frame_pixels(c) * sizeof(float4)));
         } else if (p.rows) {
             DEV(c, p.dev, dev_bind_output(p.dev, G.send[q] + (size_t)sub * p.rows * W, (size_t)p.rows * W * sizeof(float4)));
         }
     }
-    c->bound = nullptr;
     return BHRAY_OK;
+}
+
+// Where every partition's tiles land on the root, the de-interleave table, and the send / staging buffers - for the partition the
+// ctx holds now.  Called by bhray_create and, with `headroom`, by bhray_set_partition (everything idle): buffers only ever grow.
+int layout_gather(bhray_ctx* c, bool headroom) {
+    const size_t W = c->cfg.frame_w;
+    size_t row0 = 0;
+    std::vector<RowDesc> table;
+    for (uint32_t q = 0; q < c->world; q++) {
+        Part& p = c->parts[q];
+        if (q == c->root) continue;
+        p.stage_row0 = row0;
+        for (uint32_t i = 0; i < p.rows; i++) {
+            RowDesc d; d.src_row0 = (uint32_t)(row0 + i); d.part_rows = p.rows; d.frame_row = p.row_list[i]; d.pad = 0;
+            table.push_back(d);
+        }
+        row0 += (size_t)c->B * p.rows;
+    }
+    c->staging_rows = row0;
+    if (c->send_alloc.size() != c->world) c->send_alloc.assign(c->world, 0);
+    auto grown = [&](size_t need, size_t cap) { size_t n = headroom ? need + need / 4 + 8 : need; return n > cap ? std::max(cap, need) : n; };
+    for (uint32_t q = 0; q < c->world; q++) {
+        Part& p = c->parts[q];
+        if (!p.dev || q == c->root || p.rows <= c->send_alloc[q]) continue;
+        const size_t rows = grown(p.rows, c->cfg.frame_h);
+        GHIP(c, hipSetDevice(p.device));
+        for (GroupSlot& G : c->gslots) {
+            if (G.send[q]) { GHIP(c, hipFree(G.send[q])); G.send[q] = nullptr; }
+            GHIP(c, hipMalloc(&G.send[q], (size_t)c->B * rows * W * sizeof(float4)));
+            GHIP(c, hipMemset(G.send[q], 0xFF, (size_t)c->B * rows * W * sizeof(float4)));
+            if (c->gather_sky) {
+                if (G.send16[q]) { GHIP(c, hipFree(G.send16[q])); G.send16[q] = nullptr; }
+                GHIP(c, hipMalloc(&G.send16[q], (size_t)c->B * rows * W * sizeof(uint2)));
+            }
+        }
+        c->send_alloc[q] = rows;
+    }
+    if (c->root_local) {
+        GHIP(c, hipSetDevice(c->parts[c->root].device));
+        if (c->staging_rows > c->staging_alloc) {
+            const size_t rows = grown(c->staging_rows, (size_t)c->B * c->cfg.frame_h);
+            for (GroupSlot& G : c->gslots) {
+                if (!c->gather_sky) { if (G.staging) { GHIP(c, hipFree(G.staging)); G.staging = nullptr; } GHIP(c, hipMalloc(&G.staging, rows * W * sizeof(float4))); }
+                else { if (G.staging16) { GHIP(c, hipFree(G.staging16)); G.staging16 = nullptr; } GHIP(c, hipMalloc(&G.staging16, rows * W * sizeof(uint2))); }
+            }
+            c->staging_alloc = rows;
+        }
+        c->table_rows = (uint32_t)table.size();
+        if (table.size() > c->table_alloc) {
+            if (c->d_table) { GHIP(c, hipFree(c->d_table)); c->d_table = nullptr; }
+            GHIP(c, hipMalloc(&c->d_table, (size_t)c->cfg.frame_h * sizeof(RowDesc)));      // never more rows than the frame has
+            c->table_alloc = c->cfg.frame_h;
+        }
+        if (!table.empty()) GHIP(c, hipMemcpy(c->d_table, table.data(), table.size() * sizeof(RowDesc), hipMemcpyHostToDevice));
+    }
+    return BHRAY_OK;
+}
+
+// ---- issue threads ---------------------------------------------------------------------------
+// One recorded frame on one rank's engines: uniforms, the staging position (checked against the caller's mirror), the gather of a
+// batch that a change of kernel variant launched, the output bindings, the render, the gather of the batch it completed.
+int worker_render(bhray_ctx* c, const CommRank* cr, const RenderCmd& cmd) {
+    for (Part& p : c->parts) {
+        if (!p.dev || p.rank != cr->rank) continue;
+        DEV(c, p.dev, dev_set_uniforms(p.dev, cmd.cam, cmd.bh, cmd.det));
+        for (uint32_t mi = 0; mi < BHRAY_MAX_MODELS; mi++) if (cmd.mset[mi]) DEV(c, p.dev, dev_set_model_transform(p.dev, mi, cmd.mpos[mi], cmd.mvis[mi]));
+        int s; uint32_t k;
+        DEV(c, p.dev, dev_next_position(p.dev, &s, &k));
+        if (s != cmd.si || k != cmd.sub) return gfail(c, BHRAY_E_STATE, "internal: issue thread out of step with the caller (slot %d/%d, position %u/%u)", s, cmd.si, k, cmd.sub);
+    }
+    { int rc = after_launch(c, cr); if (rc) return rc; }
+    { int rc = bind_partitions(c, cmd.si, cmd.sub, cmd.bound, cmd.serial, cr); if (rc) return rc; }
+    for (Part& p : c->parts) if (p.dev && p.rank == cr->rank) DEV(c, p.dev, dev_render(p.dev));
+    return after_launch(c, cr);
+}
+
+void worker_main(bhray_ctx* c, Worker* w) {
+    const CommRank* cr = &c->ranks[w->rank_index];
+    (void)hipSetDevice(cr->device);
+    std::unique_lock<std::mutex> lk(w->m);
+    for (;;) {
+        w->cv.wait(lk, [&] { return w->stop || !w->q.empty(); });
+        if (w->q.empty()) { if (w->stop) return; continue; }
+        const RenderCmd cmd = w->q.front();
+        w->q.pop_front();
+        w->busy = true;
+        lk.unlock();
+        int rc = BHRAY_OK; std::string msg;
+        tl_err = &msg;                 // gfail / dfail of this thread write here
+        if (!c->async_failed.load(std::memory_order_acquire)) rc = worker_render(c, cr, cmd);
+        lk.lock();
+        if (rc != BHRAY_OK && w->rc == BHRAY_OK) { w->rc = rc; w->err = msg; c->async_failed.store(true, std::memory_order_release); }
+        w->busy = false;
+        w->idle_cv.notify_all();
+        w->cv.notify_all();          // (a caller waiting for room in the queue)
+    }
+}
+
+// wait until every issue thread is idle; then report the first error any of them met (sticky: the ctx is failed)
+int drain(bhray_ctx* c) {
+    if (!c->threaded) return BHRAY_OK;
+    for (auto& w : c->workers) {
+        std::unique_lock<std::mutex> lk(w->m);
+        w->idle_cv.wait(lk, [&] { return w->q.empty() && !w->busy; });
+    }
+    c->mirror_stale = true;          // whatever the caller does next on its own thread may launch staged frames
+    if (c->async_failed.load(std::memory_order_acquire)) {
+        for (auto& w : c->workers) {
+            std::lock_guard<std::mutex> lk(w->m);
+            if (w->rc != BHRAY_OK) { c->err = "issue thread of GPU " + std::to_string(c->ranks[w->rank_index].device) + ": " + w->err; c->async_rc = w->rc; break; }
+        }
+        c->failed = true;
+        return c->async_rc ? c->async_rc : BHRAY_E_STATE;
+    }
+    return BHRAY_OK;
+}
+#define ENTER(c) do { if ((c)->threaded) { int rc_ = drain(c); if (rc_) return rc_; } } while (0)
+
+void stop_workers(bhray_ctx* c) {
+    for (auto& w : c->workers) {
+        { std::lock_guard<std::mutex> lk(w->m); w->stop = true; }
+        w->cv.notify_all();
+        if (w->th.joinable()) w->th.join();
+    }
+    c->workers.clear();
+    c->threaded = false;
+}
+
+// Frame row the hole projects to (create_ray, ray.wgsl:269-285, inverted; plain float arithmetic: a heuristic for bhray_rebalance, not pixels)
+void track_hole_row(bhray_ctx* c, const void* cam32, const void* bh132) {
+    bhray_camera_uniform cam; bhray_black_hole_uniform bh;
+    memcpy(&cam, cam32, sizeof cam); memcpy(&bh, bh132, sizeof bh);
+    const double f[3] = {cam.forward[0], cam.forward[1], cam.forward[2]};
+    // right = normalize(forward x (0,-1,0)), up = normalize(forward x right)
+    double r[3] = {f[1] * 0.0 - f[2] * -1.0, f[2] * 0.0 - f[0] * 0.0, f[0] * -1.0 - f[1] * 0.0};
+    const double rl = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (!(rl > 0.0)) { c->hole_row_valid = false; return; }
+    for (double& v : r) v /= rl;
+    double u[3] = {f[1] * r[2] - f[2] * r[1], f[2] * r[0] - f[0] * r[2], f[0] * r[1] - f[1] * r[0]};
+    const double ul = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    if (!(ul > 0.0)) { c->hole_row_valid = false; return; }
+    for (double& v : u) v /= ul;
+    const double ff = 1.0 / tan(0.5 * (double)cam.fov);
+    const double d[3] = {bh.position[0] - cam.position[0], bh.position[1] - cam.position[1], bh.position[2] - cam.position[2]};
+    const double along = (d[0] * f[0] + d[1] * f[1] + d[2] * f[2]) / ((f[0] * f[0] + f[1] * f[1] + f[2] * f[2]) * ff);   // d = along * (posx right + posy up + forward ff)
+    if (!(along > 0.0)) { c->hole_row_valid = false; return; }
+    const double posy = (d[0] * u[0] + d[1] * u[1] + d[2] * u[2]) / along;
+    const uint32_t nl = c->cfg.levels;
+    const double lw = c->cfg.level_w[nl - 1], lh = c->cfg.level_h[nl - 1];
+    const double sm = std::min(lw - 1.0, lh - 1.0);
+    c->hole_row = posy * sm * 0.5 + (lh - 1.0) * 0.5 - (double)c->cfg.crop_y;
+    c->hole_row_valid = c->hole_row == c->hole_row;
+}
+
+// kernel variant of the frame the current uniforms describe (the rule of the engines: bhray_api.hip frame_variant)
+void ctx_variant(const bhray_ctx* c, int& method, bool& models) {
+    bhray_details d; memcpy(&d, c->u_det, sizeof d);
+    method = d.integration_method != 0 ? 1 : 0;
+    int mc = d.model_count; if (mc < 0) mc = 0; if (mc > BHRAY_MAX_MODELS) mc = BHRAY_MAX_MODELS;
+    models = false;
+    for (int i = 0; i < mc; i++) if (c->m_usable[i] && c->m_vis[i] != 0) models = true;
 }
 
 }  // namespace
@@ -551,6 +777,7 @@ const char* bhray_last_error(const bhray_ctx* c) { return c ? c->err.c_str() : d
 
 void bhray_destroy(bhray_ctx* c) {
     if (!c) return;
+    stop_workers(c);                 // (the issue threads finish what they hold first)
     group_free(c);
     delete c;
 }
@@ -639,6 +866,12 @@ int bhray_create(const bhray_config* cfg_in, bhray_ctx** out) {
         one.device = p.device; one.device_count = 0; one.gather = BHRAY_GATHER_NONE;
         one.row_rank = q; one.row_world = c->world; one.stripe_rows = stripe;
         DevOptions opt; opt.external_out = true; opt.frame_rowmap = (q == c->root);
+        // Partitions that share a physical GPU (a one-GPU box standing in for N) share its hardware queues: beyond ~24 user queues the
+        // device's scheduler serves them a few at a time, milliseconds apart (8 engines x 6 streams: a 20-frame block 44 ms, x 2 streams:
+        // 14 ms = the sum of the rank probes; profiles/EXPERIMENTS.md R5.1), so their frame slots together get 22 streams.
+        uint32_t same_dev = 0;
+        for (uint32_t k = 0; k < c->world; k++) if (c->parts[k].device == p.device) same_dev++;
+        if (same_dev > 1) opt.max_streams = std::max(1u, 22u / same_dev);
         int rc = dev_create(&one, opt, &p.dev);
         if (rc) { bhray_destroy(c); return rc; }
         if (dev_local_rows(p.dev) != p.rows) FAIL(BHRAY_E_STATE, "internal: partition %u has %u rows, expected %u", q, dev_local_rows(p.dev), p.rows);
@@ -662,20 +895,6 @@ int bhray_create(const bhray_config* cfg_in, bhray_ctx** out) {
     }
     for (CommRank& r : c->ranks) { CH(hipSetDevice(r.device)); CH(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking)); }
     // ---- buffers
-    const size_t W = cfg->frame_w;
-    size_t row0 = 0;
-    std::vector<RowDesc> table;
-    for (uint32_t q = 0; q < c->world; q++) {
-        Part& p = c->parts[q];
-        if (q == c->root) continue;
-        p.stage_row0 = row0;
-        for (uint32_t i = 0; i < p.rows; i++) {
-            RowDesc d; d.src_row0 = (uint32_t)(row0 + i); d.part_rows = p.rows; d.frame_row = p.row_list[i]; d.pad = 0;
-            table.push_back(d);
-        }
-        row0 += (size_t)c->B * p.rows;
-    }
-    c->staging_rows = row0;
     c->gslots.resize(c->nslots);
     for (GroupSlot& G : c->gslots) {
         memset(G.dst, 0, sizeof G.dst); memset(G.sky, 0, sizeof G.sky);
@@ -684,35 +903,240 @@ int bhray_create(const bhray_config* cfg_in, bhray_ctx** out) {
             Part& p = c->parts[q];
             if (!p.dev || q == c->root) continue;
             CH(hipSetDevice(p.device));
-            if (p.rows) { CH(hipMalloc(&G.send[q], (size_t)c->B * p.rows * W * sizeof(float4))); CH(hipMemset(G.send[q], 0xFF, (size_t)c->B * p.rows * W * sizeof(float4))); }
-            if (p.rows && c->gather_sky) CH(hipMalloc(&G.send16[q], (size_t)c->B * p.rows * W * sizeof(uint2)));
             CH(hipEventCreateWithFlags(&G.sent[q], hipEventDisableTiming));
         }
         if (c->root_local) {
             CH(hipSetDevice(c->parts[c->root].device));
             CH(hipMalloc(&G.frames, (size_t)c->B * frame_pixels(c) * sizeof(float4)));
             CH(hipMemset(G.frames, 0xFF, (size_t)c->B * frame_pixels(c) * sizeof(float4)));
-            if (c->staging_rows && !c->gather_sky) CH(hipMalloc(&G.staging, c->staging_rows * W * sizeof(float4)));
-            if (c->gather_sky) {
-                if (c->staging_rows) CH(hipMalloc(&G.staging16, c->staging_rows * W * sizeof(uint2)));
+            if (c->gather_sky)
                 for (uint32_t k = 0; k < c->B; k++) { CH(hipMalloc(&G.sky[k], frame_pixels(c) * sizeof(uint2))); CH(hipMemset(G.sky[k], 0xFF, frame_pixels(c) * sizeof(uint2))); }
-            }
             CH(hipEventCreateWithFlags(&G.frame_done, hipEventDisableTiming));
             if (cfg->flags & (BHRAY_F_TIMING | BHRAY_F_TIMING_SPARSE)) for (auto& e : G.tev) CH(hipEventCreate(&e));
         }
     }
-    if (c->root_local) {
-        CH(hipSetDevice(c->parts[c->root].device));
-        c->table_rows = (uint32_t)table.size();
-        if (!table.empty()) {
-            CH(hipMalloc(&c->d_table, table.size() * sizeof(RowDesc)));
-            CH(hipMemcpy(c->d_table, table.data(), table.size() * sizeof(RowDesc), hipMemcpyHostToDevice));
-        }
-    }
+    // send buffers, staging, the de-interleave table: for the partition of the config (bhray_set_partition lays them out again)
+    { int rc_ = layout_gather(c, false); if (rc_) { dev_set_create_error(c->err.c_str()); bhray_destroy(c); return rc_; } }
 #undef CH
 #undef CN
 #undef FAIL
+    // one process, N GPUs: one issue thread per GPU (see "Issue threads" above)
+    {
+        const char* e = getenv("BHRAY_ISSUE_THREADS");
+        if (multi_dev && !(e && atoi(e) == 0)) {
+            for (size_t k = 0; k < c->ranks.size(); k++) {
+                std::unique_ptr<Worker> w(new (std::nothrow) Worker());
+                if (!w) { bhray_destroy(c); return gfail(nullptr, BHRAY_E_NOMEM, "host allocation failed"); }
+                w->rank_index = k;
+                c->workers.push_back(std::move(w));
+            }
+            c->threaded = true;
+            for (auto& w : c->workers) w->th = std::thread(worker_main, c, w.get());
+        }
+    }
     *out = c;
+    return BHRAY_OK;
+}
+
+// ---- run-time partition ---------------------------------------------------------------------------
+int bhray_get_partition(const bhray_ctx* c, uint32_t* slab_row0, uint32_t* partitions) {
+    if (!c || !slab_row0) return BHRAY_E_INVALID;
+    if (partitions) *partitions = c->world;
+    if (c->world > 1 && c->cfg.partition != BHRAY_PARTITION_SLABS) return BHRAY_E_STATE;
+    if (c->world <= 1) { slab_row0[0] = 0; slab_row0[1] = c->cfg.frame_h; return BHRAY_OK; }
+    for (uint32_t p = 0; p <= c->world; p++) slab_row0[p] = c->cfg.slab_row0[p];
+    return BHRAY_OK;
+}
+
+int bhray_set_partition(bhray_ctx* c, const uint32_t* slab_row0) {
+    if (!c || !slab_row0) return BHRAY_E_INVALID;
+    ENTER(c);
+    if (c->world > BHRAY_MAX_DEVICES) return gfail(c, BHRAY_E_INVALID, "more partitions than slab_row0 holds");
+    if (c->cfg.flags & BHRAY_F_FUSED) return gfail(c, BHRAY_E_STATE, "the partition of a BHRAY_F_FUSED ctx is fixed (its tile graph is built at bhray_create)");
+    bhray_config n = c->cfg;
+    n.partition = BHRAY_PARTITION_SLABS;
+    for (uint32_t p = 0; p <= c->world; p++) n.slab_row0[p] = slab_row0[p];
+    if (const char* why = partition_error(n, c->world)) return gfail(c, BHRAY_E_INVALID, "bad row partition: %s", why);
+    if (c->single) {
+        bhray_dev* d = c->parts[0].dev;
+        DEV(c, d, dev_set_partition(d, BHRAY_PARTITION_SLABS, 0, n.slab_row0, c->cfg.row_rank, c->world));
+        c->cfg = n;
+        c->repartitions++;
+        return BHRAY_OK;
+    }
+    { int rc = group_sync(c); if (rc) return rc; }          // nothing in flight reads the tables that are rewritten below
+    c->cfg = n;
+    for (uint32_t q = 0; q < c->world; q++) {
+        Part& p = c->parts[q];
+        p.row_list = partition_row_list(c->cfg, c->world, q);
+        p.rows = (uint32_t)p.row_list.size();
+        if (!p.dev) continue;
+        DEV(c, p.dev, dev_set_partition(p.dev, BHRAY_PARTITION_SLABS, 0, n.slab_row0, q, c->world));
+        if (dev_local_rows(p.dev) != p.rows) return gfail(c, BHRAY_E_STATE, "internal: partition %u has %u rows, expected %u", q, dev_local_rows(p.dev), p.rows);
+    }
+    { int rc = layout_gather(c, true); if (rc) return rc; }
+    // a sky image resolved for a frame of the old partition stays valid (it is a whole-frame image on the root); nothing else is cached
+    c->repartitions++;
+    return BHRAY_OK;
+}
+
+int bhray_rebalance_slabs(uint32_t H, uint32_t world, const uint32_t* b_in, const double* part_ms, const double* extra_ms,
+                          double shift_rows, double* w, uint32_t* b_out, double* slowest_predicted) {
+    if (!b_in || !part_ms || !w || !b_out || H < 1 || world < 1 || world > BHRAY_MAX_DEVICES) return BHRAY_E_INVALID;
+    if (b_in[0] != 0 || b_in[world] != H) return BHRAY_E_INVALID;
+    for (uint32_t p = 0; p < world; p++) if (b_in[p] > b_in[p + 1] || !(part_ms[p] >= 0.0) || (extra_ms && !(extra_ms[p] >= 0.0))) return BHRAY_E_INVALID;
+    bool any = false;
+    for (uint32_t r = 0; r < H; r++) { if (!(w[r] >= 0.0)) return BHRAY_E_INVALID; any = any || w[r] > 0.0; }
+    if (!any) for (uint32_t r = 0; r < H; r++) w[r] = 1.0;
+    // (1) what was measured: the rows of partition p cost part_ms[p] together
+    for (uint32_t p = 0; p < world; p++) {
+        const uint32_t a = b_in[p], b = b_in[p + 1];
+        if (b <= a || !(part_ms[p] > 0.0)) continue;
+        double sum = 0.0;
+        for (uint32_t r = a; r < b; r++) sum += w[r];
+        if (!(sum > 0.0)) { for (uint32_t r = a; r < b; r++) w[r] = part_ms[p] / (double)(b - a); continue; }
+        const double f = part_ms[p] / sum;
+        for (uint32_t r = a; r < b; r++) w[r] *= f;
+    }
+    // (1b) the scene moves: what was learned about row r is expected at row r + shift_rows in the frames to come (the rows the hole and
+    // the disk project to travel with the camera's pitch); linear interpolation, the frame's edge rows repeat
+    if (shift_rows == shift_rows && shift_rows != 0.0 && fabs(shift_rows) < (double)H) {
+        std::vector<double> old(w, w + H);
+        for (uint32_t r = 0; r < H; r++) {
+            double src = (double)r - shift_rows;
+            if (src < 0.0) src = 0.0;
+            if (src > (double)(H - 1)) src = (double)(H - 1);
+            const uint32_t i0 = (uint32_t)src, i1 = i0 + 1 < H ? i0 + 1 : i0;
+            const double t = src - (double)i0;
+            w[r] = old[i0] * (1.0 - t) + old[i1] * t;
+        }
+    }
+    // rows nobody measured (an empty partition's neighbours own them: none are left out) keep their weight; a row must cost something
+    double total = 0.0;
+    for (uint32_t r = 0; r < H; r++) total += w[r];
+    if (!(total > 0.0)) return BHRAY_E_INVALID;
+    const double floor_w = 1e-6 * total / (double)H;
+    std::vector<double> pre((size_t)H + 1, 0.0);
+    for (uint32_t r = 0; r < H; r++) pre[r + 1] = pre[r] + (w[r] > floor_w ? w[r] : floor_w);
+    auto ex = [&](uint32_t p) { return extra_ms ? extra_ms[p] : 0.0; };
+    // (2) bounds that minimise the largest (rows' weight + extra): bisection on the load, greedy packing decides feasibility
+    auto pack = [&](double cap, uint32_t* bounds) -> bool {
+        uint32_t a = 0;
+        for (uint32_t p = 0; p < world; p++) {
+            if (bounds) bounds[p] = a;
+            const double budget = cap - ex(p);
+            if (a < H && budget > 0.0) {
+                uint32_t lo = a, hi = H;                          // largest b with pre[b] - pre[a] <= budget
+                while (lo < hi) { const uint32_t mid = lo + (hi - lo + 1) / 2; if (pre[mid] - pre[a] <= budget) lo = mid; else hi = mid - 1; }
+                a = lo;
+            }
+        }
+        if (bounds) bounds[world] = H;
+        return a >= H;
+    };
+    double lo = 0.0, hi = pre[H];
+    for (uint32_t p = 0; p < world; p++) hi += ex(p);
+    for (int it = 0; it < 80 && hi - lo > 1e-12 * hi; it++) { const double mid = 0.5 * (lo + hi); if (pack(mid, nullptr)) hi = mid; else lo = mid; }
+    if (!pack(hi, b_out)) return BHRAY_E_STATE;
+    // the greedy packing front-loads: even out neighbours (never beyond the cap found above)
+    auto load = [&](uint32_t p, uint32_t a, uint32_t b) { return pre[b] - pre[a] + ex(p); };
+    for (int round = 0; round < 8; round++) {
+        for (uint32_t p = 1; p < world; p++) {
+            const uint32_t a = b_out[p - 1], b = b_out[p + 1];
+            if (b <= a) continue;
+            uint32_t best = b_out[p]; double bestv = std::max(load(p - 1, a, best), load(p, best, b));
+            uint32_t l2 = a, h2 = b;
+            while (l2 < h2) { const uint32_t mid = l2 + (h2 - l2) / 2; if (load(p - 1, a, mid) < load(p, mid, b)) l2 = mid + 1; else h2 = mid; }
+            for (uint32_t m = (l2 > a ? l2 - 1 : l2); m <= l2 && m <= b; m++) {
+                const double v = std::max(load(p - 1, a, m), load(p, m, b));
+                if (v < bestv) { bestv = v; best = m; }
+            }
+            b_out[p] = best;
+        }
+    }
+    if (slowest_predicted) {
+        double mx = 0.0;
+        for (uint32_t p = 0; p < world; p++) mx = std::max(mx, load(p, b_out[p], b_out[p + 1]));
+        *slowest_predicted = mx;
+    }
+    return BHRAY_OK;
+}
+
+int bhray_rebalance(bhray_ctx* c, bhray_rebalance_info* out) {
+    if (!c) return BHRAY_E_INVALID;
+    ENTER(c);
+    if (out) memset(out, 0, sizeof *out);
+    if (!(c->cfg.flags & (BHRAY_F_TIMING | BHRAY_F_TIMING_SPARSE))) return gfail(c, BHRAY_E_STATE, "bhray_rebalance needs a ctx created with BHRAY_F_TIMING or BHRAY_F_TIMING_SPARSE");
+    if (c->world < 2 || c->single) return gfail(c, BHRAY_E_STATE, "bhray_rebalance needs a ctx that gathers (device_count >= 2, or gather = BHRAY_GATHER_RCCL); a host that moves the tiles itself balances with bhray_rebalance_slabs");
+    const uint32_t N = c->world, H = c->cfg.frame_h;
+    // a ctx created with interleaved stripes starts from equal slabs
+    uint32_t cur[BHRAY_MAX_DEVICES + 1];
+    const bool was_slabs = c->cfg.partition == BHRAY_PARTITION_SLABS;
+    for (uint32_t p = 0; p <= N; p++) cur[p] = was_slabs ? c->cfg.slab_row0[p] : (uint32_t)((uint64_t)H * p / N);
+    { int rc = group_sync(c); if (rc) return rc; }
+    double ms[BHRAY_MAX_DEVICES] = {0}, extra[BHRAY_MAX_DEVICES] = {0};
+    uint32_t frames = 0;
+    bool have[BHRAY_MAX_DEVICES] = {false};
+    for (uint32_t q = 0; q < N; q++) {
+        Part& p = c->parts[q];
+        if (!p.dev) continue;
+        bhray_timing t;
+        DEV(c, p.dev, dev_get_timing(p.dev, &t));
+        if (t.frames == 0) continue;
+        have[q] = true;
+        ms[q] = (t.trace_exec_launches ? (double)t.trace_exec_ms : (double)t.trace_ms) / (double)t.frames;
+        if (q == c->root || !c->root_local) frames = t.frames;
+    }
+    if (c->root_local) {                                         // the root's de-interleave: work that stays with the root whatever its rows
+        GHIP(c, hipSetDevice(root_part(c)->device));
+        for (GroupSlot& G : c->gslots) {
+            if (!G.timed) continue;
+            float a = 0, b = 0;
+            GHIP(c, hipEventElapsedTime(&a, G.tev[0], G.tev[1])); GHIP(c, hipEventElapsedTime(&b, G.tev[1], G.tev[2]));
+            c->gather_ms += a; c->deint_ms += b; G.timed = false;
+        }
+        if (c->gathers) extra[c->root] = (double)c->deint_ms / ((double)c->gathers * (double)c->B);
+        c->gather_ms = 0; c->deint_ms = 0; c->gathers = 0;
+    }
+    if (c->ranks.size() == 1 && c->comm_size > 1) {
+        // one process per GPU: everybody learns everybody's numbers (2 floats per rank) over the communicator, on the communication stream
+        Rccl* R = rccl();
+        if (!R) return gfail(c, BHRAY_E_COMM, "%s", g_rccl.error.c_str());
+        CommRank& cr = c->ranks[0];
+        GHIP(c, hipSetDevice(cr.device));
+        if (!c->d_xchg) GHIP(c, hipMalloc(&c->d_xchg, (2 + 2 * (size_t)N) * sizeof(float)));
+        const uint32_t me = c->cfg.row_rank;
+        float mine[2] = {have[me] ? (float)ms[me] : -1.0f, (float)extra[me]};
+        GHIP(c, hipMemcpyAsync(c->d_xchg, mine, sizeof mine, hipMemcpyHostToDevice, cr.stream));
+        GNCCL(c, R, R->AllGather(c->d_xchg, c->d_xchg + 2, 2, ncclFloat32, cr.comm, cr.stream));
+        std::vector<float> all(2 * (size_t)N);
+        GHIP(c, hipMemcpyAsync(all.data(), c->d_xchg + 2, all.size() * sizeof(float), hipMemcpyDeviceToHost, cr.stream));
+        GHIP(c, hipStreamSynchronize(cr.stream));
+        for (uint32_t q = 0; q < N; q++) { have[q] = all[2 * q] >= 0.0f; ms[q] = have[q] ? all[2 * q] : 0.0; extra[q] = all[2 * q + 1]; }
+    }
+    // a partition without rows measures nothing and that is fine; a partition WITH rows and no measurement means no frame was timed yet
+    for (uint32_t q = 0; q < N; q++) if (cur[q + 1] > cur[q] && !have[q]) return gfail(c, BHRAY_E_STATE, "bhray_rebalance: no timed frame since the previous call (partition %u)", q);
+    if (c->row_weight.size() != H) c->row_weight.assign(H, 0.0);
+    // the frames to come are expected one period's displacement of the hole's projection further on (a camera that keeps pitching)
+    double shift = 0.0;
+    if (c->hole_row_valid && c->hole_row_prev_valid) shift = c->hole_row - c->hole_row_prev;
+    if (!(fabs(shift) < 0.5 * (double)H)) shift = 0.0;          // a cut, not a motion
+    c->hole_row_prev = c->hole_row; c->hole_row_prev_valid = c->hole_row_valid;
+    uint32_t next[BHRAY_MAX_DEVICES + 1];
+    double predicted = 0.0, before = 0.0;
+    for (uint32_t q = 0; q < N; q++) before = std::max(before, ms[q] + extra[q]);
+    { int rc = bhray_rebalance_slabs(H, N, cur, ms, extra, shift, c->row_weight.data(), next, &predicted); if (rc) return gfail(c, rc, "bhray_rebalance_slabs failed"); }
+    c->rebalances++;
+    bool differ = !was_slabs;
+    for (uint32_t p = 0; p <= N; p++) differ = differ || next[p] != cur[p];
+    const bool apply = differ && predicted < 0.98 * before;
+    if (apply) { int rc = bhray_set_partition(c, next); if (rc) return rc; }
+    if (out) {
+        out->partitions = N; out->applied = apply ? 1u : 0u; out->frames = frames;
+        for (uint32_t p = 0; p <= N; p++) out->slab_row0[p] = apply ? next[p] : cur[p];
+        for (uint32_t q = 0; q < N; q++) { out->part_ms[q] = (float)ms[q]; out->extra_ms[q] = (float)extra[q]; }
+        out->slowest_ms_before = (float)before; out->slowest_ms_predicted = (float)predicted;
+    }
     return BHRAY_OK;
 }
 
@@ -744,24 +1168,37 @@ int bhray_debug_read_queue(bhray_ctx* c, uint32_t level, uint32_t* out, uint32_t
 // ---- scene state: replicated on every local partition ---------------------------------------
 int bhray_set_texture(bhray_ctx* c, int slot, const uint8_t* rgba8, uint32_t w, uint32_t h) {
     if (!c) return BHRAY_E_INVALID;
+    ENTER(c);
     if (c->gather) { int rc = group_sync(c); if (rc) return rc; }
     for (Part& p : c->parts) if (p.dev) DEV(c, p.dev, dev_set_texture(p.dev, slot, rgba8, w, h));
     return BHRAY_OK;
 }
 int bhray_upload_model_uniform(bhray_ctx* c, uint32_t mi, const void* bytes, size_t size) {
     if (!c) return BHRAY_E_INVALID;
+    ENTER(c);
     if (c->gather) { int rc = group_sync(c); if (rc) return rc; }
     for (Part& p : c->parts) if (p.dev) DEV(c, p.dev, dev_upload_model_uniform(p.dev, mi, bytes, size));
+    if (mi < BHRAY_MAX_MODELS && bytes && size == BHRAY_MODEL_UNIFORM_BYTES) {      // the caller's mirror of what decides the kernel variant
+        bhray_model_header hd; memcpy(&hd, bytes, sizeof hd);
+        c->m_usable[mi] = hd.triangle_count > 0; c->m_vis[mi] = hd.visible; memcpy(c->m_pos[mi], hd.position, 12); c->m_dirty[mi] = false;
+    }
     return BHRAY_OK;
 }
 int bhray_upload_model(bhray_ctx* c, uint32_t mi, const bhray_model_desc* d) {
     if (!c) return BHRAY_E_INVALID;
+    ENTER(c);
     if (c->gather) { int rc = group_sync(c); if (rc) return rc; }
     for (Part& p : c->parts) if (p.dev) DEV(c, p.dev, dev_upload_model(p.dev, mi, d));
+    if (mi < BHRAY_MAX_MODELS && d) { c->m_usable[mi] = d->triangle_count > 0; c->m_vis[mi] = d->visible; memcpy(c->m_pos[mi], d->position, 12); c->m_dirty[mi] = false; }
     return BHRAY_OK;
 }
 int bhray_set_model_transform(bhray_ctx* c, uint32_t mi, const float position[3], int32_t visible) {
     if (!c) return BHRAY_E_INVALID;
+    if (c->threaded) {               // travels with the next frame (the engines belong to their issue threads)
+        if (mi >= BHRAY_MAX_MODELS || !position) return gfail(c, BHRAY_E_INVALID, "bad model arguments");
+        memcpy(c->m_pos[mi], position, 12); c->m_vis[mi] = visible; c->m_dirty[mi] = true;
+        return BHRAY_OK;
+    }
     for (Part& p : c->parts) if (p.dev) DEV(c, p.dev, dev_set_model_transform(p.dev, mi, position, visible));
     return BHRAY_OK;
 }
@@ -772,6 +1209,13 @@ int bhray_set_materials(bhray_ctx* c, const void* bytes, size_t size) {
 }
 int bhray_set_uniforms(bhray_ctx* c, const void* cam32, const void* bh132, const void* det32) {
     if (!c) return BHRAY_E_INVALID;
+    if (c->gather && cam32 && bh132) track_hole_row(c, cam32, bh132);
+    if (c->threaded) {               // travel with the next frame
+        if (!cam32 || !bh132 || !det32) return gfail(c, BHRAY_E_INVALID, "null uniform block");
+        memcpy(c->u_cam, cam32, 32); memcpy(c->u_bh, bh132, 132); memcpy(c->u_det, det32, 32);
+        c->have_uniforms = true;
+        return BHRAY_OK;
+    }
     for (Part& p : c->parts) if (p.dev) DEV(c, p.dev, dev_set_uniforms(p.dev, cam32, bh132, det32));
     return BHRAY_OK;
 }
@@ -787,6 +1231,42 @@ int bhray_render(bhray_ctx* c) {
         c->rendered = true;
         return BHRAY_OK;
     }
+    if (c->threaded) {
+        // record the frame and hand it to the issue threads ("Issue threads" above); nothing here touches an engine or a GPU
+        if (c->async_failed.load(std::memory_order_acquire)) return drain(c);
+        if (!c->have_uniforms) return gfail(c, BHRAY_E_STATE, "bhray_set_uniforms has not been called");
+        if (c->mirror_stale) {       // the threads are idle (every call but this one waits for them): read the staging position back
+            for (Part& p : c->parts) {
+                if (!p.dev) continue;
+                int m; bool md;
+                dev_peek_position(p.dev, &c->st_counter, &c->st_pending, &m, &md);
+                c->st_method = m; c->st_models = md;
+                break;
+            }
+            c->mirror_stale = false;
+        }
+        int method; bool models;
+        ctx_variant(c, method, models);
+        if (c->st_pending > 0 && (method != c->st_method || models != c->st_models)) { c->st_counter++; c->st_pending = 0; }   // the engines launch the staged frames first
+        if (c->st_pending == 0) { c->st_method = method; c->st_models = models; }
+        RenderCmd cmd;
+        memcpy(cmd.cam, c->u_cam, 32); memcpy(cmd.bh, c->u_bh, 132); memcpy(cmd.det, c->u_det, 32);
+        for (uint32_t mi = 0; mi < BHRAY_MAX_MODELS; mi++) { memcpy(cmd.mpos[mi], c->m_pos[mi], 12); cmd.mvis[mi] = c->m_vis[mi]; cmd.mset[mi] = c->m_dirty[mi]; c->m_dirty[mi] = false; }
+        cmd.si = (int)(c->st_counter % c->nslots); cmd.sub = c->st_pending;
+        cmd.bound = c->bound; c->bound = nullptr;
+        cmd.serial = ++c->frames_staged;
+        if (++c->st_pending == c->B) { c->st_counter++; c->st_pending = 0; }
+        c->last_slot = cmd.si; c->last_sub = cmd.sub; c->rendered = true;
+        for (WaitEvent& w : c->wait_pool) w.in_use = false;
+        for (auto& w : c->workers) {
+            std::unique_lock<std::mutex> lk(w->m);
+            w->cv.wait(lk, [&] { return w->q.size() < 256; });        // (a host far ahead of its GPUs)
+            w->q.push_back(cmd);
+            lk.unlock();
+            w->cv.notify_all();
+        }
+        return BHRAY_OK;
+    }
     // staged frames of another kernel variant are launched (and gathered) first: the staging position is then final
     int si = -1; uint32_t sub = 0;
     for (Part& p : c->parts) {
@@ -797,22 +1277,25 @@ int bhray_render(bhray_ctx* c) {
         si = s; sub = k;
     }
     { int rc = after_launch(c); if (rc) return rc; }
-    { int rc = bind_partitions(c, si, sub); if (rc) return rc; }
+    { int rc = bind_partitions(c, si, sub, c->bound, c->frames_staged + 1); if (rc) return rc; }
+    c->bound = nullptr;
     for (Part& p : c->parts) if (p.dev) DEV(c, p.dev, dev_render(p.dev));
     for (WaitEvent& w : c->wait_pool) w.in_use = false;
     c->last_slot = si; c->last_sub = sub; c->rendered = true;
-    c->gslots[(size_t)si].frame_no[sub] = ++c->frames_staged;
+    ++c->frames_staged;
     return after_launch(c);
 }
 
 int bhray_flush(bhray_ctx* c) {
     if (!c) return BHRAY_E_INVALID;
+    ENTER(c);
     if (c->single) { DEV(c, c->parts[0].dev, dev_flush(c->parts[0].dev)); return BHRAY_OK; }
     return group_flush(c);
 }
 
 int bhray_sync(bhray_ctx* c) {
     if (!c) return BHRAY_E_INVALID;
+    ENTER(c);
     if (c->single) { DEV(c, c->parts[0].dev, dev_sync(c->parts[0].dev)); return BHRAY_OK; }
     return group_sync(c);
 }
@@ -834,6 +1317,7 @@ int bhray_local_row_index(const bhray_ctx* c, uint32_t i, uint32_t* frame_row) {
 
 int bhray_read_hdr(bhray_ctx* c, float* dst, size_t pitch) {
     if (!c) return BHRAY_E_INVALID;
+    ENTER(c);
     if (c->single) { DEV(c, c->parts[0].dev, dev_read_hdr(c->parts[0].dev, dst, pitch)); return BHRAY_OK; }
     if (c->gather_sky) return gfail(c, BHRAY_E_STATE, "BHRAY_F_GATHER_SKY: the RGBA32F frame is not assembled (read the sky image)");
     { int rc = group_sync(c); if (rc) return rc; }
@@ -848,6 +1332,7 @@ int bhray_read_hdr(bhray_ctx* c, float* dst, size_t pitch) {
 
 int bhray_read_level(bhray_ctx* c, uint32_t level, float* dst, size_t pitch) {
     if (!c) return BHRAY_E_INVALID;
+    ENTER(c);
     if (c->single) { DEV(c, c->parts[0].dev, dev_read_level(c->parts[0].dev, level, dst, pitch)); return BHRAY_OK; }
     // every partition computed the level rows its stripes depend on: overlay them (unrendered pixels are NaN-filled; pixels
     // computed by several partitions are identical)
@@ -887,6 +1372,7 @@ int bhray_read_level(bhray_ctx* c, uint32_t level, float* dst, size_t pitch) {
 
 int bhray_hdr_device_ptr(bhray_ctx* c, void** p, size_t* bytes) {
     if (!c || !p) return BHRAY_E_INVALID;
+    ENTER(c);
     if (c->single) { DEV(c, c->parts[0].dev, dev_hdr_device_ptr(c->parts[0].dev, p, bytes)); return BHRAY_OK; }
     if (c->gather_sky) { *p = nullptr; return gfail(c, BHRAY_E_STATE, "BHRAY_F_GATHER_SKY: the RGBA32F frame is not assembled (read the sky image)"); }
     *p = c->root_local ? (void*)c->gslots[(size_t)c->last_slot].dst[c->last_sub] : nullptr;
@@ -910,6 +1396,7 @@ int bhray_bind_output(bhray_ctx* c, void* p, size_t bytes) {
 // ---- asynchronous hand-off -------------------------------------------------------------------------
 int bhray_read_hdr_async(bhray_ctx* c, float* dst, size_t pitch, uint64_t* ticket) {
     if (!c || !ticket) return BHRAY_E_INVALID;
+    ENTER(c);
     if (c->single) { DEV(c, c->parts[0].dev, dev_read_hdr_async(c->parts[0].dev, dst, pitch, ticket)); return BHRAY_OK; }
     if (c->gather_sky) return gfail(c, BHRAY_E_STATE, "BHRAY_F_GATHER_SKY: the RGBA32F frame is not assembled (read the sky image)");
     if (!c->rendered) return gfail(c, BHRAY_E_STATE, "nothing rendered yet");
@@ -938,6 +1425,7 @@ int bhray_read_hdr_async(bhray_ctx* c, float* dst, size_t pitch, uint64_t* ticke
 
 int bhray_read_sky_async(bhray_ctx* c, uint16_t* dst, size_t pitch, uint64_t* ticket) {
     if (!c || !ticket) return BHRAY_E_INVALID;
+    ENTER(c);
     if (c->single) { DEV(c, c->parts[0].dev, dev_read_sky_async(c->parts[0].dev, dst, pitch, ticket)); return BHRAY_OK; }
     if (!c->rendered) return gfail(c, BHRAY_E_STATE, "nothing rendered yet");
     if (c->gather_sky) { int rc = group_flush(c); if (rc) return rc; }      // (the batch's gather produces the image)
@@ -1029,6 +1517,7 @@ int bhray_release_external(bhray_ctx* c, void* dev_ptr) {
 // ---- ordering against caller streams ------------------------------------------------------------
 int bhray_wait_stream(bhray_ctx* c, void* s) {
     if (!c) return BHRAY_E_INVALID;
+    ENTER(c);
     // One event per call (two calls with different streams before one render are two dependencies), recorded with the STREAM's
     // device current (a stream of another partition's GPU is fine: the renders wait across devices).  The events are handed
     // to every local partition and recycled once the next bhray_render has consumed them.
@@ -1057,6 +1546,7 @@ int bhray_next_stream(bhray_ctx* c, void** s) {
 
 int bhray_signal_stream(bhray_ctx* c, void* s) {
     if (!c) return BHRAY_E_INVALID;
+    ENTER(c);
     if (c->single) { DEV(c, c->parts[0].dev, dev_signal_stream(c->parts[0].dev, s)); return BHRAY_OK; }
     if (!c->rendered) return BHRAY_OK;
     { int rc = group_flush(c); if (rc) return rc; }
@@ -1074,6 +1564,7 @@ int bhray_signal_stream(bhray_ctx* c, void* s) {
 // ---- sky resolve -----------------------------------------------------------------------------------
 int bhray_resolve_sky(bhray_ctx* c) {
     if (!c) return BHRAY_E_INVALID;
+    ENTER(c);
     if (c->single) { DEV(c, c->parts[0].dev, dev_resolve_sky(c->parts[0].dev)); return BHRAY_OK; }
     if (!c->rendered) return gfail(c, BHRAY_E_STATE, "nothing rendered yet");
     { int rc = group_flush(c); if (rc) return rc; }
@@ -1095,6 +1586,7 @@ int bhray_resolve_sky(bhray_ctx* c) {
 
 int bhray_read_sky(bhray_ctx* c, uint16_t* dst, size_t pitch) {
     if (!c) return BHRAY_E_INVALID;
+    ENTER(c);
     if (c->single) { DEV(c, c->parts[0].dev, dev_read_sky(c->parts[0].dev, dst, pitch)); return BHRAY_OK; }
     { int rc = group_sync(c); if (rc) return rc; }
     if (!c->root_local) return BHRAY_OK;
@@ -1119,6 +1611,7 @@ int bhray_sky_device_ptr(bhray_ctx* c, void** p, size_t* bytes) {
 // ---- measurement -------------------------------------------------------------------------------------
 int bhray_selftest(bhray_ctx* c, uint64_t mismatches[3]) {
     if (!c || !mismatches) return BHRAY_E_INVALID;
+    ENTER(c);
     uint64_t sum[3] = {0, 0, 0};
     for (Part& p : c->parts) {
         if (!p.dev) continue;
@@ -1132,6 +1625,7 @@ int bhray_selftest(bhray_ctx* c, uint64_t mismatches[3]) {
 
 int bhray_get_level_counters(bhray_ctx* c, uint32_t level, bhray_counters* out) {
     if (!c || !out) return BHRAY_E_INVALID;
+    ENTER(c);
     if (c->gather) { int rc = group_sync(c); if (rc) return rc; }
     memset(out, 0, sizeof *out);
     for (Part& p : c->parts) {                                   // local partitions only: whole-frame work = sum over all
@@ -1146,6 +1640,7 @@ int bhray_get_level_counters(bhray_ctx* c, uint32_t level, bhray_counters* out) 
 
 int bhray_get_row_work(bhray_ctx* c, uint32_t level, uint64_t* out, uint32_t n) {
     if (!c || !out) return BHRAY_E_INVALID;
+    ENTER(c);
     if (level >= c->cfg.levels || n != c->cfg.level_h[level]) return gfail(c, BHRAY_E_INVALID, "level out of range, or n is not the level's height");
     if (c->gather) { int rc = group_sync(c); if (rc) return rc; }
     memset(out, 0, (size_t)n * sizeof(uint64_t));
@@ -1168,6 +1663,7 @@ int bhray_get_counters(bhray_ctx* c, bhray_counters* out) {
 
 int bhray_get_timing(bhray_ctx* c, bhray_timing* out) {
     if (!c || !out) return BHRAY_E_INVALID;
+    ENTER(c);
     if (c->single) { DEV(c, c->parts[0].dev, dev_get_timing(c->parts[0].dev, out)); return BHRAY_OK; }
     if (!(c->cfg.flags & (BHRAY_F_TIMING | BHRAY_F_TIMING_SPARSE))) return gfail(c, BHRAY_E_STATE, "ctx created without BHRAY_F_TIMING");
     { int rc = group_sync(c); if (rc) return rc; }

@@ -120,6 +120,18 @@ assert C.sizeof(BhrayDetails) == 32 and C.sizeof(BhrayCameraUniform) == 32 and C
 assert C.sizeof(BhrayNode) == 32 and C.sizeof(BhrayTriangle) == 24
 
 # every symbol include/bhray.h declares: name -> (restype, argtypes)
+class BhrayRebalanceInfo(C.Structure):
+    """bhray_rebalance_info (include/bhray.h)"""
+    _fields_ = [("partitions", C.c_uint32), ("applied", C.c_uint32), ("slab_row0", C.c_uint32 * 17), ("part_ms", C.c_float * 16), ("extra_ms", C.c_float * 16),
+                ("slowest_ms_before", C.c_float), ("slowest_ms_predicted", C.c_float), ("frames", C.c_uint32)]
+
+    def as_dict(self):
+        n = int(self.partitions)
+        return {"partitions": n, "applied": bool(self.applied), "slab_row0": [int(v) for v in self.slab_row0[:n + 1]], "part_ms": [float(v) for v in self.part_ms[:n]],
+                "extra_ms": [float(v) for v in self.extra_ms[:n]], "slowest_ms_before": float(self.slowest_ms_before), "slowest_ms_predicted": float(self.slowest_ms_predicted),
+                "frames": int(self.frames)}
+
+
 P = C.POINTER
 vp, u32, i32, sz = C.c_void_p, C.c_uint32, C.c_int32, C.c_size_t
 SYMBOLS = {
@@ -138,6 +150,10 @@ SYMBOLS = {
     "bhray_balance_slabs": (C.c_int, [P(BhrayConfig), P(P(C.c_uint64)), u32, P(u32)]),
     "bhray_comm_unique_id": (C.c_int, [vp]),
     "bhray_get_gather_info": (C.c_int, [vp, P(BhrayGatherInfo)]),
+    "bhray_set_partition": (C.c_int, [vp, P(u32)]),
+    "bhray_get_partition": (C.c_int, [vp, P(u32), P(u32)]),
+    "bhray_rebalance_slabs": (C.c_int, [u32, u32, P(u32), P(C.c_double), P(C.c_double), C.c_double, P(C.c_double), P(u32), P(C.c_double)]),
+    "bhray_rebalance": (C.c_int, [vp, P(BhrayRebalanceInfo)]),
     "bhray_set_materials": (C.c_int, [vp, vp, sz]),
     "bhray_set_texture": (C.c_int, [vp, C.c_int, vp, u32, u32]),
     "bhray_upload_model_uniform": (C.c_int, [vp, u32, vp, sz]),
@@ -198,10 +214,12 @@ def declare(L):
         f.argtypes = args
 
 
-def check(rc, ctx=None):
+def check(rc, ctx=None, L=None):
+    """Raise BhrayError for a non-zero return code; the message comes from the library the ctx belongs to (L)."""
     if rc != 0:
-        from ._lib import lib
-        L = lib()
+        if L is None:
+            from ._lib import lib
+            L = lib()
         msg = L.bhray_last_error(ctx) or b""
         if not msg:
             msg = L.bhray_strerror(rc)

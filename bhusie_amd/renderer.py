@@ -14,7 +14,7 @@ import numpy as np
 
 from ._lib import lib
 from .layouts import (PARTITION_SLABS, F_COUNTERS, F_EVAL_FMA, F_FUSED, F_GATHER_SKY, F_LITERAL, F_TEMPORAL, F_TIMING, F_TIMING_SPARSE, GATHER_RCCL, TEX_DISK, TEX_SKY, TEX_TEMP_LUT, BhrayConfig, BhrayCounters,
-                      BhrayGatherInfo, BhrayTiming, check)
+                      BhrayGatherInfo, BhrayRebalanceInfo, BhrayTiming, check)
 from .model import Model
 from .scene import BlackHole, Camera, RayDetails
 
@@ -80,6 +80,19 @@ def balance_slabs(cfg: BhrayConfig, row_work, world: int):
     return [int(v) for v in out]
 
 
+def rebalance_slabs(frame_h: int, slab_row0, part_ms, row_weight: np.ndarray, extra_ms=None, shift_rows: float = 0.0):
+    """bhray_rebalance_slabs: (new bounds, predicted slowest partition); row_weight (float64[frame_h], zeros before the first call) is updated in place."""
+    world = len(part_ms)
+    assert row_weight.dtype == np.float64 and row_weight.shape == (frame_h,) and row_weight.flags.c_contiguous
+    b_in = (C.c_uint32 * (world + 1))(*[int(v) for v in slab_row0])
+    ms = (C.c_double * world)(*[float(v) for v in part_ms])
+    ex = (C.c_double * world)(*[float(v) for v in extra_ms]) if extra_ms is not None else None
+    out = (C.c_uint32 * (world + 1))()
+    pred = C.c_double()
+    check(lib().bhray_rebalance_slabs(frame_h, world, b_in, ms, ex, float(shift_rows), row_weight.ctypes.data_as(C.POINTER(C.c_double)), out, C.byref(pred)))
+    return [int(v) for v in out], float(pred.value)
+
+
 class RayPass:
     """devices=[d0, d1, ...]: ONE ctx drives several GPUs (partition i on devices[i]); bhray_render then also gathers the row
     tiles to `gather_root`'s GPU over RCCL and de-interleaves them, and every output call refers to the whole frame.
@@ -112,7 +125,7 @@ class RayPass:
         cfg.superset_levels = superset_levels
         self.cfg = cfg
         h = C.c_void_p()
-        self._L = lib()                                          # the library this ctx belongs to (tests swap in libbhray_fused.so)
+        self._L = lib()                                          # the library this ctx belongs to: EVERY call on self._h goes through it (a handle of one .so must never be driven by another)
         check(self._L.bhray_create(C.byref(cfg), C.byref(h)))
         self._h = h
 
@@ -131,53 +144,70 @@ class RayPass:
     def set_texture(self, slot: int, rgba: np.ndarray):
         a = np.ascontiguousarray(rgba, dtype=np.uint8)
         assert a.ndim == 3 and a.shape[2] == 4
-        check(lib().bhray_set_texture(self._h, slot, a.ctypes.data, a.shape[1], a.shape[0]), self._h)
+        check(self._L.bhray_set_texture(self._h, slot, a.ctypes.data, a.shape[1], a.shape[0]), self._h, self._L)
 
     def set_textures(self, temp_lut, disk, sky):
         self.set_texture(TEX_TEMP_LUT, temp_lut); self.set_texture(TEX_DISK, disk); self.set_texture(TEX_SKY, sky)
 
     def upload_model(self, model: Model, index=0):
         d = model.desc()
-        check(lib().bhray_upload_model(self._h, index, C.byref(d)), self._h)
+        check(self._L.bhray_upload_model(self._h, index, C.byref(d)), self._h, self._L)
 
     def upload_model_uniform(self, blob: bytes, index=0):
-        check(lib().bhray_upload_model_uniform(self._h, index, blob, len(blob)), self._h)
+        check(self._L.bhray_upload_model_uniform(self._h, index, blob, len(blob)), self._h, self._L)
 
     def set_materials(self, blob: bytes = bytes(128)):
         """mod.rs:389 — accepted and ignored (the shader never reads the materials)."""
-        check(lib().bhray_set_materials(self._h, blob, len(blob)), self._h)
+        check(self._L.bhray_set_materials(self._h, blob, len(blob)), self._h, self._L)
 
     def row_work(self):
         """[per-row iterations of the last render, one uint64 array per ladder level] (needs counters=True) - the input of balance_slabs."""
         out = []
         for l in range(self.cfg.levels):
             a = np.zeros(self.cfg.level_h[l], dtype=np.uint64)
-            check(lib().bhray_get_row_work(self._h, l, a.ctypes.data_as(C.POINTER(C.c_uint64)), a.size), self._h)
+            check(self._L.bhray_get_row_work(self._h, l, a.ctypes.data_as(C.POINTER(C.c_uint64)), a.size), self._h, self._L)
             out.append(a)
         return out
 
     def gather_info(self) -> dict:
         g = BhrayGatherInfo()
-        check(lib().bhray_get_gather_info(self._h, C.byref(g)), self._h)
+        check(self._L.bhray_get_gather_info(self._h, C.byref(g)), self._h, self._L)
         return g.as_dict()
 
+    # -- run-time partition (multi-GPU balance that follows the scene)
+    def set_partition(self, slab_row0):
+        """From the next render on partition p owns frame rows [slab_row0[p], slab_row0[p + 1]) - no re-create (bhray_set_partition)."""
+        a = (C.c_uint32 * len(slab_row0))(*[int(v) for v in slab_row0])
+        check(self._L.bhray_set_partition(self._h, a), self._h, self._L)
+
+    def get_partition(self):
+        a, n = (C.c_uint32 * 17)(), C.c_uint32()
+        check(self._L.bhray_get_partition(self._h, a, C.byref(n)), self._h, self._L)
+        return [int(v) for v in a[:n.value + 1]]
+
+    def rebalance(self) -> dict:
+        """New slab bounds from the times the ctx measured since the last call (timing=True or "sparse"); applied when they promise >= 2 % (bhray_rebalance)."""
+        info = BhrayRebalanceInfo()
+        check(self._L.bhray_rebalance(self._h, C.byref(info)), self._h, self._L)
+        return info.as_dict()
+
     def set_model_transform(self, position, visible=1, index=0):
-        check(lib().bhray_set_model_transform(self._h, index, (C.c_float * 3)(*[float(x) for x in position]), int(visible)), self._h)
+        check(self._L.bhray_set_model_transform(self._h, index, (C.c_float * 3)(*[float(x) for x in position]), int(visible)), self._h, self._L)
 
     # -- per frame
     def set_uniforms(self, camera: bytes, black_hole: bytes, details: bytes):
         assert len(camera) == 32 and len(black_hole) == 132 and len(details) == 32
-        check(lib().bhray_set_uniforms(self._h, camera, black_hole, details), self._h)
+        check(self._L.bhray_set_uniforms(self._h, camera, black_hole, details), self._h, self._L)
 
     def render(self):
-        check(lib().bhray_render(self._h), self._h)
+        check(self._L.bhray_render(self._h), self._h, self._L)
 
     def flush(self):
         """frames_per_batch > 1: enqueue the launches of the frames staged so far."""
-        check(lib().bhray_flush(self._h), self._h)
+        check(self._L.bhray_flush(self._h), self._h, self._L)
 
     def sync(self):
-        check(lib().bhray_sync(self._h), self._h)
+        check(self._L.bhray_sync(self._h), self._h, self._L)
 
     # -- output
     @property
@@ -185,108 +215,108 @@ class RayPass:
         return int(self.cfg.frame_w), int(self.cfg.frame_h)
 
     def local_rows(self) -> np.ndarray:
-        n = int(lib().bhray_local_rows(self._h))
+        n = int(self._L.bhray_local_rows(self._h))
         out = np.zeros(n, dtype=np.uint32)
         r = C.c_uint32()
         for i in range(n):
-            check(lib().bhray_local_row_index(self._h, i, C.byref(r)), self._h)
+            check(self._L.bhray_local_row_index(self._h, i, C.byref(r)), self._h, self._L)
             out[i] = r.value
         return out
 
     def read_hdr(self) -> np.ndarray:
-        n = int(lib().bhray_local_rows(self._h))
+        n = int(self._L.bhray_local_rows(self._h))
         out = np.empty((n, int(self.cfg.frame_w), 4), dtype=np.float32)
-        check(lib().bhray_read_hdr(self._h, out.ctypes.data, int(self.cfg.frame_w) * 16), self._h)
+        check(self._L.bhray_read_hdr(self._h, out.ctypes.data, int(self.cfg.frame_w) * 16), self._h, self._L)
         return out
 
     def read_hdr_async(self, dst: "PinnedFrame") -> int:
         """Enqueue the device->host copy of the most recently enqueued frame into pinned memory, behind its kernels; returns a ticket."""
         t = C.c_uint64()
-        check(lib().bhray_read_hdr_async(self._h, C.c_void_p(dst.ptr), int(self.cfg.frame_w) * 16, C.byref(t)), self._h)
+        check(self._L.bhray_read_hdr_async(self._h, C.c_void_p(dst.ptr), int(self.cfg.frame_w) * 16, C.byref(t)), self._h, self._L)
         return int(t.value)
 
     def read_sky_async(self, dst: "PinnedFrame") -> int:
         """The RGBA16F image of the sky pass (resolve_sky first) into pinned memory (a PinnedFrame(rows, width, channels16=True))."""
         t = C.c_uint64()
-        check(lib().bhray_read_sky_async(self._h, C.c_void_p(dst.ptr), int(self.cfg.frame_w) * 8, C.byref(t)), self._h)
+        check(self._L.bhray_read_sky_async(self._h, C.c_void_p(dst.ptr), int(self.cfg.frame_w) * 8, C.byref(t)), self._h, self._L)
         return int(t.value)
 
     def wait_read(self, ticket: int):
-        check(lib().bhray_wait_read(self._h, C.c_uint64(ticket)), self._h)
+        check(self._L.bhray_wait_read(self._h, C.c_uint64(ticket)), self._h, self._L)
 
     def import_external_fd(self, fd: int, nbytes: int) -> int:
         """Map memory exported by another API (Vulkan OPAQUE_FD / dma-buf) on the GPU that delivers the frame; returns a device pointer for bind_output."""
         p = C.c_void_p()
-        check(lib().bhray_import_external_fd(self._h, int(fd), nbytes, C.byref(p)), self._h)
+        check(self._L.bhray_import_external_fd(self._h, int(fd), nbytes, C.byref(p)), self._h, self._L)
         return p.value
 
     def release_external(self, ptr: int):
-        check(lib().bhray_release_external(self._h, C.c_void_p(ptr)), self._h)
+        check(self._L.bhray_release_external(self._h, C.c_void_p(ptr)), self._h, self._L)
 
     def read_level(self, level: int) -> np.ndarray:
         w, h = int(self.cfg.level_w[level]), int(self.cfg.level_h[level])
         out = np.empty((h, w, 4), dtype=np.float32)
-        check(lib().bhray_read_level(self._h, level, out.ctypes.data, out.strides[0]), self._h)
+        check(self._L.bhray_read_level(self._h, level, out.ctypes.data, out.strides[0]), self._h, self._L)
         return out
 
     def resolve_sky(self):
         """sky.wgsl behind the last frame (mod.rs:419): direction pixels -> sky^4; RGBA16F."""
-        check(lib().bhray_resolve_sky(self._h), self._h)
+        check(self._L.bhray_resolve_sky(self._h), self._h, self._L)
 
     def read_sky(self) -> np.ndarray:
-        n = int(lib().bhray_local_rows(self._h))
+        n = int(self._L.bhray_local_rows(self._h))
         out = np.empty((n, int(self.cfg.frame_w), 4), dtype=np.float16)
-        check(lib().bhray_read_sky(self._h, out.ctypes.data, int(self.cfg.frame_w) * 8), self._h)
+        check(self._L.bhray_read_sky(self._h, out.ctypes.data, int(self.cfg.frame_w) * 8), self._h, self._L)
         return out
 
     def device_ptr(self):
         p, n = C.c_void_p(), C.c_size_t()
-        check(lib().bhray_hdr_device_ptr(self._h, C.byref(p), C.byref(n)), self._h)
+        check(self._L.bhray_hdr_device_ptr(self._h, C.byref(p), C.byref(n)), self._h, self._L)
         return p.value, n.value
 
     def bind_output(self, ptr, nbytes):
-        check(lib().bhray_bind_output(self._h, C.c_void_p(ptr), nbytes), self._h)
+        check(self._L.bhray_bind_output(self._h, C.c_void_p(ptr), nbytes), self._h, self._L)
 
     def wait_stream(self, s):
         """The next render starts after everything enqueued so far on hipStream_t `s`."""
-        check(lib().bhray_wait_stream(self._h, C.c_void_p(s)), self._h)
+        check(self._L.bhray_wait_stream(self._h, C.c_void_p(s)), self._h, self._L)
 
     def next_stream(self) -> int:
         """hipStream_t (as int) of the slot the next render will use."""
         s = C.c_void_p()
-        check(lib().bhray_next_stream(self._h, C.byref(s)), self._h)
+        check(self._L.bhray_next_stream(self._h, C.byref(s)), self._h, self._L)
         return s.value
 
     def signal_stream(self, s):
         """Work enqueued on hipStream_t `s` from now on starts after the last render."""
-        check(lib().bhray_signal_stream(self._h, C.c_void_p(s)), self._h)
+        check(self._L.bhray_signal_stream(self._h, C.c_void_p(s)), self._h, self._L)
 
     def counters(self) -> dict:
         c = BhrayCounters()
-        check(lib().bhray_get_counters(self._h, C.byref(c)), self._h)
+        check(self._L.bhray_get_counters(self._h, C.byref(c)), self._h, self._L)
         return c.as_dict()
 
     def scheduling_counters(self) -> dict:
         """wave steps, rays adopted through the drain-merging mailbox, lane occupancy of the step loop (needs counters=True)"""
         c = BhrayCounters()
-        check(lib().bhray_get_counters(self._h, C.byref(c)), self._h)
+        check(self._L.bhray_get_counters(self._h, C.byref(c)), self._h, self._L)
         return c.scheduling()
 
     def level_counters(self, level: int) -> dict:
         c = BhrayCounters()
-        check(lib().bhray_get_level_counters(self._h, level, C.byref(c)), self._h)
+        check(self._L.bhray_get_level_counters(self._h, level, C.byref(c)), self._h, self._L)
         return c.as_dict()
 
     def selftest(self):
         """(1/x mismatches, sqrt mismatches, places where the portable acos increases): exhaustive device checks of the
         properties the exact shortcuts rest on; all must be 0."""
         m = (C.c_uint64 * 3)()
-        check(lib().bhray_selftest(self._h, m), self._h)
+        check(self._L.bhray_selftest(self._h, m), self._h, self._L)
         return int(m[0]), int(m[1]), int(m[2])
 
     def timing(self) -> BhrayTiming:
         t = BhrayTiming()
-        check(lib().bhray_get_timing(self._h, C.byref(t)), self._h)
+        check(self._L.bhray_get_timing(self._h, C.byref(t)), self._h, self._L)
         return t
 
 

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define BHRAY_VERSION_MAJOR 0
-#define BHRAY_VERSION_MINOR 3
+#define BHRAY_VERSION_MINOR 4
 
 /* ------------------------------------------------------------------------------------------
  * Error codes
@@ -302,6 +302,44 @@ int bhray_config_partition_row_index(const bhray_config* cfg, uint32_t part, uin
  * included); the bounds minimise the largest partition's work over all contiguous partitions.  Pure host arithmetic.
  * Writes slab_row0[0..world] (slab_row0[0] = 0, slab_row0[world] = frame_h); the caller copies them into bhray_config.slab_row0. */
 int bhray_balance_slabs(const bhray_config* cfg, const uint64_t* const* row_work, uint32_t world, uint32_t* slab_row0);
+/* Run-time partition: the bounds can follow the scene (the reference's camera moves every frame, src/app.rs:98-102; the rows the
+ * hole and the disk project to are where the work is).  None of these re-creates the ctx; frames before and after are the same pixels.
+ *
+ * bhray_set_partition: from the next bhray_render on, partition p owns the frame rows [slab_row0[p], slab_row0[p + 1]) (contiguous
+ *   slabs whatever the ctx was created with; partitions = device_count, or row_world; a partition may own no rows).  Waits for
+ *   everything enqueued so far, rewrites the row tables of the engines and the gather tables in place; per-frame queues, send and
+ *   staging buffers grow when the new rows need more (by a quarter more than needed, so that bounds that keep moving a few rows do
+ *   not reallocate).  One process per GPU: every rank calls it with the same bounds before its next bhray_render.  Not with BHRAY_F_FUSED.
+ * bhray_rebalance_slabs: pure host arithmetic behind bhray_rebalance, exposed so that a host can balance by its own measurements.
+ *   row_weight[frame_h] is the caller's persistent estimate of what every frame row costs (all zero before the first call); the call
+ *   rescales the rows of every partition so that their sum is that partition's measured part_ms (the shape inside a partition is
+ *   kept: it is what earlier calls learned), then finds the bounds that minimise the largest (sum of weights + extra_ms[p]) over
+ *   contiguous partitions.  extra_ms (may be NULL) = work of a partition that does not move with its rows (the root's gather).
+ *   shift_rows: the frames to come are expected to show what was measured this many rows further down (a camera that pitches moves
+ *   the rows the hole projects to); the learned weights are shifted before the bounds are found.  0 for a scene at rest.
+ * bhray_rebalance: the same from what the ctx measures by itself - needs BHRAY_F_TIMING or BHRAY_F_TIMING_SPARSE: the execution spans
+ *   the trace kernels stamp (bhray_timing.trace_exec_ms) of the frames since the previous call, per partition, and on the root the
+ *   de-interleave of the gathered tiles as its extra work; shift_rows = how far the frame row the hole projects to (from the uniforms
+ *   of bhray_set_uniforms) moved since the previous call.  No counting build, no calibration frame.  The new bounds are applied
+ *   (bhray_set_partition) when they promise at least 2 % less for the slowest partition.  One process per GPU: collective - every rank
+ *   calls it at the same point of its frame sequence; the times travel over the ctx's communicator (one small all-gather).
+ *   Call it every second or so of frames: it waits for the frames in flight.                                                      */
+typedef struct bhray_rebalance_info {
+    uint32_t partitions;
+    uint32_t applied;                                 /* 1: the partition was changed                                              */
+    uint32_t slab_row0[BHRAY_MAX_DEVICES + 1];        /* the bounds in force after the call                                         */
+    float    part_ms[BHRAY_MAX_DEVICES];              /* measured: trace-kernel execution per frame and partition                   */
+    float    extra_ms[BHRAY_MAX_DEVICES];             /* measured: work that does not move with the rows (root: de-interleave)       */
+    float    slowest_ms_before, slowest_ms_predicted; /* max over partitions of part_ms + extra_ms; what the new bounds promise     */
+    uint32_t frames;                                  /* frames the measurement covers (partition of this rank / the root)          */
+} bhray_rebalance_info;
+int bhray_set_partition(bhray_ctx* ctx, const uint32_t* slab_row0 /* partitions + 1 entries */);
+int bhray_rebalance_slabs(uint32_t frame_h, uint32_t partitions, const uint32_t* slab_row0, const double* part_ms, const double* extra_ms,
+                          double shift_rows, double* row_weight, uint32_t* slab_row0_out, double* slowest_predicted /* may be NULL */);
+int bhray_rebalance(bhray_ctx* ctx, bhray_rebalance_info* out /* may be NULL */);
+/* The partition in force: partitions + 1 bounds when it is contiguous slabs; BHRAY_E_STATE for interleaved stripes.              */
+int bhray_get_partition(const bhray_ctx* ctx, uint32_t* slab_row0 /* BHRAY_MAX_DEVICES + 1 entries */, uint32_t* partitions);
+
 /* One process per GPU: a fresh communicator id (ncclGetUniqueId); call on ONE rank, hand the bytes to all ranks.  */
 int bhray_comm_unique_id(uint8_t id[BHRAY_COMM_ID_BYTES]);
 /* What a ctx gathers with.                                                                                          */

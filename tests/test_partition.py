@@ -86,3 +86,68 @@ def test_balancer_without_measured_work_gives_equal_rows():
     cfg = B.ladder_for_frame((320, 200), 3, 3)
     work = [np.zeros(cfg.level_h[l], dtype=np.uint64) for l in range(cfg.levels)]
     assert B.balance_slabs(cfg, work, 4) == [0, 50, 100, 150, 200]
+
+
+def _profile(h, centre, width=0.1):
+    rows = np.arange(h)
+    return 0.02 + np.exp(-((rows - centre) / (width * h)) ** 2) + 0.3 * np.exp(-((rows - centre) / (0.25 * h)) ** 2)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_rebalance_slabs_converges_on_equal_partition_times(world):
+    """bhray_rebalance_slabs (the arithmetic of bhray_rebalance): partitions report what their rows cost; the row weights learn it, the
+    bounds equalise it.  A scene at rest: a few rounds to within 3 % of the mean, from equal slabs and knowing nothing."""
+    h = 1080
+    cost = _profile(h, 450)
+    w = np.zeros(h)
+    b = [h * p // world for p in range(world + 1)]
+    worst = []
+    for _ in range(8):
+        ms = [float(cost[b[p]:b[p + 1]].sum()) for p in range(world)]
+        worst.append(max(ms) / (sum(ms) / world))
+        b, pred = B.rebalance_slabs(h, b, ms, w)
+        assert b[0] == 0 and b[-1] == h and all(x <= y for x, y in zip(b, b[1:]))
+        assert pred >= sum(ms) / world * 0.999                       # nothing is promised below the mean
+    assert worst[0] > 1.5 and worst[-1] < 1.03, worst
+    assert abs(float(w.sum()) - float(cost.sum())) < 1e-6 * float(cost.sum())      # the weights carry the measured total
+
+
+def test_rebalance_slabs_follows_a_moving_profile_when_told_the_shift():
+    h, world = 1080, 8
+    w = np.zeros(h)
+    b = [h * p // world for p in range(world + 1)]
+    worst = []
+    for it in range(14):
+        cost = _profile(h, 300 + 30 * it)
+        ms = [float(cost[b[p]:b[p + 1]].sum()) for p in range(world)]
+        worst.append(max(ms) / (sum(ms) / world))
+        b, _ = B.rebalance_slabs(h, b, ms, w, shift_rows=30.0)
+    assert max(worst[5:]) < 1.06, worst
+    # ... and without the hint it lags behind
+    w = np.zeros(h); b = [h * p // world for p in range(world + 1)]; lag = []
+    for it in range(14):
+        cost = _profile(h, 300 + 30 * it)
+        ms = [float(cost[b[p]:b[p + 1]].sum()) for p in range(world)]
+        lag.append(max(ms) / (sum(ms) / world))
+        b, _ = B.rebalance_slabs(h, b, ms, w)
+    assert max(lag[5:]) > max(worst[5:]) + 0.1
+
+
+def test_rebalance_slabs_gives_the_root_fewer_rows_for_its_extra_work_and_rejects_nonsense():
+    h, world = 400, 4
+    w = np.zeros(h)
+    b = [0, 100, 200, 300, 400]
+    extra = [0.0, 0.0, 30.0, 0.0]
+    for _ in range(4):
+        ms = [float(b[p + 1] - b[p]) for p in range(world)]              # every row costs 1
+        b, pred = B.rebalance_slabs(h, b, ms, w, extra_ms=extra)
+    sizes = [y - x for x, y in zip(b, b[1:])]
+    assert sizes[2] + 30 <= max(sizes) + 1 and abs(sizes[0] - sizes[1]) <= 1 and abs(max(sizes) - (h + 30) / 4) <= 1.5, sizes
+    # extra work larger than the balanced load: that partition keeps no rows
+    b2, _ = B.rebalance_slabs(h, [0, 100, 200, 300, 400], [100.0] * 4, np.zeros(h), extra_ms=[0.0, 500.0, 0.0, 0.0])
+    assert b2[1] == b2[2]
+    for bad in (dict(slab_row0=[0, 100, 200, 300, 399]), dict(slab_row0=[0, 200, 100, 300, 400]), dict(part_ms=[1.0, -1.0, 1.0, 1.0]), dict(part_ms=[1.0, float("nan"), 1.0, 1.0])):
+        args = dict(slab_row0=[0, 100, 200, 300, 400], part_ms=[1.0] * 4)
+        args.update(bad)
+        with pytest.raises(B.BhrayError):
+            B.rebalance_slabs(h, args["slab_row0"], args["part_ms"], np.zeros(h))
