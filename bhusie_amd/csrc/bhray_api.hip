@@ -60,7 +60,8 @@ struct FrameRes {
     std::vector<uint32_t*> stamp;       // per level: stamp[y * w + x] == stamp_value <=> the predicted launch traced that pixel this frame
     uint32_t stamp_value = 0;
 
-    uint32_t* d_qctl = nullptr;         // [2*BHRAY_MAX_LEVELS]: qcount[l], qhead[l]   (a slice of Slot::d_qctl)
+    uint32_t* d_qctl = nullptr;         // [BHRAY_QCTL_WORDS]: qcount[l], qhead[l], then the work counters   (a slice of Slot::d_qctl)
+    unsigned long long* d_work = nullptr;   // [BHRAY_WORK_WORDS] inside that slice: integrator steps the trace waves issued for the frame held here (FrameLaunch::work)
     Counters64* d_counters = nullptr;   // [BHRAY_MAX_LEVELS]                         (a slice of Slot::d_counters)
     unsigned long long* d_row_work = nullptr;   // BHRAY_F_COUNTERS: iterations per level row, level l at bhray_dev::row_work_off[l] (bhray_get_row_work)
     float4* own_out = nullptr;
@@ -87,7 +88,8 @@ struct Slot {
     std::vector<FrameRes> fr;
     uint32_t pending = 0;               // frames staged and not launched yet
     int method = 0; bool models = false;   // kernel variant of the staged frames (a batch is homogeneous)
-    uint32_t* d_qctl = nullptr;         // [frames_per_batch][2*BHRAY_MAX_LEVELS]
+    uint32_t* d_qctl = nullptr;         // [frames_per_batch][BHRAY_QCTL_WORDS]
+    uint32_t launched_frames = 0;       // frames of the batch launched last from this slot (their work counters are valid once it has completed)
     Counters64* d_counters = nullptr;   // [frames_per_batch][BHRAY_MAX_LEVELS]
     uint8_t* h_args = nullptr;          // pinned staging of the argument block: FrameParams[B], then FrameLaunch[B] per launch
     uint8_t* d_args = nullptr;
@@ -683,8 +685,8 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
         CHK(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
         CHK(hipEventCreateWithFlags(&S.uploaded, hipEventDisableTiming));
         const size_t B = c->batch;
-        CHK(hipMalloc(&S.d_qctl, B * 2 * BHRAY_MAX_LEVELS * sizeof(uint32_t)));
-        CHK(hipMemset(S.d_qctl, 0, B * 2 * BHRAY_MAX_LEVELS * sizeof(uint32_t)));
+        CHK(hipMalloc(&S.d_qctl, B * BHRAY_QCTL_WORDS * sizeof(uint32_t)));
+        CHK(hipMemset(S.d_qctl, 0, B * BHRAY_QCTL_WORDS * sizeof(uint32_t)));
         CHK(hipMalloc(&S.d_counters, B * BHRAY_MAX_LEVELS * sizeof(Counters64)));
         CHK(hipMemset(S.d_counters, 0, B * BHRAY_MAX_LEVELS * sizeof(Counters64)));
         S.args_cap = (B * (sizeof(FrameParams) + nlaunch * sizeof(FrameLaunch) + sizeof(FusedFrame) + 16) + 15) & ~(size_t)15;
@@ -693,7 +695,8 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
         S.fr.resize(B);
         for (size_t k = 0; k < B; k++) {
             FrameRes& R = S.fr[k];
-            R.d_qctl = S.d_qctl + k * 2 * BHRAY_MAX_LEVELS;
+            R.d_qctl = S.d_qctl + k * BHRAY_QCTL_WORDS;
+            R.d_work = reinterpret_cast<unsigned long long*>(R.d_qctl + 2 * BHRAY_MAX_LEVELS);
             R.d_counters = S.d_counters + k * BHRAY_MAX_LEVELS;
             R.level_out.assign(nl > 0 ? nl - 1 : 0, nullptr);
             R.queue.assign(nl, nullptr);
@@ -1346,8 +1349,14 @@ int launch_batch(bhray_dev* c) {
     } else {
         c->ring_spans[ring] = 0;
     }
+    for (const Launch& Ln : seq) {             // every trace launch adds the steps its waves issue for a frame to that frame's work counters
+        if (Ln.kind != 1) continue;
+        FrameLaunch* hl = (FrameLaunch*)(S.h_args + ((const uint8_t*)Ln.d - S.d_args));
+        for (uint32_t k = 0; k < nb; k++) hl[k].work = S.fr[k].d_work;
+    }
+    S.launched_frames = nb;
     // enqueue
-    HIPCHK(c, launch_upload(S.h_args, S.d_args, (args_used + 15) / 16, S.d_qctl, (size_t)nb * 2 * BHRAY_MAX_LEVELS, st));   // + queue control reset
+    HIPCHK(c, launch_upload(S.h_args, S.d_args, (args_used + 15) / 16, S.d_qctl, (size_t)nb * BHRAY_QCTL_WORDS, st));   // + queue control reset
     HIPCHK(c, hipEventRecord(S.uploaded, st));
     if (count) HIPCHK(c, hipMemsetAsync(S.d_counters, 0, (size_t)nb * BHRAY_MAX_LEVELS * sizeof(Counters64), st));
     if (count) for (uint32_t k = 0; k < nb; k++) if (S.fr[k].d_row_work) HIPCHK(c, hipMemsetAsync(S.fr[k].d_row_work, 0, c->row_work_off[nl] * sizeof(unsigned long long), st));
@@ -1512,11 +1521,12 @@ int dev_read_sky_async(bhray_dev* c, uint16_t* dst, size_t pitch, uint64_t* tick
     const size_t rowb = (size_t)c->cfg.frame_w * sizeof(uint2);
     if (!c->rendered) return fail(c, BHRAY_E_STATE, "nothing rendered yet");
     HIPCHK(c, hipSetDevice(c->device));
-    { int rc = launch_batch(c); if (rc) return rc; }          // (dev_resolve_sky launched the frame's batch; a render since then would be another frame)
     Slot& S = c->slots[(size_t)c->last_slot];
     FrameRes& R = S.fr[(size_t)c->last_sub];
     const size_t rows = c->local_rows.size();
+    // refused BEFORE anything is launched: a misuse (render without resolve_sky) must not flush a partly filled batch on its way to the error
     if (rows && (!R.sky_out || R.sky_frame_id != R.frame_id)) return fail(c, BHRAY_E_STATE, "dev_resolve_sky has not been called for this frame");
+    { int rc = launch_batch(c); if (rc) return rc; }          // (dev_resolve_sky launched the frame's batch: nothing is pending unless a partition without rows skipped it)
     const uint64_t t = c->read_tickets;
     hipEvent_t& ev = c->read_ev[t % BHRAY_READ_RING];
     if (!ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -1618,7 +1628,11 @@ int dev_read_sky(bhray_dev* c, uint16_t* dst, size_t pitch) {
 
 int dev_sky_device_ptr(bhray_dev* c, void** p, size_t* bytes) {
     if (!c || !p) return BHRAY_E_INVALID;
-    *p = c->slots[(size_t)c->last_slot].fr[(size_t)c->last_sub].sky_out;
+    *p = nullptr;
+    const FrameRes& R = c->slots[(size_t)c->last_slot].fr[(size_t)c->last_sub];
+    // the same rule as the reads: the image belongs to the frame it was resolved from (a slot position is reused: an older frame's image is stale)
+    if (!c->local_rows.empty() && (!R.sky_out || R.sky_frame_id != R.frame_id)) return fail(c, BHRAY_E_STATE, "dev_resolve_sky has not been called for this frame");
+    *p = R.sky_out;
     if (bytes) *bytes = c->local_rows.size() * (size_t)c->cfg.frame_w * sizeof(uint2);
     return BHRAY_OK;
 }
@@ -1720,6 +1734,33 @@ int dev_add_row_work(bhray_dev* c, uint32_t level, uint64_t* acc, uint32_t n) {
     std::vector<unsigned long long> tmp(n);
     HIPCHK(c, hipMemcpy(tmp.data(), R.d_row_work + c->row_work_off[level], (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (uint32_t y = 0; y < n; y++) acc[y] += tmp[y];
+    return BHRAY_OK;
+}
+
+// What the frames of the batches still held by the slots cost this engine: integrator steps issued by its trace waves (FrameLaunch::work),
+// mean per frame, and the pixels its classify launches visit per frame (an HBM-bound pass: its cost goes with the pixels).
+int dev_get_work(bhray_dev* c, double* wave_steps_per_frame, double* classify_pixels_per_frame, uint32_t* frames, int* method) {
+    if (!c || !wave_steps_per_frame || !classify_pixels_per_frame || !frames || !method) return BHRAY_E_INVALID;
+    int rc = dev_sync(c);
+    if (rc) return rc;
+    std::vector<uint32_t> tmp((size_t)c->batch * BHRAY_QCTL_WORDS);
+    double sum = 0.0; uint32_t n = 0;
+    for (const Slot& S : c->slots) {
+        if (!S.used || S.launched_frames == 0) continue;
+        HIPCHK(c, hipMemcpy(tmp.data(), S.d_qctl, (size_t)S.launched_frames * BHRAY_QCTL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (uint32_t k = 0; k < S.launched_frames; k++) {
+            unsigned long long w[BHRAY_WORK_WORDS];
+            memcpy(w, tmp.data() + (size_t)k * BHRAY_QCTL_WORDS + 2 * BHRAY_MAX_LEVELS, sizeof w);
+            for (unsigned long long v : w) sum += (double)v;
+            n++;
+        }
+    }
+    double px = 0.0;
+    for (const Level& L : c->levels) px += (double)L.queue_cap;
+    *wave_steps_per_frame = n ? sum / (double)n : 0.0;
+    *classify_pixels_per_frame = px;
+    *frames = n;
+    *method = c->det.integration_method != 0 ? 1 : 0;
     return BHRAY_OK;
 }
 

@@ -84,6 +84,8 @@ int  dev_add_row_work(bhray_dev* c, uint32_t level, uint64_t* acc, uint32_t n); 
 int  dev_debug_read_queue(bhray_dev* c, uint32_t level, uint32_t* out, uint32_t cap, uint32_t* count);   // diagnostics only
 int  dev_get_counters(bhray_dev* c, bhray_counters* out);
 int  dev_get_timing(bhray_dev* c, bhray_timing* out);
+// what the frames still held by the slots cost: integrator steps issued by the trace waves (mean per frame) and pixels visited by the classify launches
+int  dev_get_work(bhray_dev* c, double* wave_steps_per_frame, double* classify_pixels_per_frame, uint32_t* frames, int* method);   // method: the integrator of the current uniforms (1 = RK)
 
 // hooks for the gather (bhray_group.hip)
 int  dev_device(const bhray_dev* c);

@@ -24,6 +24,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -139,6 +140,18 @@ __global__ __launch_bounds__(256) void deinterleave16_kernel(const uint2* __rest
     }
 }
 
+// The descriptor handed to hipImportExternalMemory is a dup() of the caller's.  ROCm 7.2 does not say whether the runtime closes it
+// (CUDA's rule is that an imported fd belongs to the driver).  So the library closes it when the import is released - but only if the
+// number still refers to the same open file as when it was duplicated (same device and inode: a dma-buf has an inode of its own); if the
+// runtime closed it and the number has been reused by something else, it is left alone.  Either way an import leaks no descriptor.
+struct FdId { dev_t dev; ino_t ino; bool ok; };
+inline FdId fd_identity(int fd) { struct stat st; FdId r = {0, 0, false}; if (fstat(fd, &st) == 0) { r.dev = st.st_dev; r.ino = st.st_ino; r.ok = true; } return r; }
+inline void close_if_still_ours(int fd, const FdId& id) {
+    if (fd < 0 || !id.ok) return;
+    const FdId now = fd_identity(fd);
+    if (now.ok && now.dev == id.dev && now.ino == id.ino) (void)close(fd);
+}
+
 struct Part {                      // one row partition of the frame
     bhray_dev* dev = nullptr;      // non-null: rendered by this ctx
     int device = -1;
@@ -241,6 +254,8 @@ struct bhray_ctx {
     hipEvent_t read_ev[64] = {nullptr};
     uint64_t read_tickets = 0;
     std::vector<void*> external;           // bhray_import_external_fd: hipExternalMemory_t handles, by mapped pointer (pairs: ptr, handle)
+    std::vector<int> external_fd;          // ... and the duplicated descriptor each import handed to the runtime, with what it referred to then
+    std::vector<FdId> external_fd_id;
     std::vector<WaitEvent> wait_pool;      // bhray_wait_stream: one event per call until the next render has consumed them
     int last_slot = 0; uint32_t last_sub = 0;
     uint64_t frames_staged = 0;
@@ -468,6 +483,7 @@ void group_free(bhray_ctx* c) {
     for (auto& e : c->read_ev) if (e) (void)hipEventDestroy(e);
     if (c->d_xchg && !c->ranks.empty()) { (void)hipSetDevice(c->ranks[0].device); (void)hipFree(c->d_xchg); }
     for (size_t i = 0; i + 1 < c->external.size(); i += 2) if (c->external[i + 1]) (void)hipDestroyExternalMemory((hipExternalMemory_t)c->external[i + 1]);
+    for (size_t i = 0; i < c->external_fd.size(); i++) close_if_still_ours(c->external_fd[i], c->external_fd_id[i]);
     for (WaitEvent& w : c->wait_pool) if (w.ev) { (void)hipSetDevice(w.device); (void)hipEventDestroy(w.ev); }
 }
 
@@ -1062,60 +1078,71 @@ int bhray_rebalance_slabs(uint32_t H, uint32_t world, const uint32_t* b_in, cons
     return BHRAY_OK;
 }
 
+// What a partition costs its GPU per frame, in integrator steps issued by a wave ("wave-steps"): the steps its trace waves issued (counted
+// by the kernels: FrameLaunch::work - a property of the rays and of how they share waves, not of what else the GPU is doing or of how many
+// frames are in flight) plus the pixels its classify launches visit, an HBM-bound pass, at their price in wave-steps; on the root also the
+// pixels it receives and de-interleaves.  The prices are ratios of measured rates on MI355X (1920x1080: a wave-step of the RK kernel 207
+// VALU instructions at ~0.7 of the issue rate = ~590 SIMD-cycles, of the Euler kernel 92 at ~0.52 = ~350; classify 21 SIMD-cycles of a
+// saturated device per pixel; profiles/EXPERIMENTS.md R5.2), fitted against the ranks' wall times in profiles/r05_rebalance_emulated.json.
+// BHRAY_REBALANCE_PRICES="classify_rk,classify_euler,gather" overrides (tuning).
+struct RebalancePrices { double classify[2]; double gather; };
+RebalancePrices rebalance_prices() {
+    RebalancePrices p = {{0.035, 0.06}, 0.05};
+    if (const char* e = getenv("BHRAY_REBALANCE_PRICES")) { double a, b, g; if (sscanf(e, "%lf,%lf,%lf", &a, &b, &g) == 3 && a >= 0 && b >= 0 && g >= 0) { p.classify[0] = a; p.classify[1] = b; p.gather = g; } }
+    return p;
+}
+
 int bhray_rebalance(bhray_ctx* c, bhray_rebalance_info* out) {
     if (!c) return BHRAY_E_INVALID;
     ENTER(c);
     if (out) memset(out, 0, sizeof *out);
-    if (!(c->cfg.flags & (BHRAY_F_TIMING | BHRAY_F_TIMING_SPARSE))) return gfail(c, BHRAY_E_STATE, "bhray_rebalance needs a ctx created with BHRAY_F_TIMING or BHRAY_F_TIMING_SPARSE");
-    if (c->world < 2 || c->single) return gfail(c, BHRAY_E_STATE, "bhray_rebalance needs a ctx that gathers (device_count >= 2, or gather = BHRAY_GATHER_RCCL); a host that moves the tiles itself balances with bhray_rebalance_slabs");
+    if (c->world < 2 || c->single) return gfail(c, BHRAY_E_STATE, "bhray_rebalance needs a ctx that gathers (device_count >= 2, or gather = BHRAY_GATHER_RCCL); a host that moves the tiles itself balances with bhray_get_work + bhray_rebalance_slabs");
+    if (c->cfg.flags & BHRAY_F_FUSED) return gfail(c, BHRAY_E_STATE, "the partition of a BHRAY_F_FUSED ctx is fixed");
     const uint32_t N = c->world, H = c->cfg.frame_h;
     // a ctx created with interleaved stripes starts from equal slabs
     uint32_t cur[BHRAY_MAX_DEVICES + 1];
     const bool was_slabs = c->cfg.partition == BHRAY_PARTITION_SLABS;
     for (uint32_t p = 0; p <= N; p++) cur[p] = was_slabs ? c->cfg.slab_row0[p] : (uint32_t)((uint64_t)H * p / N);
     { int rc = group_sync(c); if (rc) return rc; }
-    double ms[BHRAY_MAX_DEVICES] = {0}, extra[BHRAY_MAX_DEVICES] = {0};
+    const RebalancePrices price = rebalance_prices();
+    bhray_details det; memcpy(&det, c->threaded ? c->u_det : c->u_det, sizeof det);
+    double cost[BHRAY_MAX_DEVICES] = {0}, extra[BHRAY_MAX_DEVICES] = {0};
     uint32_t frames = 0;
     bool have[BHRAY_MAX_DEVICES] = {false};
+    int method = -1;
     for (uint32_t q = 0; q < N; q++) {
         Part& p = c->parts[q];
         if (!p.dev) continue;
-        bhray_timing t;
-        DEV(c, p.dev, dev_get_timing(p.dev, &t));
-        if (t.frames == 0) continue;
+        double ws = 0.0, px = 0.0; uint32_t n = 0; int m = 0;
+        DEV(c, p.dev, dev_get_work(p.dev, &ws, &px, &n, &m));
+        if (n == 0) continue;
         have[q] = true;
-        ms[q] = (t.trace_exec_launches ? (double)t.trace_exec_ms : (double)t.trace_ms) / (double)t.frames;
-        if (q == c->root || !c->root_local) frames = t.frames;
+        method = m;
+        cost[q] = ws + price.classify[m ? 0 : 1] * px;
+        if (q == c->root || !c->root_local) frames = n;
     }
-    if (c->root_local) {                                         // the root's de-interleave: work that stays with the root whatever its rows
-        GHIP(c, hipSetDevice(root_part(c)->device));
-        for (GroupSlot& G : c->gslots) {
-            if (!G.timed) continue;
-            float a = 0, b = 0;
-            GHIP(c, hipEventElapsedTime(&a, G.tev[0], G.tev[1])); GHIP(c, hipEventElapsedTime(&b, G.tev[1], G.tev[2]));
-            c->gather_ms += a; c->deint_ms += b; G.timed = false;
-        }
-        if (c->gathers) extra[c->root] = (double)c->deint_ms / ((double)c->gathers * (double)c->B);
-        c->gather_ms = 0; c->deint_ms = 0; c->gathers = 0;
-    }
+    (void)det;
+    if (method < 0) return gfail(c, BHRAY_E_STATE, "bhray_rebalance: nothing rendered since the ctx was created");
+    // the root's share of the gather: every pixel of the other partitions is received and de-interleaved there (with BHRAY_F_GATHER_SKY at half the bytes)
+    extra[c->root] = price.gather * (c->gather_sky ? 0.5 : 1.0) * (double)c->cfg.frame_w * (double)(H - (cur[c->root + 1] - cur[c->root]));
     if (c->ranks.size() == 1 && c->comm_size > 1) {
-        // one process per GPU: everybody learns everybody's numbers (2 floats per rank) over the communicator, on the communication stream
+        // one process per GPU: everybody learns everybody's number over the communicator, on the communication stream
         Rccl* R = rccl();
         if (!R) return gfail(c, BHRAY_E_COMM, "%s", g_rccl.error.c_str());
         CommRank& cr = c->ranks[0];
         GHIP(c, hipSetDevice(cr.device));
         if (!c->d_xchg) GHIP(c, hipMalloc(&c->d_xchg, (2 + 2 * (size_t)N) * sizeof(float)));
         const uint32_t me = c->cfg.row_rank;
-        float mine[2] = {have[me] ? (float)ms[me] : -1.0f, (float)extra[me]};
+        float mine[2] = {have[me] ? (float)cost[me] : -1.0f, 0.0f};
         GHIP(c, hipMemcpyAsync(c->d_xchg, mine, sizeof mine, hipMemcpyHostToDevice, cr.stream));
         GNCCL(c, R, R->AllGather(c->d_xchg, c->d_xchg + 2, 2, ncclFloat32, cr.comm, cr.stream));
         std::vector<float> all(2 * (size_t)N);
         GHIP(c, hipMemcpyAsync(all.data(), c->d_xchg + 2, all.size() * sizeof(float), hipMemcpyDeviceToHost, cr.stream));
         GHIP(c, hipStreamSynchronize(cr.stream));
-        for (uint32_t q = 0; q < N; q++) { have[q] = all[2 * q] >= 0.0f; ms[q] = have[q] ? all[2 * q] : 0.0; extra[q] = all[2 * q + 1]; }
+        for (uint32_t q = 0; q < N; q++) { have[q] = all[2 * q] >= 0.0f; cost[q] = have[q] ? all[2 * q] : 0.0; }
     }
-    // a partition without rows measures nothing and that is fine; a partition WITH rows and no measurement means no frame was timed yet
-    for (uint32_t q = 0; q < N; q++) if (cur[q + 1] > cur[q] && !have[q]) return gfail(c, BHRAY_E_STATE, "bhray_rebalance: no timed frame since the previous call (partition %u)", q);
+    // a partition without rows measures nothing and that is fine; a partition WITH rows and no measurement means it has not rendered yet
+    for (uint32_t q = 0; q < N; q++) if (cur[q + 1] > cur[q] && !have[q]) return gfail(c, BHRAY_E_STATE, "bhray_rebalance: partition %u has rendered no frame yet", q);
     if (c->row_weight.size() != H) c->row_weight.assign(H, 0.0);
     // the frames to come are expected one period's displacement of the hole's projection further on (a camera that keeps pitching)
     double shift = 0.0;
@@ -1124,8 +1151,8 @@ int bhray_rebalance(bhray_ctx* c, bhray_rebalance_info* out) {
     c->hole_row_prev = c->hole_row; c->hole_row_prev_valid = c->hole_row_valid;
     uint32_t next[BHRAY_MAX_DEVICES + 1];
     double predicted = 0.0, before = 0.0;
-    for (uint32_t q = 0; q < N; q++) before = std::max(before, ms[q] + extra[q]);
-    { int rc = bhray_rebalance_slabs(H, N, cur, ms, extra, shift, c->row_weight.data(), next, &predicted); if (rc) return gfail(c, rc, "bhray_rebalance_slabs failed"); }
+    for (uint32_t q = 0; q < N; q++) before = std::max(before, cost[q] + extra[q]);
+    { int rc = bhray_rebalance_slabs(H, N, cur, cost, extra, shift, c->row_weight.data(), next, &predicted); if (rc) return gfail(c, rc, "bhray_rebalance_slabs failed"); }
     c->rebalances++;
     bool differ = !was_slabs;
     for (uint32_t p = 0; p <= N; p++) differ = differ || next[p] != cur[p];
@@ -1134,9 +1161,26 @@ int bhray_rebalance(bhray_ctx* c, bhray_rebalance_info* out) {
     if (out) {
         out->partitions = N; out->applied = apply ? 1u : 0u; out->frames = frames;
         for (uint32_t p = 0; p <= N; p++) out->slab_row0[p] = apply ? next[p] : cur[p];
-        for (uint32_t q = 0; q < N; q++) { out->part_ms[q] = (float)ms[q]; out->extra_ms[q] = (float)extra[q]; }
-        out->slowest_ms_before = (float)before; out->slowest_ms_predicted = (float)predicted;
+        for (uint32_t q = 0; q < N; q++) { out->part_cost[q] = (float)cost[q]; out->extra_cost[q] = (float)extra[q]; }
+        out->slowest_before = (float)before; out->slowest_predicted = (float)predicted;
     }
+    return BHRAY_OK;
+}
+
+// What the frames still held by the frame slots cost the partition(s) of this ctx (see bhray_rebalance): for a host that balances by itself.
+int bhray_get_work(bhray_ctx* c, double* wave_steps_per_frame, double* classify_pixels_per_frame, uint32_t* frames) {
+    if (!c || !wave_steps_per_frame || !classify_pixels_per_frame) return BHRAY_E_INVALID;
+    ENTER(c);
+    if (c->gather) { int rc = group_sync(c); if (rc) return rc; }
+    double ws = 0.0, px = 0.0; uint32_t n = 0;
+    for (Part& p : c->parts) {
+        if (!p.dev) continue;
+        double a = 0.0, b = 0.0; uint32_t k = 0; int m = 0;
+        DEV(c, p.dev, dev_get_work(p.dev, &a, &b, &k, &m));
+        ws += a; px += b; n = std::max(n, k);
+    }
+    *wave_steps_per_frame = ws; *classify_pixels_per_frame = px;
+    if (frames) *frames = n;
     return BHRAY_OK;
 }
 
@@ -1484,6 +1528,7 @@ int bhray_import_external_fd(bhray_ctx* c, int fd, size_t bytes, void** dev_ptr)
     // the runtime owns an imported descriptor (CUDA semantics): hand it a duplicate, the caller keeps the original (include/bhray.h)
     const int own = dup(fd);
     if (own < 0) return gfail(c, BHRAY_E_INVALID, "dup(fd %d) failed: not an open descriptor", fd);
+    const FdId own_id = fd_identity(own);
     hipExternalMemoryHandleDesc hd; memset(&hd, 0, sizeof hd);
     hd.type = hipExternalMemoryHandleTypeOpaqueFd;
     hd.handle.fd = own;
@@ -1495,8 +1540,9 @@ int bhray_import_external_fd(bhray_ctx* c, int fd, size_t bytes, void** dev_ptr)
     bd.offset = 0; bd.size = bytes;
     void* p = nullptr;
     e = hipExternalMemoryGetMappedBuffer(&p, em, &bd);
-    if (e != hipSuccess || !p) { (void)hipDestroyExternalMemory(em); return gfail(c, BHRAY_E_HIP, "hipExternalMemoryGetMappedBuffer: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess || !p) { (void)hipDestroyExternalMemory(em); close_if_still_ours(own, own_id); return gfail(c, BHRAY_E_HIP, "hipExternalMemoryGetMappedBuffer: %s", hipGetErrorString(e)); }
     c->external.push_back(p); c->external.push_back((void*)em);
+    c->external_fd.push_back(own); c->external_fd_id.push_back(own_id);
     *dev_ptr = p;
     return BHRAY_OK;
 }
@@ -1508,6 +1554,8 @@ int bhray_release_external(bhray_ctx* c, void* dev_ptr) {
         { int rc = bhray_sync(c); if (rc) return rc; }
         hipError_t e = hipDestroyExternalMemory((hipExternalMemory_t)c->external[i + 1]);
         c->external.erase(c->external.begin() + (long)i, c->external.begin() + (long)i + 2);
+        close_if_still_ours(c->external_fd[i / 2], c->external_fd_id[i / 2]);
+        c->external_fd.erase(c->external_fd.begin() + (long)(i / 2)); c->external_fd_id.erase(c->external_fd_id.begin() + (long)(i / 2));
         if (e != hipSuccess) return gfail(c, BHRAY_E_HIP, "hipDestroyExternalMemory: %s", hipGetErrorString(e));
         return BHRAY_OK;
     }
@@ -1603,6 +1651,12 @@ int bhray_read_sky(bhray_ctx* c, uint16_t* dst, size_t pitch) {
 int bhray_sky_device_ptr(bhray_ctx* c, void** p, size_t* bytes) {
     if (!c || !p) return BHRAY_E_INVALID;
     if (c->single) { DEV(c, c->parts[0].dev, dev_sky_device_ptr(c->parts[0].dev, p, bytes)); return BHRAY_OK; }
+    ENTER(c);
+    *p = nullptr;
+    if (c->root_local) {                 // the same rule as the reads: an image resolved from an earlier frame of this slot position is stale
+        const GroupSlot& GS = c->gslots[(size_t)c->last_slot];
+        if (!GS.sky[c->last_sub] || GS.sky_frame_no[c->last_sub] != GS.frame_no[c->last_sub]) return gfail(c, BHRAY_E_STATE, "bhray_resolve_sky has not been called for this frame");
+    }
     *p = c->root_local ? (void*)c->gslots[(size_t)c->last_slot].sky[c->last_sub] : nullptr;
     if (bytes) *bytes = c->root_local ? frame_pixels(c) * sizeof(uint2) : 0;
     return BHRAY_OK;

@@ -169,7 +169,12 @@ struct FrameLaunch {
     int blocks;            // predict (one launch, all levels): this level's own block count
     const FusedFrame* fz;  // fused ladder: this frame's tile graph and queues (nullptr otherwise)
     unsigned long long* span; // trace, entry 0 of a timed launch: [0] max(~first block start) [1] max(last block end), device wall clock; nullptr: untimed
+    unsigned long long* work; // trace, entry 0 of a launch: work[blockIdx & (BHRAY_WORK_WORDS - 1)] += integrator steps this wave ISSUED for the frames of the batch
+                              // (a step costs the wave the same whether 1 or 64 of its lanes march): what the batch's rays cost this GPU, whatever else shares
+                              // it - the measure bhray_rebalance balances.  Counted in whole batches of BHRAY_REL_BATCH steps.
 };
+#define BHRAY_WORK_WORDS 16      // counters per frame (the waves of a launch spread over them: one word would serialise 2 048 atomics at every launch's end)
+#define BHRAY_QCTL_WORDS (2 * BHRAY_MAX_LEVELS + 2 * BHRAY_WORK_WORDS)   // 32-bit words of a frame's control block: queue counts / heads, then the work counters (64-bit)
 
 // classify / predict: a 256-thread block covers a rectangle of BX x BY 8x8-pixel tiles (4 waves, BX*BY/4 tiles each in turn)
 #ifndef BHRAY_CLASSIFY_BX

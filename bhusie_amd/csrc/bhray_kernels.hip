@@ -811,6 +811,18 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #ifndef BHRAY_WITH_PAIR
 #define BHRAY_WITH_PAIR 0        // 1 (make pair -> libbhray_pair.so): the dense RK kernel without meshes marches TWO rays per lane on packed FP32 (bhray_pair.inc)
 #endif
+#ifndef BHRAY_PAIR_RK
+#define BHRAY_PAIR_RK 1          // pair build: the dense RK kernel marches two rays per lane ...
+#endif
+#ifndef BHRAY_PAIR_RK_V
+#define BHRAY_PAIR_RK_V v2       // ... on packed FP32 (v2) or as two interleaved scalar streams (s2)
+#endif
+#ifndef BHRAY_PAIR_EULER
+#define BHRAY_PAIR_EULER 1       // pair build: the dense Euler kernel too ...
+#endif
+#ifndef BHRAY_PAIR_EULER_V
+#define BHRAY_PAIR_EULER_V s2    // ... as two interleaved scalar streams (the Euler step is almost all one dependent chain per ray)
+#endif
 #ifndef BHRAY_WITH_FUSED
 #define BHRAY_WITH_FUSED 0       // 1 (make fused -> libbhray_fused.so): the fused ladder, BHRAY_F_FUSED - measured slower than the launch-per-level ladder, a tested option
 #endif
@@ -873,6 +885,11 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
 #endif
     constexpr bool COLD_LDS = (DENSE && !MODELS) || (MODELS && BHRAY_MESH_COLD_LDS != 0);
     __shared__ float cold_lds[COLD_LDS ? (8 + BHRAY_HIT_LDS) * BHRAY_TRACE_THREADS : 1];
+    // Integrator steps this wave issues for the frames of the batch -> Fb[0].work at the kernel's end.  Wave-uniform: a scalar register.
+    // Counted in whole batches of steps, where the step loop is entered (a batch cut short by its last ray counts in full), and for the
+    // whole launch rather than per frame: the count of a batch's steps kept live across the loop cost the Euler kernel 1-2 %, a flush
+    // per frame the mesh variant 11-18 vector spills (profiles/EXPERIMENTS.md R5.2).
+    unsigned work_steps = 0;
     // mesh variant: the short traversal stacks (trace_ray_model) live in LDS
     // (dynamic LDS: with a static array the compiler assumes 64 KB of LDS per CU - gfx950 has 160 KB -, concludes that occupancy is
     // LDS-limited and gives up the 64-VGPR budget of 8 waves per SIMD: 142-152 VGPRs, 3 waves)
@@ -1186,6 +1203,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
         }
 
         // ---- a batch of integrator steps (ray.wgsl:522-553) for lanes inside the sphere
+        if (__any(mode == M_REL)) work_steps += (unsigned)BHRAY_REL_BATCH;
         for (int k = 0; k < BHRAY_REL_BATCH; k++) {       // (unrolled by 2 / 4 to let prev = curr become renaming: -1 % / 0 %, measured)
             if (!__any(mode == M_REL)) break;
             if (COUNT && lane == 0) cnt[10]++;
@@ -1200,6 +1218,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
             }
         }
     }
+
     if (COUNT) {
         for (int k = 3; k < 12; k++) {
             unsigned long long v = cnt[k];
@@ -1213,6 +1232,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
         }
     }
     }   // frames of the batch
+    if (!FZ && work_steps != 0u && Fb[0].work && lanes_below(~0ull) == 0u) atomicAdd(&Fb[0].work[blockIdx.x & (BHRAY_WORK_WORDS - 1)], (unsigned long long)work_steps);
 #ifndef BHRAY_NO_SPAN
     if (Fb[0].span && threadIdx.x == 0) atomicMax(&Fb[0].span[1], (unsigned long long)wall_clock64());
 #endif
@@ -1400,11 +1420,16 @@ hipError_t launch_trace(const FrameParams* Pb, const FrameLaunch* Fb, int nb, in
                         int grid_blocks, hipStream_t s) {
     if (nb <= 0) return hipSuccess;
 #if BHRAY_WITH_PAIR
-    if (eval == 0 && method == 1 && !models && dense) {
+    if (eval == 0 && !models && dense && (method == 1 ? BHRAY_PAIR_RK != 0 : BHRAY_PAIR_EULER != 0)) {
         (void)hipGetLastError();
         const dim3 grid((grid_blocks * 256 + BHRAY_TRACE_THREADS - 1) / BHRAY_TRACE_THREADS);
-        if (count) hipLaunchKernelGGL((trace_pair_kernel<true>), grid, dim3(BHRAY_TRACE_THREADS), pair_dyn_lds_bytes, s, Pb, Fb, nb, err_flag);
-        else hipLaunchKernelGGL((trace_pair_kernel<false>), grid, dim3(BHRAY_TRACE_THREADS), pair_dyn_lds_bytes, s, Pb, Fb, nb, err_flag);
+        if (method == 1) {
+            if (count) hipLaunchKernelGGL((trace_pair_kernel<true, 1, BHRAY_PAIR_RK_V>), grid, dim3(BHRAY_TRACE_THREADS), pair_dyn_lds_bytes, s, Pb, Fb, nb, err_flag);
+            else hipLaunchKernelGGL((trace_pair_kernel<false, 1, BHRAY_PAIR_RK_V>), grid, dim3(BHRAY_TRACE_THREADS), pair_dyn_lds_bytes, s, Pb, Fb, nb, err_flag);
+        } else {
+            if (count) hipLaunchKernelGGL((trace_pair_kernel<true, 0, BHRAY_PAIR_EULER_V>), grid, dim3(BHRAY_TRACE_THREADS), pair_dyn_lds_bytes, s, Pb, Fb, nb, err_flag);
+            else hipLaunchKernelGGL((trace_pair_kernel<false, 0, BHRAY_PAIR_EULER_V>), grid, dim3(BHRAY_TRACE_THREADS), pair_dyn_lds_bytes, s, Pb, Fb, nb, err_flag);
+        }
         return hipGetLastError();
     }
 #endif
@@ -1434,8 +1459,9 @@ static const void* trace_kernel_ptr(int method, int has_models, int count, int d
 int trace_blocks_per_cu(int method, int has_models, int count, int dense, int eval) {
     int n = 0;
 #if BHRAY_WITH_PAIR
-    if (eval == 0 && method == 1 && !has_models && dense) {
-        const void* fp = count ? (const void*)trace_pair_kernel<true> : (const void*)trace_pair_kernel<false>;
+    if (eval == 0 && !has_models && dense && (method == 1 ? BHRAY_PAIR_RK != 0 : BHRAY_PAIR_EULER != 0)) {
+        const void* fp = method == 1 ? (count ? (const void*)trace_pair_kernel<true, 1, BHRAY_PAIR_RK_V> : (const void*)trace_pair_kernel<false, 1, BHRAY_PAIR_RK_V>)
+                                     : (count ? (const void*)trace_pair_kernel<true, 0, BHRAY_PAIR_EULER_V> : (const void*)trace_pair_kernel<false, 0, BHRAY_PAIR_EULER_V>);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fp, BHRAY_TRACE_THREADS, pair_dyn_lds_bytes) != hipSuccess || n < 1) n = 2;
         n = n * BHRAY_TRACE_THREADS / 256;
         return n < 1 ? 1 : n;

@@ -122,13 +122,13 @@ assert C.sizeof(BhrayNode) == 32 and C.sizeof(BhrayTriangle) == 24
 # every symbol include/bhray.h declares: name -> (restype, argtypes)
 class BhrayRebalanceInfo(C.Structure):
     """bhray_rebalance_info (include/bhray.h)"""
-    _fields_ = [("partitions", C.c_uint32), ("applied", C.c_uint32), ("slab_row0", C.c_uint32 * 17), ("part_ms", C.c_float * 16), ("extra_ms", C.c_float * 16),
-                ("slowest_ms_before", C.c_float), ("slowest_ms_predicted", C.c_float), ("frames", C.c_uint32)]
+    _fields_ = [("partitions", C.c_uint32), ("applied", C.c_uint32), ("slab_row0", C.c_uint32 * 17), ("part_cost", C.c_float * 16), ("extra_cost", C.c_float * 16),
+                ("slowest_before", C.c_float), ("slowest_predicted", C.c_float), ("frames", C.c_uint32)]
 
     def as_dict(self):
         n = int(self.partitions)
-        return {"partitions": n, "applied": bool(self.applied), "slab_row0": [int(v) for v in self.slab_row0[:n + 1]], "part_ms": [float(v) for v in self.part_ms[:n]],
-                "extra_ms": [float(v) for v in self.extra_ms[:n]], "slowest_ms_before": float(self.slowest_ms_before), "slowest_ms_predicted": float(self.slowest_ms_predicted),
+        return {"partitions": n, "applied": bool(self.applied), "slab_row0": [int(v) for v in self.slab_row0[:n + 1]], "part_cost": [float(v) for v in self.part_cost[:n]],
+                "extra_cost": [float(v) for v in self.extra_cost[:n]], "slowest_before": float(self.slowest_before), "slowest_predicted": float(self.slowest_predicted),
                 "frames": int(self.frames)}
 
 
@@ -154,6 +154,7 @@ SYMBOLS = {
     "bhray_get_partition": (C.c_int, [vp, P(u32), P(u32)]),
     "bhray_rebalance_slabs": (C.c_int, [u32, u32, P(u32), P(C.c_double), P(C.c_double), C.c_double, P(C.c_double), P(u32), P(C.c_double)]),
     "bhray_rebalance": (C.c_int, [vp, P(BhrayRebalanceInfo)]),
+    "bhray_get_work": (C.c_int, [vp, P(C.c_double), P(C.c_double), P(u32)]),
     "bhray_set_materials": (C.c_int, [vp, vp, sz]),
     "bhray_set_texture": (C.c_int, [vp, C.c_int, vp, u32, u32]),
     "bhray_upload_model_uniform": (C.c_int, [vp, u32, vp, sz]),
@@ -208,7 +209,11 @@ SYMBOLS = {
 
 
 def declare(L):
+    import os
+    old_build = os.environ.get("BHRAY_AB_OLD_BUILD") == "1"      # kernel A/B against a library built from an earlier tree (profiles/jobs/ab.sh): symbols it lacks are not bound
     for name, (res, args) in SYMBOLS.items():
+        if old_build and not hasattr(L, name):
+            continue
         f = getattr(L, name)          # AttributeError if the library does not export it
         f.restype = res
         f.argtypes = args

@@ -185,8 +185,14 @@ class RayPass:
         check(self._L.bhray_get_partition(self._h, a, C.byref(n)), self._h, self._L)
         return [int(v) for v in a[:n.value + 1]]
 
+    def work(self):
+        """(integrator steps the trace waves issued, pixels the classify launches visited) per frame, over the frames the slots still hold (bhray_get_work)"""
+        ws, px, n = C.c_double(), C.c_double(), C.c_uint32()
+        check(self._L.bhray_get_work(self._h, C.byref(ws), C.byref(px), C.byref(n)), self._h, self._L)
+        return float(ws.value), float(px.value), int(n.value)
+
     def rebalance(self) -> dict:
-        """New slab bounds from the times the ctx measured since the last call (timing=True or "sparse"); applied when they promise >= 2 % (bhray_rebalance)."""
+        """New slab bounds from the work the ctx's kernels counted for the frames in its slots; applied when they promise >= 2 % (bhray_rebalance)."""
         info = BhrayRebalanceInfo()
         check(self._L.bhray_rebalance(self._h, C.byref(info)), self._h, self._L)
         return info.as_dict()

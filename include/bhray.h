@@ -312,30 +312,35 @@ int bhray_balance_slabs(const bhray_config* cfg, const uint64_t* const* row_work
  *   not reallocate).  One process per GPU: every rank calls it with the same bounds before its next bhray_render.  Not with BHRAY_F_FUSED.
  * bhray_rebalance_slabs: pure host arithmetic behind bhray_rebalance, exposed so that a host can balance by its own measurements.
  *   row_weight[frame_h] is the caller's persistent estimate of what every frame row costs (all zero before the first call); the call
- *   rescales the rows of every partition so that their sum is that partition's measured part_ms (the shape inside a partition is
- *   kept: it is what earlier calls learned), then finds the bounds that minimise the largest (sum of weights + extra_ms[p]) over
- *   contiguous partitions.  extra_ms (may be NULL) = work of a partition that does not move with its rows (the root's gather).
+ *   rescales the rows of every partition so that their sum is that partition's measured part_cost (the shape inside a partition is
+ *   kept: it is what earlier calls learned), then finds the bounds that minimise the largest (sum of weights + extra_cost[p]) over
+ *   contiguous partitions.  extra_cost (may be NULL) = work of a partition that does not move with its rows (the root's gather).
  *   shift_rows: the frames to come are expected to show what was measured this many rows further down (a camera that pitches moves
  *   the rows the hole projects to); the learned weights are shifted before the bounds are found.  0 for a scene at rest.
- * bhray_rebalance: the same from what the ctx measures by itself - needs BHRAY_F_TIMING or BHRAY_F_TIMING_SPARSE: the execution spans
- *   the trace kernels stamp (bhray_timing.trace_exec_ms) of the frames since the previous call, per partition, and on the root the
- *   de-interleave of the gathered tiles as its extra work; shift_rows = how far the frame row the hole projects to (from the uniforms
- *   of bhray_set_uniforms) moved since the previous call.  No counting build, no calibration frame.  The new bounds are applied
- *   (bhray_set_partition) when they promise at least 2 % less for the slowest partition.  One process per GPU: collective - every rank
- *   calls it at the same point of its frame sequence; the times travel over the ctx's communicator (one small all-gather).
+ * bhray_get_work: what the frames still held by the frame slots cost this ctx's partition(s), per frame: the integrator steps its trace
+ *   waves ISSUED (counted by the kernels in every build: a wave pays for a step whether 1 or 64 of its lanes march - this is the GPU
+ *   time of the march, independent of what else shares the GPU and of how many frames are in flight) and the pixels its classify
+ *   launches visit (an HBM-bound pass).  Waits for the frames in flight.
+ * bhray_rebalance: new bounds from that measure, per partition, in wave-steps: steps issued + classified pixels at their price in
+ *   wave-steps (0.035 for the RK kernel on MI355X, 0.06 for Euler) and, on the root, the pixels it receives and de-interleaves (0.05
+ *   each) as work that does not move with its rows; shift_rows = how far the frame row the hole projects to (from the uniforms of
+ *   bhray_set_uniforms) moved since the previous call.  No counting build, no calibration frame, no timing flags.  The new bounds are
+ *   applied (bhray_set_partition) when they promise at least 2 % less for the slowest partition.  One process per GPU: collective -
+ *   every rank calls it at the same point of its frame sequence; the numbers travel over the ctx's communicator (one small all-gather).
  *   Call it every second or so of frames: it waits for the frames in flight.                                                      */
 typedef struct bhray_rebalance_info {
     uint32_t partitions;
     uint32_t applied;                                 /* 1: the partition was changed                                              */
     uint32_t slab_row0[BHRAY_MAX_DEVICES + 1];        /* the bounds in force after the call                                         */
-    float    part_ms[BHRAY_MAX_DEVICES];              /* measured: trace-kernel execution per frame and partition                   */
-    float    extra_ms[BHRAY_MAX_DEVICES];             /* measured: work that does not move with the rows (root: de-interleave)       */
-    float    slowest_ms_before, slowest_ms_predicted; /* max over partitions of part_ms + extra_ms; what the new bounds promise     */
+    float    part_cost[BHRAY_MAX_DEVICES];            /* measured, wave-steps per frame: steps issued + classified pixels at their price */
+    float    extra_cost[BHRAY_MAX_DEVICES];           /* modelled, same unit: work that does not move with the rows (root: receive + de-interleave) */
+    float    slowest_before, slowest_predicted;       /* max over partitions of part_cost + extra_cost; what the new bounds promise */
     uint32_t frames;                                  /* frames the measurement covers (partition of this rank / the root)          */
 } bhray_rebalance_info;
 int bhray_set_partition(bhray_ctx* ctx, const uint32_t* slab_row0 /* partitions + 1 entries */);
-int bhray_rebalance_slabs(uint32_t frame_h, uint32_t partitions, const uint32_t* slab_row0, const double* part_ms, const double* extra_ms,
+int bhray_rebalance_slabs(uint32_t frame_h, uint32_t partitions, const uint32_t* slab_row0, const double* part_cost, const double* extra_cost,
                           double shift_rows, double* row_weight, uint32_t* slab_row0_out, double* slowest_predicted /* may be NULL */);
+int bhray_get_work(bhray_ctx* ctx, double* wave_steps_per_frame, double* classify_pixels_per_frame, uint32_t* frames /* may be NULL */);
 int bhray_rebalance(bhray_ctx* ctx, bhray_rebalance_info* out /* may be NULL */);
 /* The partition in force: partitions + 1 bounds when it is contiguous slabs; BHRAY_E_STATE for interleaved stripes.              */
 int bhray_get_partition(const bhray_ctx* ctx, uint32_t* slab_row0 /* BHRAY_MAX_DEVICES + 1 entries */, uint32_t* partitions);
@@ -414,8 +419,8 @@ int bhray_bind_output(bhray_ctx* ctx, void* dev_ptr, size_t bytes);
  *     the frame (hipImportExternalMemory) and returns a device pointer for bhray_bind_output.  The library imports a dup() of the
  *     descriptor: hipImportExternalMemory follows the CUDA rule that an imported fd belongs to the runtime afterwards, so the
  *     CALLER'S fd stays the caller's - usable and closable at any time after the call returns - whatever the runtime does with the
- *     duplicate (ROCm 7.2 does not say whether hipDestroyExternalMemory closes it; the library does not, so an import costs at most one
- *     descriptor).  The handle type is the opaque-fd one also for dma-buf descriptors; where tests/test_gpu_handoff.py skips (export or
+ *     duplicate (ROCm 7.2 does not say whether hipDestroyExternalMemory closes it: bhray_release_external / bhray_destroy close the
+ *     duplicate themselves if its number still refers to the file it was duplicated from, so an import leaks no descriptor either way).  The handle type is the opaque-fd one also for dma-buf descriptors; where tests/test_gpu_handoff.py skips (export or
  *     import refused by the driver) this path is unverified on that system.  Ordering: bhray_sync, or an exported semaphore the host
  *     signals from a stream it ordered with bhray_signal_stream.
  * (2) asynchronous read-back: bhray_read_hdr_async enqueues the device->host copy of the most recently enqueued frame (SDMA: no CU

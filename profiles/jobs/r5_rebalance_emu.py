@@ -48,41 +48,61 @@ def run(frames, **kw):
             rp.set_uniforms(*u); rp.render()
         rp.sync(); best = min(best, (time.perf_counter() - t0) / len(frames) * 1e3)
     tm = rp.timing()
+    ws, px, _ = rp.work()
     rp.close()
     span = (tm.trace_exec_ms / tm.frames) if tm.frames else 0.0
-    return best, span
+    return best, span, ws, px
 
 
 out = {"frame": [W, H], "partitions": N, "period_frames": PERIOD, "periods": PERIODS, "frames_per_batch": FPB,
        "hole_row_first_last": [round(hole_row(0), 1), round(hole_row(total - 1), 1)], "one_gpu_ms_per_frame": [], "policies": {}}
 one = []
 for k in range(PERIODS):
-    w1, _ = run(U[k * PERIOD:(k + 1) * PERIOD])
+    w1 = run(U[k * PERIOD:(k + 1) * PERIOD])[0]
     one.append(w1)
 out["one_gpu_ms_per_frame"] = [round(v, 5) for v in one]
 print("one GPU:", out["one_gpu_ms_per_frame"], flush=True)
 
-def policy(name, follow, shift):
+KAPPA = float(os.environ.get("EMU_KAPPA", "0.035"))             # classified pixels in wave-steps (bhray_rebalance's price for the RK kernel)
+
+
+def measure(signal, r):
+    wall, span, ws, px = r
+    return {"wall": wall, "span": span, "work": ws + KAPPA * px}[signal]
+
+
+def policy(name, follow, shift, signal):
     w = np.zeros(H)
     b = [H * p // N for p in range(N + 1)]
     # a scene at rest first: three rounds on the first period's frames (what a host does before the camera starts to move)
     for _ in range(3):
-        spans = [run(U[:PERIOD], row_rank=q, row_world=N, slab_row0=b, frames_per_batch=FPB)[1] for q in range(N)]
-        b, _ = B.rebalance_slabs(H, b, spans, w)
+        m = [measure(signal, run(U[:PERIOD], row_rank=q, row_world=N, slab_row0=b, frames_per_batch=FPB)) for q in range(N)]
+        b, _ = B.rebalance_slabs(H, b, m, w)
     rec = []
     for k in range(PERIODS):
         fr = U[k * PERIOD:(k + 1) * PERIOD]
         res = [run(fr, row_rank=q, row_world=N, slab_row0=b, frames_per_batch=FPB) for q in range(N)]
-        walls, spans = [r[0] for r in res], [r[1] for r in res]
-        rec.append({"period": k, "slab_row0": list(b), "rank_wall_ms": [round(v, 5) for v in walls], "rank_span_ms": [round(v, 5) for v in spans],
+        walls = [r[0] for r in res]
+        rec.append({"period": k, "slab_row0": list(b), "rank_wall_ms": [round(v, 5) for v in walls], "rank_span_ms": [round(r[1], 5) for r in res],
+                    "rank_wave_steps": [round(r[2], 1) for r in res], "rank_classify_pixels": [round(r[3], 1) for r in res],
                     "slowest_rank_ms": round(max(walls), 5), "scaling": round(one[k] / max(walls), 3), "wall_imbalance": round(max(walls) / (sum(walls) / N), 3)})
         print(name, rec[-1]["period"], rec[-1]["scaling"], rec[-1]["wall_imbalance"], b, flush=True)
         if follow:
             sh = (hole_row((k + 1) * PERIOD - 1) - hole_row(k * PERIOD)) if shift else 0.0      # one period's displacement, as bhray_rebalance takes it from the uniforms
-            b, _ = B.rebalance_slabs(H, b, spans, w, shift_rows=sh)
-    out["policies"][name] = {"periods": rec, "scaling_min": min(r["scaling"] for r in rec), "scaling_mean": round(sum(r["scaling"] for r in rec) / len(rec), 3)}
+            b, _ = B.rebalance_slabs(H, b, [measure(signal, r) for r in res], w, shift_rows=sh)
+    out["policies"][name] = {"signal": signal, "periods": rec, "scaling_min": min(r["scaling"] for r in rec), "scaling_mean": round(sum(r["scaling"] for r in rec) / len(rec), 3)}
 
-for name, follow, shift in (("fixed", False, False), ("follow", True, False), ("follow+shift", True, True)):
-    policy(name, follow, shift)
+for name, follow, shift, signal in [p_ for p_ in (("fixed", False, False, "work"), ("spans+shift", True, True, "span"), ("work+shift (bhray_rebalance)", True, True, "work"), ("wall+shift (reference: the ranks' own wall times)", True, True, "wall"))
+                                    if not os.environ.get("EMU_POLICIES") or p_[0].split()[0] in os.environ["EMU_POLICIES"].split(",")]:
+    policy(name, follow, shift, signal)
+# what a wave-step and a classified pixel cost: least squares of the ranks' wall times over all periods and policies
+A, y = [], []
+for pol in out["policies"].values():
+    for r in pol["periods"]:
+        for q in range(N):
+            A.append([r["rank_wave_steps"][q], r["rank_classify_pixels"][q], 1.0]); y.append(r["rank_wall_ms"][q])
+coef = np.linalg.lstsq(np.asarray(A), np.asarray(y), rcond=None)[0]
+out["fit_wall_ms"] = {"per_wave_step": float(coef[0]), "per_classified_pixel": float(coef[1]), "constant": float(coef[2]), "pixel_in_wave_steps": float(coef[1] / coef[0]) if coef[0] else None}
+print("fit", out["fit_wall_ms"])
 json.dump(out, open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r05_rebalance_emulated.json", "w"), indent=1)
 print({k: (v["scaling_min"], v["scaling_mean"]) for k, v in out["policies"].items()})

@@ -1,0 +1,17 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/s6; O=gpurun_out/s6
+export GPU_MAX_HW_QUEUES=64
+timeout 900 python -m pytest tests/test_gpu_repartition.py -x -q -m gpu 2>&1 | tail -8
+one() {  # label lib workload-args
+  for cfg in "--steps 20 --warmup 5" "--steps 400 --warmup 32"; do
+    BHRAY_AB_OLD_BUILD=1 BHRAY_LIB=$2 timeout 300 python bench.py $cfg $3 --no-extra-legs --no-cpu-baseline --min-seconds 2 --sustained-steps 0 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', '$3', d['steps'], d['value'], d['ms_per_step'])"
+  done
+}
+for r in 1 2; do
+  for wl in "" "--integrator euler" "--workload mesh"; do
+    one r4 $GRAFT_REPO_ROOT/profiles/variants/libbhray_r4.so "$wl"
+    one now "" "$wl"
+  done
+done 2>&1 | tee $O/ab_work_counter.txt
+timeout 1500 python profiles/jobs/r5_rebalance_emu.py $O/rebalance_emulated.json 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -40

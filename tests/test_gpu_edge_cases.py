@@ -248,3 +248,44 @@ def test_fuzz_every_build_and_mode_delivers_the_same_frame(monkeypatch):
             both_nan = np.isnan(f) & np.isnan(ref)
             a, b = np.where(both_nan, 0.0, f).astype(np.float32), np.where(both_nan, 0.0, ref).astype(np.float32)
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"trial {trial}: {name} differs from the latency build ({cfg.sizes()}, method {method})"
+
+
+@pytest.mark.parametrize("grid", [1, 3, 8, 40])
+def test_a_batch_on_a_small_persistent_grid_traces_every_frame(monkeypatch, grid):
+    """The short queues of a batch's coarse launches are dealt out over the blocks whose own frame it is - which needs blocks for every
+    frame of the batch (bhray_kernels.hip: gridDim.x >= 4 * nb).  A grid smaller than that (BHRAY_TRACE_GRID: tuning runs, tiny devices)
+    must fall back to pulling from the queue head: every frame of the batch complete, byte for byte the frame of a ctx without batches."""
+    tex = T.textures()
+    cfg = B.ladder_for_frame((160, 90), 3, 3)
+    frames = [T.uniforms(integration_method=k & 1, time=0.3 * k) for k in range(6)]
+    want = []
+    monkeypatch.delenv("BHRAY_TRACE_GRID", raising=False)
+    monkeypatch.setenv("BHRAY_TRACE_DENSE", "0")                 # the latency build is the one that deals short queues out
+    for u in frames:
+        rp = gpu_frame(cfg, u, tex, frames_in_flight=1)
+        want.append(rp.read_hdr()); rp.close()
+    monkeypatch.setenv("BHRAY_TRACE_GRID", str(grid))            # persistent trace blocks per launch: fewer than 4 x frames_per_batch for 1, 3, 8
+    for spec in (0, 2):
+        rp = B.RayPass(cfg, device=0, frames_per_batch=3, frames_in_flight=2, speculative_levels=spec)
+        rp.set_textures(*tex)
+        for k, u in enumerate(frames):                          # batches of 3: two integrators alternate, so batches are also cut short by the variant change
+            rp.set_uniforms(*u); rp.render()
+            if k in (1, 2, 5):
+                assert np.array_equal(rp.read_hdr().view(np.uint32), want[k].view(np.uint32)), (grid, spec, k)
+        rp.close()
+    same = [T.uniforms(integration_method=1, time=0.1 * k) for k in range(5)]
+    ref = []
+    monkeypatch.delenv("BHRAY_TRACE_GRID", raising=False)
+    for u in same:
+        rp = gpu_frame(cfg, u, tex, frames_in_flight=1); ref.append(rp.read_hdr()); rp.close()
+    monkeypatch.setenv("BHRAY_TRACE_GRID", str(grid))
+    rp = B.RayPass(cfg, device=0, frames_per_batch=5, frames_in_flight=1)       # ONE batch of five frames of one variant: nb = 5
+    rp.set_textures(*tex)
+    bufs = [T.DeviceBuffer(160 * 90 * 16) for _ in same]
+    for u, b in zip(same, bufs):
+        rp.set_uniforms(*u); rp.bind_output(b.ptr.value, b.nbytes); rp.render()
+    rp.sync()
+    for k, b in enumerate(bufs):
+        assert np.array_equal(b.read(np.uint32), ref[k].view(np.uint32).ravel()), (grid, k)
+        b.free()
+    rp.close()

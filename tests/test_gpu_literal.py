@@ -359,4 +359,4 @@ def test_default_kernel_against_the_executed_shader_at_the_native_frame():
     _record({"config": "reference-native 1918x1081 adaptive RK, 6000 executed-shader sample pixels", "default_kernels_vs": "ray.wgsl as executed (oracle/wgsl_exec.py)",
              "by_kind": {name: {"fraction_within_1e-4_per_channel": round(a, 4), "fraction_within_1e-4_of_the_norm": round(b, 4)} for name, a, b in rows}})
     for name, f_ch, f_norm in rows:                                                  # the bounds of tests/test_wgsl_pin.py (the contract oracle = these kernels, bit for bit)
-        assert f_ch >= {"traced_escaped": 0.90, "border": 0.88}.get(name, 0.995) and f_norm >= 0.99, (name, f_ch, f_norm)
+        assert f_ch >= {"traced_escaped": 0.915, "border": 0.89}.get(name, 0.995) and f_norm >= 0.99, (name, f_ch, f_norm)

@@ -216,7 +216,7 @@ def test_contract_oracle_against_the_native_samples(native):
         #   copied 1.000 / 1.000   interpolated 0.999 / 1.000   traced_escaped 0.925 / 0.998   traced_disk 0.997 / 0.998   traced_captured 1 / 1   border 0.901 / 0.994
         # The traced-and-escaped rays of the LAST level are the 0.5 % of a frame's pixels that pass closest to the hole and still escape (everything
         # easier was interpolated): unit vectors carrying ~1e-6 of accumulated rounding, more than 1e-4 RELATIVE in a channel near zero.
-        lo_ch = {"traced_escaped": 0.90, "border": 0.88}.get(name, 0.995)
+        lo_ch = {"traced_escaped": 0.915, "border": 0.89}.get(name, 0.995)
         assert f_ch >= lo_ch and f_norm >= 0.99, (name, f_ch, f_norm)
 
 
