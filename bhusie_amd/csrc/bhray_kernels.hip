@@ -272,6 +272,9 @@ __device__ __forceinline__ bool hit_triangle(F3 pos, F3 dir, float t_min, float 
 #ifndef BHRAY_BVH_LDS_STACK
 #define BHRAY_BVH_LDS_STACK 8      // entries of the short traversal stack in LDS (16 KB per 256-thread block: 8 blocks per CU fit in 160 KB)
 #endif
+#ifndef BHRAY_BVH_WHILE_WHILE
+#define BHRAY_BVH_WHILE_WHILE 0    // 1: inner nodes and leaves in loops of their own (see trace_ray_model)
+#endif
 #ifndef BHRAY_MODEL_INLINE
 #define BHRAY_MODEL_INLINE __forceinline__   // the traversal inline, in a kernel budgeted for 5 waves per SIMD (96 VGPRs): the step loop stays free of spills and what is
                                              // parked around a flat phase is 116-156 bytes per lane once per phase.  As a __noinline__ call (rounds 2-3, 8 waves, 64 VGPRs)
@@ -305,6 +308,78 @@ __device__ BHRAY_MODEL_INLINE void trace_ray_model(const ModelDev& M, const BvhL
     int lev = 0;                      // tree level of the decision the current node's children are (root's children: 0)
     int sp = 0, held = 0;             // ring position; valid entries in the ring (<= D)
     int target = -1;                  // >= 0: re-descending to take the pending far child of that level
+#if BHRAY_BVH_WHILE_WHILE
+    // "while-while" form: every lane first walks inner nodes until it stands at a leaf (or is done), then the lanes that hold a leaf test
+    // their triangles together.  In the one-loop form below a lane at a leaf (<= 2 triangles, ~300 instructions) and a lane at an inner node
+    // (two box tests, ~80) take turns within every iteration; rays of one tile reach their leaves at different iterations, so most
+    // iterations paid for both.  Every lane still visits its own nodes in its own order: same hits, same counters, same equal-t ties.
+    bool alive = true;
+    // the pop of the one-loop form: the next node for this lane, or the end of its traversal
+    auto do_pop = [&]() {
+        if (pend == 0ull) { alive = false; return; }
+        const int k = 63 - __builtin_clzll(pend);               // the deepest level with a pending far child: the top of the stack, if it is still there
+        if (held > 0) {
+            sp--; held--;
+            const int2 e = lds.stack[(sp % D) * BHRAY_TRACE_THREADS];
+            contents = e.x; obj_count = e.y;
+            pend &= ~(1ull << k); wentfar |= 1ull << k;
+            lev = k + 1;
+        } else {                                                // its entry was overwritten: find it again from the root
+            target = k; contents = root_contents; obj_count = root_count; lev = 0;
+        }
+    };
+    while (alive) {
+        while (alive && obj_count == 0) {
+            if (lev >= BHRAY_BVH_STACK) { *err = BHRAY_E_BVH_DEPTH; alive = false; break; }
+            const float4* pair = M.nodes + 2 * (size_t)contents;
+            const float4 a_lo = pair[0], a_hi = pair[1], b_lo = pair[2], b_hi = pair[3];
+            float d1 = hit_aabb(pos, inv, a_lo, a_hi, mpos);
+            float d2 = hit_aabb(pos, inv, b_lo, b_hi, mpos);
+            int2 n1 = make_int2(__float_as_int(a_lo.w), __float_as_int(a_hi.w));
+            int2 n2 = make_int2(__float_as_int(b_lo.w), __float_as_int(b_hi.w));
+            if (d1 > d2) { float td = d1; d1 = d2; d2 = td; int2 tn = n1; n1 = n2; n2 = tn; }
+            const unsigned long long bit = 1ull << lev;
+            if (target >= 0) {                                      // re-descent: follow the recorded path, decide nothing
+                if (lev < target) {
+                    const int2 n = (wentfar & bit) ? n2 : n1;
+                    contents = n.x; obj_count = n.y; lev++;
+                } else {                                            // the pending far child itself
+                    pend &= ~bit; wentfar |= bit;
+                    contents = n2.x; obj_count = n2.y; lev++;
+                    target = -1;
+                }
+                continue;
+            }
+            if (COUNT) cnt[6]++;
+            if (d1 > closest.t) {
+                do_pop();
+            } else {
+                contents = n1.x; obj_count = n1.y;
+                wentfar &= ~bit;
+                if (d2 < closest.t) {                               // the far child will be visited, whatever closest.t becomes (as in the reference)
+                    pend |= bit;
+                    lds.stack[(sp % D) * BHRAY_TRACE_THREADS] = n2;
+                    sp++; held = held < D ? held + 1 : D;
+                }
+                lev++;
+            }
+        }
+        if (alive) {
+            for (int i = 0; i < obj_count; i++) {
+                const float4* g = M.leaf + 6 * (size_t)(contents + i);
+                const float4 A = g[0], B = g[1], Cc = g[2], N1 = g[3], N2 = g[4], N3 = g[5];
+                if (COUNT) cnt[7]++;
+                float t; F3 col, nrm;
+                if (hit_triangle(pos, dir, t_min, t_max, f3(A.x, A.y, A.z) + mpos, f3(B.x, B.y, B.z) + mpos,
+                                 f3(Cc.x, Cc.y, Cc.z) + mpos, f3(N1.x, N1.y, N1.z), f3(N2.x, N2.y, N2.z),
+                                 f3(N3.x, N3.y, N3.z), t, col, nrm)) {
+                    if (t < closest.t) { closest.hit = true; closest.t = t; closest.color = col; closest.opacity = 1.0f; normal_out = nrm; }
+                }
+            }
+            do_pop();
+        }
+    }
+#else
     for (;;) {
         bool pop = false;
         if (obj_count == 0) {
@@ -369,6 +444,7 @@ __device__ BHRAY_MODEL_INLINE void trace_ray_model(const ModelDev& M, const BvhL
             }
         }
     }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
