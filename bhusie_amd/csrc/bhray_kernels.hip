@@ -275,6 +275,9 @@ __device__ __forceinline__ bool hit_triangle(F3 pos, F3 dir, float t_min, float 
 #ifndef BHRAY_BVH_WHILE_WHILE
 #define BHRAY_BVH_WHILE_WHILE 0    // 1: inner nodes and leaves in loops of their own (see trace_ray_model)
 #endif
+#ifndef BHRAY_BVH_PREFETCH
+#define BHRAY_BVH_PREFETCH 0       // 1 (with BHRAY_BVH_WHILE_WHILE): request a dword of both children's data as soon as a pair has arrived (see trace_ray_model)
+#endif
 #ifndef BHRAY_MODEL_INLINE
 #define BHRAY_MODEL_INLINE __forceinline__   // the traversal inline, in a kernel budgeted for 5 waves per SIMD (96 VGPRs): the step loop stays free of spills and what is
                                              // parked around a flat phase is 116-156 bytes per lane once per phase.  As a __noinline__ call (rounds 2-3, 8 waves, 64 VGPRs)
@@ -314,6 +317,9 @@ __device__ BHRAY_MODEL_INLINE void trace_ray_model(const ModelDev& M, const BvhL
     // (two box tests, ~80) take turns within every iteration; rays of one tile reach their leaves at different iterations, so most
     // iterations paid for both.  Every lane still visits its own nodes in its own order: same hits, same counters, same equal-t ties.
     bool alive = true;
+#if BHRAY_BVH_PREFETCH
+    int pf0 = 0, pf1 = 0;
+#endif
     // the pop of the one-loop form: the next node for this lane, or the end of its traversal
     auto do_pop = [&]() {
         if (pend == 0ull) { alive = false; return; }
@@ -337,6 +343,19 @@ __device__ BHRAY_MODEL_INLINE void trace_ray_model(const ModelDev& M, const BvhL
             float d2 = hit_aabb(pos, inv, b_lo, b_hi, mpos);
             int2 n1 = make_int2(__float_as_int(a_lo.w), __float_as_int(a_hi.w));
             int2 n2 = make_int2(__float_as_int(b_lo.w), __float_as_int(b_hi.w));
+#if BHRAY_BVH_PREFETCH
+            // The traversal is a chain of dependent 64-byte loads: the next pair's address is known as soon as this pair has arrived, before the
+            // two box tests and the bookkeeping (~100 instructions) that decide WHICH child is next.  One dword of each child's own pair (or
+            // leaf) is requested now into two registers nobody reads: by the time the decision is made its line is in the CU's L1, and the real
+            // load of the next iteration hits there instead of in L2 / HBM.  (The registers stay reserved for the whole loop - "+v" on every
+            // iteration - so a late write-back lands nowhere else; the compiler's vmcnt accounting only ever over-waits for loads it does not know.)
+            {
+                const float4* c1 = n1.y == 0 ? M.nodes + 2 * (size_t)n1.x : M.leaf + 6 * (size_t)n1.x;
+                const float4* c2 = n2.y == 0 ? M.nodes + 2 * (size_t)n2.x : M.leaf + 6 * (size_t)n2.x;
+                asm volatile("global_load_dword %0, %1, off" : "+v"(pf0) : "v"(c1) : "memory");
+                asm volatile("global_load_dword %0, %1, off" : "+v"(pf1) : "v"(c2) : "memory");
+            }
+#endif
             if (d1 > d2) { float td = d1; d1 = d2; d2 = td; int2 tn = n1; n1 = n2; n2 = tn; }
             const unsigned long long bit = 1ull << lev;
             if (target >= 0) {                                      // re-descent: follow the recorded path, decide nothing
