@@ -89,11 +89,11 @@ def test_default_build_has_no_pair_march_and_the_pair_step_is_next_ray_rk_on_2_v
         return out
 
     scalar = stage_lines(body(src, "void next_ray_rk(F3 q0"))
-    packed = stage_lines(body(inc, "void next_ray_rk_pair(P3 q0"))
+    packed = stage_lines(body(inc, "void next_ray_rk_pair(P3T<V> q0"))
     assert len(scalar) == len(packed) == 9
     for a, b in zip(scalar, packed):
         b = b.replace("P3", "F3").replace("pmadd3", "fmadd3").replace("pcross", "fcross")
-        b = re.sub(r"sp\(([A-Z0-9]+)\)", r"\1", b)
+        b = re.sub(r"sp<V>\(([A-Z0-9]+)\)", r"\1", b)
         assert a == b, (a, b)
     mk = open(os.path.join(ROOT, "bhusie_amd", "csrc", "Makefile")).read()
     assert "-DBHRAY_WITH_PAIR=1" in mk and "pair:" in mk
