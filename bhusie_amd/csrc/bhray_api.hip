@@ -253,6 +253,7 @@ void derive_frame(const bhray_dev* c, FrameParams& P) {
     P.bh[0] = bpos.x; P.bh[1] = bpos.y; P.bh[2] = bpos.z;
     memcpy(P.bn, bh.normal, 12);
     P.bn_len = length(ld3(bh.normal));
+    P.cull_outer_pad = bh.accretion_disk_outer + 0.0501f; P.cull_plane_c1 = 1.0101f * P.bn_len; P.cull_plane_c2 = 1.01e-4f * P.bn_len;
     P.inner = bh.accretion_disk_inner; P.outer = bh.accretion_disk_outer;
     P.rot_speed = bh.rotation_speed; P.R = bh.relativity_sphere_radius;
     P.show_tex = bh.show_disk_texture; P.show_shift = bh.show_red_shift;

@@ -1092,6 +1092,43 @@ RebalancePrices rebalance_prices() {
     return p;
 }
 
+// cost[q] / extra[q] / have[q] of the partitions THIS ctx renders (the others stay 0 / false), for the bounds `cur`: see above
+static int partition_costs(bhray_ctx* c, const uint32_t* cur, double* cost, double* extra, bool* have, uint32_t* frames) {
+    const RebalancePrices price = rebalance_prices();
+    const uint32_t N = c->world, H = c->cfg.frame_h;
+    int method = -1;
+    for (uint32_t q = 0; q < N; q++) {
+        Part& p = c->parts[q];
+        if (!p.dev) continue;
+        double ws = 0.0, px = 0.0; uint32_t n = 0; int m = 0;
+        DEV(c, p.dev, dev_get_work(p.dev, &ws, &px, &n, &m));
+        if (n == 0) continue;
+        have[q] = true;
+        method = m;
+        cost[q] = ws + price.classify[m ? 0 : 1] * px;
+        if (frames && (q == c->root || !c->root_local)) *frames = n;
+    }
+    if (method < 0) return gfail(c, BHRAY_E_STATE, "nothing rendered since the ctx was created (or since its partition was set): no work has been counted");
+    // the root's share of the gather: every pixel of the other partitions is received and de-interleaved there (with BHRAY_F_GATHER_SKY at half the bytes)
+    if (c->root_local) extra[c->root] = price.gather * (c->gather_sky ? 0.5 : 1.0) * (double)c->cfg.frame_w * (double)(H - (cur[c->root + 1] - cur[c->root]));
+    return BHRAY_OK;
+}
+
+int bhray_get_partition_costs(bhray_ctx* c, double* cost, double* extra, uint32_t* frames) {
+    if (!c || !cost || !extra) return BHRAY_E_INVALID;
+    ENTER(c);
+    if (c->world < 2 || c->single) return gfail(c, BHRAY_E_STATE, "bhray_get_partition_costs needs a ctx that gathers (device_count >= 2, or gather = BHRAY_GATHER_RCCL)");
+    const uint32_t N = c->world, H = c->cfg.frame_h;
+    uint32_t cur[BHRAY_MAX_DEVICES + 1];
+    const bool was_slabs = c->cfg.partition == BHRAY_PARTITION_SLABS;
+    for (uint32_t p = 0; p <= N; p++) cur[p] = was_slabs ? c->cfg.slab_row0[p] : (uint32_t)((uint64_t)H * p / N);
+    { int rc = group_sync(c); if (rc) return rc; }
+    bool have[BHRAY_MAX_DEVICES] = {false};
+    for (uint32_t q = 0; q < N; q++) { cost[q] = 0.0; extra[q] = 0.0; }
+    if (frames) *frames = 0;
+    return partition_costs(c, cur, cost, extra, have, frames);
+}
+
 int bhray_rebalance(bhray_ctx* c, bhray_rebalance_info* out) {
     if (!c) return BHRAY_E_INVALID;
     ENTER(c);
@@ -1104,27 +1141,10 @@ int bhray_rebalance(bhray_ctx* c, bhray_rebalance_info* out) {
     const bool was_slabs = c->cfg.partition == BHRAY_PARTITION_SLABS;
     for (uint32_t p = 0; p <= N; p++) cur[p] = was_slabs ? c->cfg.slab_row0[p] : (uint32_t)((uint64_t)H * p / N);
     { int rc = group_sync(c); if (rc) return rc; }
-    const RebalancePrices price = rebalance_prices();
-    bhray_details det; memcpy(&det, c->threaded ? c->u_det : c->u_det, sizeof det);
     double cost[BHRAY_MAX_DEVICES] = {0}, extra[BHRAY_MAX_DEVICES] = {0};
     uint32_t frames = 0;
     bool have[BHRAY_MAX_DEVICES] = {false};
-    int method = -1;
-    for (uint32_t q = 0; q < N; q++) {
-        Part& p = c->parts[q];
-        if (!p.dev) continue;
-        double ws = 0.0, px = 0.0; uint32_t n = 0; int m = 0;
-        DEV(c, p.dev, dev_get_work(p.dev, &ws, &px, &n, &m));
-        if (n == 0) continue;
-        have[q] = true;
-        method = m;
-        cost[q] = ws + price.classify[m ? 0 : 1] * px;
-        if (q == c->root || !c->root_local) frames = n;
-    }
-    (void)det;
-    if (method < 0) return gfail(c, BHRAY_E_STATE, "bhray_rebalance: nothing rendered since the ctx was created");
-    // the root's share of the gather: every pixel of the other partitions is received and de-interleaved there (with BHRAY_F_GATHER_SKY at half the bytes)
-    extra[c->root] = price.gather * (c->gather_sky ? 0.5 : 1.0) * (double)c->cfg.frame_w * (double)(H - (cur[c->root + 1] - cur[c->root]));
+    { int rc = partition_costs(c, cur, cost, extra, have, &frames); if (rc) return rc; }
     if (c->ranks.size() == 1 && c->comm_size > 1) {
         // one process per GPU: everybody learns everybody's number over the communicator, on the communication stream
         Rccl* R = rccl();
@@ -1133,13 +1153,13 @@ int bhray_rebalance(bhray_ctx* c, bhray_rebalance_info* out) {
         GHIP(c, hipSetDevice(cr.device));
         if (!c->d_xchg) GHIP(c, hipMalloc(&c->d_xchg, (2 + 2 * (size_t)N) * sizeof(float)));
         const uint32_t me = c->cfg.row_rank;
-        float mine[2] = {have[me] ? (float)cost[me] : -1.0f, 0.0f};
+        float mine[2] = {have[me] ? (float)cost[me] : -1.0f, (float)extra[me]};
         GHIP(c, hipMemcpyAsync(c->d_xchg, mine, sizeof mine, hipMemcpyHostToDevice, cr.stream));
         GNCCL(c, R, R->AllGather(c->d_xchg, c->d_xchg + 2, 2, ncclFloat32, cr.comm, cr.stream));
         std::vector<float> all(2 * (size_t)N);
         GHIP(c, hipMemcpyAsync(all.data(), c->d_xchg + 2, all.size() * sizeof(float), hipMemcpyDeviceToHost, cr.stream));
         GHIP(c, hipStreamSynchronize(cr.stream));
-        for (uint32_t q = 0; q < N; q++) { have[q] = all[2 * q] >= 0.0f; cost[q] = have[q] ? all[2 * q] : 0.0; }
+        for (uint32_t q = 0; q < N; q++) { have[q] = all[2 * q] >= 0.0f; cost[q] = have[q] ? all[2 * q] : 0.0; extra[q] = all[2 * q + 1]; }
     }
     // a partition without rows measures nothing and that is fine; a partition WITH rows and no measurement means it has not rendered yet
     for (uint32_t q = 0; q < N; q++) if (cur[q + 1] > cur[q] && !have[q]) return gfail(c, BHRAY_E_STATE, "bhray_rebalance: partition %u has rendered no frame yet", q);

@@ -108,6 +108,7 @@ __device__ __forceinline__ bool hit_torus2d(F3 pos, F3 dir, float inner, float o
 struct HotParams {
     F3 bh, bn;
     float bn_len, inner, outer, R, ray_distance, feather, time_rot, step_size;
+    float outer_pad, plane_c1, plane_c2;      // black_hole_culls: outer + 0.05, 1.01 |n|, 1e-4 |n| (slightly more than the unfolded form's margins: rounded up)
     int max_iter, show_tex, show_shift;
     float M[9];
     TexDev disk, temp;
@@ -116,12 +117,15 @@ __device__ __forceinline__ float pin_sgpr(float v) { asm volatile("" : "+s"(v));
 __device__ __forceinline__ int pin_sgpr(int v) { asm volatile("" : "+s"(v)); return v; }
 __device__ __forceinline__ const uint8_t* pin_sgpr(const uint8_t* v) { asm volatile("" : "+s"(v)); return v; }
 __device__ __forceinline__ TexDev pin_sgpr(const TexDev& t) { TexDev r; r.rgba = pin_sgpr(t.rgba); r.w = pin_sgpr(t.w); r.h = pin_sgpr(t.h); return r; }
+template <bool FOLDED_CULLS = false>
 __device__ __forceinline__ HotParams load_hot(const FrameParams& P) {
     HotParams H;
     H.bh = f3(pin_sgpr(P.bh[0]), pin_sgpr(P.bh[1]), pin_sgpr(P.bh[2]));
     H.bn = f3(pin_sgpr(P.bn[0]), pin_sgpr(P.bn[1]), pin_sgpr(P.bn[2]));
     H.bn_len = pin_sgpr(P.bn_len);
     H.inner = pin_sgpr(P.inner); H.outer = pin_sgpr(P.outer); H.R = pin_sgpr(P.R);
+    if (FOLDED_CULLS) { H.outer_pad = pin_sgpr(P.cull_outer_pad); H.plane_c1 = pin_sgpr(P.cull_plane_c1); H.plane_c2 = P.cull_plane_c2; }      // formed on the host (gfx950 has no scalar float arithmetic)
+    else { H.outer_pad = 0.0f; H.plane_c1 = 0.0f; H.plane_c2 = 0.0f; }
     H.ray_distance = pin_sgpr(P.ray_distance); H.feather = pin_sgpr(P.feather);
     H.time_rot = pin_sgpr(P.time_rot); H.step_size = pin_sgpr(P.step_size);
     H.max_iter = pin_sgpr(P.max_iter); H.show_tex = pin_sgpr(P.show_tex); H.show_shift = pin_sgpr(P.show_shift);
@@ -193,13 +197,25 @@ __device__ __forceinline__ void shade_disk(const HotParams& P, F3 pos, F3 dir, f
 // (shade_disk) is run by the caller - the trace kernel defers it to a wave-uniform phase of its own.  rs holds the horizon
 // result (hit, t, colour 0, opacity 1) or "no hit".
 // The two cull predicates of a step (see above): can the segment reach the horizon / the disk at all?
+// FOLDED: the same three predicates with the frame's constants folded (the culls are not the shader's arithmetic: any form that stays
+// conservative by more than its own rounding will do - the margins are 1-5 %, the rounding 1e-7): pos_dist <= c + 1.05 t  <=>
+// pos_dist - 1.05 t <= c, one fused operation for both radial tests; the plane test's bound one fused operation - 4 vector instructions
+// per step less.  Measured (profiles/r05_ab_culls_folded.txt, three rounds): the mesh variant +2.4 % (20- and 400-frame blocks), the
+// no-mesh RK kernel -0.7 % / -1.0 %, Euler -1.3 %: fewer instructions, a worse schedule.  So the mesh variant folds, the others do not.
+template <bool FOLDED>
 __device__ __forceinline__ void black_hole_culls(const HotParams& H, F3 pos, float pos_dist, float t_max, bool& near_horizon, bool& near_disk) {
-    const float reach = 1.05f * t_max + 0.05f;
-    near_horizon = pos_dist <= 1.0f + reach;
     // signed plane distance from the hole-RELATIVE position: its rounding error (a few ulp of |pos - bh| <= outer + reach) does not
     // grow with |bh|, unlike n.bh - n.pos for a hole far from the origin
     const float numer = fdot(H.bh - pos, H.bn);
-    near_disk = (pos_dist <= H.outer + reach) & (fabsf(numer) <= (1.01f * t_max) * H.bn_len + 1e-4f * H.bn_len);     // & : no branch
+    if (FOLDED) {
+        const float e = __builtin_fmaf(t_max, -1.05f, pos_dist);
+        near_horizon = e <= 1.05f;
+        near_disk = (e <= H.outer_pad) & (fabsf(numer) <= __builtin_fmaf(t_max, H.plane_c1, H.plane_c2));     // & : no branch
+    } else {
+        const float reach = 1.05f * t_max + 0.05f;
+        near_horizon = pos_dist <= 1.0f + reach;
+        near_disk = (pos_dist <= H.outer + reach) & (fabsf(numer) <= (1.01f * t_max) * H.bn_len + 1e-4f * H.bn_len);     // & : no branch
+    }
 }
 __device__ __forceinline__ bool hit_black_hole_geom(const HotParams& H, F3 pos, F3 dir, bool near_horizon, bool near_disk, float t_min, float t_max, Hit& rs, float& td_out) {
     const F3 bpos = H.bh;
@@ -1049,7 +1065,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
         }
         if (thin_share != 0u && fi != 0) continue;
     }
-    const HotParams H = load_hot(P);
+    const HotParams H = load_hot<MODELS>(P);
     const F3 bpos = H.bh;
     const float t_max = 1e5f, t_min = 1e-8f;
 

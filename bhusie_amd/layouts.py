@@ -155,6 +155,7 @@ SYMBOLS = {
     "bhray_rebalance_slabs": (C.c_int, [u32, u32, P(u32), P(C.c_double), P(C.c_double), C.c_double, P(C.c_double), P(u32), P(C.c_double)]),
     "bhray_rebalance": (C.c_int, [vp, P(BhrayRebalanceInfo)]),
     "bhray_get_work": (C.c_int, [vp, P(C.c_double), P(C.c_double), P(u32)]),
+    "bhray_get_partition_costs": (C.c_int, [vp, P(C.c_double), P(C.c_double), P(u32)]),
     "bhray_set_materials": (C.c_int, [vp, vp, sz]),
     "bhray_set_texture": (C.c_int, [vp, C.c_int, vp, u32, u32]),
     "bhray_upload_model_uniform": (C.c_int, [vp, u32, vp, sz]),

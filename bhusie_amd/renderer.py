@@ -191,6 +191,13 @@ class RayPass:
         check(self._L.bhray_get_work(self._h, C.byref(ws), C.byref(px), C.byref(n)), self._h, self._L)
         return float(ws.value), float(px.value), int(n.value)
 
+    def partition_costs(self):
+        """(cost[partitions], extra[partitions]) of the partitions this ctx renders - bhray_rebalance's own numbers (bhray_get_partition_costs)"""
+        n = int(self.cfg.device_count) if self.cfg.device_count >= 2 else max(1, int(self.cfg.row_world))
+        cost, extra = (C.c_double * n)(), (C.c_double * n)()
+        check(self._L.bhray_get_partition_costs(self._h, cost, extra, None), self._h, self._L)
+        return [float(v) for v in cost], [float(v) for v in extra]
+
     def rebalance(self) -> dict:
         """New slab bounds from the work the ctx's kernels counted for the frames in its slots; applied when they promise >= 2 % (bhray_rebalance)."""
         info = BhrayRebalanceInfo()

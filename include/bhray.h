@@ -342,6 +342,10 @@ int bhray_rebalance_slabs(uint32_t frame_h, uint32_t partitions, const uint32_t*
                           double shift_rows, double* row_weight, uint32_t* slab_row0_out, double* slowest_predicted /* may be NULL */);
 int bhray_get_work(bhray_ctx* ctx, double* wave_steps_per_frame, double* classify_pixels_per_frame, uint32_t* frames /* may be NULL */);
 int bhray_rebalance(bhray_ctx* ctx, bhray_rebalance_info* out /* may be NULL */);
+/* The numbers bhray_rebalance works with, for the partitions THIS ctx renders (cost[q] and extra[q] of the others are 0; both arrays hold
+ * `partitions` entries): a launcher that has a channel of its own between its ranks (MPI, torch.distributed) sums the ranks' arrays,
+ * calls bhray_rebalance_slabs and hands every rank the same bounds for bhray_set_partition - no collective inside the library.     */
+int bhray_get_partition_costs(bhray_ctx* ctx, double* cost, double* extra, uint32_t* frames /* may be NULL */);
 /* The partition in force: partitions + 1 bounds when it is contiguous slabs; BHRAY_E_STATE for interleaved stripes.              */
 int bhray_get_partition(const bhray_ctx* ctx, uint32_t* slab_row0 /* BHRAY_MAX_DEVICES + 1 entries */, uint32_t* partitions);
 

@@ -123,7 +123,9 @@ def test_rebalance_follows_a_pitching_camera_and_every_frame_is_the_undivided_fr
     history, applied = [], 0
     for i in range(n):
         if i and i % 20 == 0:
+            cost, extra = rp.partition_costs()                   # the numbers a launcher with a channel of its own would sum over its ranks
             info = rp.rebalance()
+            assert np.allclose(cost, info["part_cost"], rtol=1e-5) and np.allclose(extra, info["extra_cost"], rtol=1e-5), (cost, info)
             assert info["partitions"] == 4 and info["frames"] > 0 and min(info["part_cost"]) > 0.0 and info["extra_cost"][0] > 0.0
             assert info["slab_row0"][0] == 0 and info["slab_row0"][-1] == 180 and info["slab_row0"] == rp.get_partition()
             applied += info["applied"]

@@ -78,6 +78,21 @@ def test_launcher_plumbing_world2_gloo(tmp_path):
         assert probe == [1.0, 1.5]
         b2 = bench.share_bounds(L, B.balance_slabs(cfg, bench.reweigh_by_probe(cfg, work, b, probe, 200), 2), 2)
         assert b2[1] > b[1], (b, b2)                                                                 # the slow partition gives rows away
+        # ... and the balance of round 5 (--partition library under a launcher): every rank hands in the cost of ITS partition only, the
+        # launcher sums them, the library's arithmetic gives both ranks the same bounds; rounds until nothing promises 2 % more
+        row_w = np.zeros(200)
+        cur = [0, 100, 200]
+        prof = 1.0 + 40.0 * np.exp(-((np.arange(200) - 60.0) / 15.0) ** 2)                           # the work sits in partition 0's rows
+        for _ in range(5):
+            cost = [0.0, 0.0]; cost[r] = float(prof[cur[r]:cur[r + 1]].sum())
+            extra = [3.0 if r == 0 else 0.0, 0.0]                                                    # the root's gather, known to the root only
+            h = bench.rebalance_over_launcher(L, (cost, extra), cur, row_w, 200)
+            assert h["extra_cost"] == [3.0, 0.0] and len(h["part_cost"]) == 2 and min(h["part_cost"]) > 0
+            cur = h["slab_row0"]
+        assert cur[1] < 80, cur
+        a0, a1 = prof[:cur[1]].sum() + 3.0, prof[cur[1]:].sum()
+        assert abs(a0 - a1) < 0.1 * max(a0, a1), (cur, a0, a1)
+        b2 = b2 + cur
         L.close()
         open(os.path.join({str(tmp_path)!r}, "ok%d" % r), "w").write(",".join(str(v) for v in b2))
     """))
