@@ -1672,6 +1672,7 @@ bool dev_take_launched(bhray_dev* c, int* slot, uint32_t* frames) {
     return true;
 }
 
+int* dev_err_flag(bhray_dev* c) { return c->d_err; }
 hipStream_t dev_slot_stream(bhray_dev* c, int slot) { return c->slots[(size_t)slot].stream; }
 hipEvent_t dev_slot_done(bhray_dev* c, int slot) { return c->slots[(size_t)slot].done; }
 

@@ -97,6 +97,7 @@ int  dev_next_position(bhray_dev* c, int* slot, uint32_t* sub);
 void dev_peek_position(const bhray_dev* c, uint64_t* batch_counter, uint32_t* pending, int* method, bool* models);
 // True when launches were enqueued since the last call; reports the slot and the number of frames of the (last) launched batch.
 bool dev_take_launched(bhray_dev* c, int* slot, uint32_t* frames);
+int* dev_err_flag(bhray_dev* c);                              // the engine's device-side error word (checked by dev_sync)
 hipStream_t dev_slot_stream(bhray_dev* c, int slot);
 hipEvent_t  dev_slot_done(bhray_dev* c, int slot);            // recorded behind the slot's last launch
 // sky.wgsl over an arbitrary RGBA32F image resident on this device, with this partition's sky texture

@@ -110,19 +110,9 @@ inline uint32_t part_rows(uint32_t frame_h, uint32_t world, uint32_t stripe, uin
 struct RowDesc { uint32_t src_row0; uint32_t part_rows; uint32_t frame_row; uint32_t pad; };
 struct FramePtrs { float4* p[BHRAY_MAX_FRAMES_PER_BATCH]; };
 
-// De-interleave: row j of the concatenated non-root tiles of frame k of the batch -> its row of frame k.
-// HBM-bound copy (16 B read + 16 B written per pixel); one block per row, consecutive lanes on consecutive float4s.
-__global__ __launch_bounds__(256) void deinterleave_kernel(const float4* __restrict__ staging, const FramePtrs frames,
-                                                           const RowDesc* __restrict__ table, const int width) {
-    const RowDesc t = table[blockIdx.x];
-    const int k = blockIdx.y;
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    const f4v* __restrict__ src = (const f4v*)(staging + ((size_t)t.src_row0 + (size_t)k * t.part_rows) * (size_t)width);
-    f4v* __restrict__ dst = (f4v*)(frames.p[k] + (size_t)t.frame_row * (size_t)width);
-    for (int x = threadIdx.x; x < width; x += 256) dst[x] = __builtin_nontemporal_load(src + x);   // staging is read once
-}
-
-// The same for the RGBA16F tiles of BHRAY_F_GATHER_SKY (8 B read + 8 B written per pixel).
+// De-interleave: row j of the concatenated non-root tiles of frame k of the batch -> its row of frame k: unpack_kernel below for the RGBA32F
+// frame (whose rows travel packed), deinterleave16_kernel for the RGBA16F tiles of BHRAY_F_GATHER_SKY (8 B read + 8 B written per pixel).
+// One block per row, consecutive lanes on consecutive pixels.
 struct SkyPtrs { uint2* p[BHRAY_MAX_FRAMES_PER_BATCH]; };
 __global__ __launch_bounds__(256) void deinterleave16_kernel(const uint2* __restrict__ staging, const SkyPtrs frames,
                                                              const RowDesc* __restrict__ table, const int width) {
@@ -152,6 +142,57 @@ inline void close_if_still_ours(int fd, const FdId& id) {
     if (now.ok && now.dev == id.dev && now.ino == id.ino) (void)close(fd);
 }
 
+// The wire format of the RGBA32F gather: a pixel's alpha is exactly 0 (an escape direction) or 1 (a colour) - ray.wgsl:589-594 and the grid's
+// copy / interpolate arms write nothing else - so a row of W pixels travels as 3 W floats (x, y, z) followed by ceil(W / 32) words of alpha
+// bits: 12.1 bytes per pixel instead of 16, the same frame bit for bit.  The links into the root are what bounds an 8-GPU 1080p run (every
+// frame's tiles over 7 links: profiles/EXPERIMENTS.md R5.7), so a quarter fewer bytes is a quarter more frames.  pack_kernel runs on a
+// partition's communication stream behind its render (HBM-bound, 28 bytes per pixel); unpack_kernel replaces the de-interleave on the root
+// (reads 12.1, writes 16).  A pixel whose alpha is neither 0 nor 1 (none can exist) raises the ctx's kernel error flag instead of being mangled.
+__host__ __device__ inline size_t packed_row_words(size_t W) { return 3 * W + (W + 31) / 32; }
+// (one launch packs the rows of ALL the partitions a GPU sends - one partition per GPU on a real node; the seven of a one-GPU test box)
+struct PackJobs { const float4* src[BHRAY_MAX_DEVICES]; uint32_t* dst[BHRAY_MAX_DEVICES]; int rows[BHRAY_MAX_DEVICES]; int row0[BHRAY_MAX_DEVICES + 1]; int n; };
+__global__ __launch_bounds__(256) void pack_kernel(const PackJobs jobs, const int width, int* __restrict__ err_flag) {
+    int j = 0;
+    while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.row0[j + 1]) j++;          // which partition this row belongs to (<= 16 entries, scalar)
+    const int r = (int)blockIdx.x - jobs.row0[j], rows = jobs.rows[j];
+    const size_t wpr = packed_row_words((size_t)width);
+    const float4* __restrict__ s = jobs.src[j] + ((size_t)blockIdx.y * (size_t)rows + (size_t)r) * (size_t)width;      // frame k of the batch, row r
+    uint32_t* __restrict__ d = jobs.dst[j] + ((size_t)blockIdx.y * (size_t)rows + (size_t)r) * wpr;
+    float* __restrict__ xyz = reinterpret_cast<float*>(d);
+    uint32_t* __restrict__ mask = d + 3 * (size_t)width;
+    bool bad = false;
+    for (int x0 = 0; x0 < width; x0 += 256) {
+        const int x = x0 + (int)threadIdx.x;
+        float4 p = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (x < width) {
+            p = s[x];
+            xyz[3 * (size_t)x] = p.x; xyz[3 * (size_t)x + 1] = p.y; xyz[3 * (size_t)x + 2] = p.z;
+            const uint32_t a = __float_as_uint(p.w);
+            bad = bad || (a != 0u && a != 0x3f800000u);
+        }
+        const unsigned long long m = __ballot(x < width && p.w != 0.0f);
+        const int lane = (int)(threadIdx.x & 63), w0 = (x0 + (int)(threadIdx.x & ~63u)) >> 5;     // first mask word of this wave's 64 pixels
+        if (lane == 0 && (w0 << 5) < width) mask[w0] = (uint32_t)m;
+        if (lane == 0 && ((w0 + 1) << 5) < width) mask[w0 + 1] = (uint32_t)(m >> 32);
+    }
+    if (bad) *err_flag = BHRAY_E_STATE;
+}
+__global__ __launch_bounds__(256) void unpack_kernel(const uint32_t* __restrict__ staging, const FramePtrs frames, const RowDesc* __restrict__ table, const int width) {
+    const RowDesc t = table[blockIdx.x];
+    const int k = blockIdx.y;
+    const size_t wpr = packed_row_words((size_t)width);
+    const uint32_t* __restrict__ s = staging + ((size_t)t.src_row0 + (size_t)k * t.part_rows) * wpr;
+    const float* __restrict__ xyz = reinterpret_cast<const float*>(s);
+    const uint32_t* __restrict__ mask = s + 3 * (size_t)width;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v* __restrict__ dst = (f4v*)(frames.p[k] + (size_t)t.frame_row * (size_t)width);
+    for (int x = threadIdx.x; x < width; x += 256) {
+        const uint32_t bit = (mask[x >> 5] >> (x & 31)) & 1u;
+        f4v o = {xyz[3 * (size_t)x], xyz[3 * (size_t)x + 1], xyz[3 * (size_t)x + 2], bit ? 1.0f : 0.0f};
+        dst[x] = o;
+    }
+}
+
 struct Part {                      // one row partition of the frame
     bhray_dev* dev = nullptr;      // non-null: rendered by this ctx
     int device = -1;
@@ -172,10 +213,11 @@ struct WaitEvent { hipEvent_t ev = nullptr; int device = -1; bool in_use = false
 
 struct GroupSlot {                 // per batch slot (same index as the devices' slots)
     float4* frames = nullptr;                 // root: B assembled frames
-    float4* staging = nullptr;                // root: tiles of the other partitions, [part][frame of batch][row][x]
     std::vector<float4*> send;                // per partition: packed rows of the batch's frames (local non-root partitions)
     std::vector<uint2*> send16;               // BHRAY_F_GATHER_SKY: the same rows after the partition's own sky pass (what is sent)
     uint2* staging16 = nullptr;               // BHRAY_F_GATHER_SKY, root: RGBA16F tiles of the other partitions (layout of `staging`)
+    std::vector<uint32_t*> sendp;             // RGBA32F gather: the packed rows that travel (pack_kernel: send[q] -> sendp[q])
+    uint32_t* stagingp = nullptr;             // ... and where the root receives them, [part][frame of batch][row][packed row] (unpack_kernel -> the frames)
     std::vector<hipEvent_t> sent;             // per partition: recorded behind its send
     hipEvent_t frame_done = nullptr;          // root: recorded behind the de-interleave
     float4* dst[BHRAY_MAX_FRAMES_PER_BATCH];  // root: destination of each frame of the batch staged here (own or caller-bound)
@@ -339,7 +381,29 @@ int group_gather(bhray_ctx* c, int si, uint32_t nb, const CommRank* only = nullp
             }
         }
     }
-    const size_t words = c->gather_sky ? 2 : 4;          // 32-bit words per pixel on the wire
+    const size_t wpr = c->gather_sky ? 2 * W : packed_row_words(W);          // 32-bit words per row on the wire (RGBA16F: 8 bytes per pixel; RGBA32F: packed, 12.1)
+    if (!c->gather_sky) {
+        // the rows that travel, packed (x, y, z + alpha bits): behind the render, on the communication stream of the GPU that sends them -
+        // one launch per GPU for all the partitions it sends
+        for (CommRank& cr : c->ranks) {
+            if (only && cr.rank != only->rank) continue;
+            PackJobs jobs; memset(&jobs, 0, sizeof jobs);
+            int* err_flag = nullptr;
+            for (uint32_t q = 0; q < c->world; q++) {
+                Part& p = c->parts[q];
+                if (q == c->root || !p.dev || p.rank != cr.rank || p.rows == 0) continue;
+                jobs.src[jobs.n] = G.send[q]; jobs.dst[jobs.n] = G.sendp[q]; jobs.rows[jobs.n] = (int)p.rows;
+                jobs.row0[jobs.n + 1] = jobs.row0[jobs.n] + (int)p.rows;
+                jobs.n++;
+                err_flag = dev_err_flag(p.dev);
+            }
+            if (jobs.n == 0) continue;
+            GHIP(c, hipSetDevice(cr.device));
+            (void)hipGetLastError();
+            hipLaunchKernelGGL(pack_kernel, dim3((unsigned)jobs.row0[jobs.n], nb), dim3(256), 0, cr.stream, jobs, (int)W, err_flag);
+            GHIP(c, hipGetLastError());
+        }
+    }
     if (rr && timing) { GHIP(c, hipSetDevice(rr->device)); GHIP(c, hipEventRecord(G.tev[0], rr->stream)); }
     // ONE group: every tile of the batch.  Sends and receives are issued in partition order, so the messages between
     // a pair of ranks (several partitions may share a rank) match in order.
@@ -354,15 +418,15 @@ int group_gather(bhray_ctx* c, int si, uint32_t nb, const CommRank* only = nullp
                 if (q == c->root || !mine(p) || p.rows == 0) continue;
                 CommRank* cr = rank_of(c, p);
                 GHIP(c, hipSetDevice(p.device));
-                GNCCL(c, R, R->Send(c->gather_sky ? (const void*)G.send16[q] : (const void*)G.send[q], (size_t)nb * p.rows * W * words, ncclFloat32, rp.rank, cr->comm, cr->stream));
+                GNCCL(c, R, R->Send(c->gather_sky ? (const void*)G.send16[q] : (const void*)G.sendp[q], (size_t)nb * p.rows * wpr, ncclFloat32, rp.rank, cr->comm, cr->stream));
             }
             if (rr) {
                 GHIP(c, hipSetDevice(rr->device));
                 for (uint32_t q = 0; q < c->world; q++) {
                     const Part& p = c->parts[q];
                     if (q == c->root || p.rows == 0) continue;
-                    void* into = c->gather_sky ? (void*)(G.staging16 + p.stage_row0 * W) : (void*)(G.staging + p.stage_row0 * W);
-                    GNCCL(c, R, R->Recv(into, (size_t)nb * p.rows * W * words, ncclFloat32, p.rank, rr->comm, rr->stream));
+                    void* into = c->gather_sky ? (void*)(G.staging16 + p.stage_row0 * W) : (void*)(G.stagingp + p.stage_row0 * wpr);
+                    GNCCL(c, R, R->Recv(into, (size_t)nb * p.rows * wpr, ncclFloat32, p.rank, rr->comm, rr->stream));
                 }
             }
             return BHRAY_OK;
@@ -393,7 +457,7 @@ int group_gather(bhray_ctx* c, int si, uint32_t nb, const CommRank* only = nullp
             FramePtrs fp; memset(&fp, 0, sizeof fp);
             for (uint32_t k = 0; k < nb; k++) fp.p[k] = G.dst[k];
             (void)hipGetLastError();          // a stale error of an unrelated earlier call must not be blamed on this launch
-            hipLaunchKernelGGL(deinterleave_kernel, dim3(c->table_rows, nb), dim3(256), 0, rr->stream, G.staging, fp, c->d_table, (int)W);
+            hipLaunchKernelGGL(unpack_kernel, dim3(c->table_rows, nb), dim3(256), 0, rr->stream, G.stagingp, fp, c->d_table, (int)W);
             GHIP(c, hipGetLastError());
         }
         if (c->gather_sky) for (uint32_t k = 0; k < nb; k++) G.sky_frame_no[k] = G.frame_no[k];      // the sky image of every frame of the batch is current
@@ -460,6 +524,7 @@ void group_free(bhray_ctx* c) {
         for (GroupSlot& G : c->gslots) {
             if (q < G.send.size() && G.send[q]) (void)hipFree(G.send[q]);
             if (q < G.send16.size() && G.send16[q]) (void)hipFree(G.send16[q]);
+            if (q < G.sendp.size() && G.sendp[q]) (void)hipFree(G.sendp[q]);
             if (q < G.sent.size() && G.sent[q]) (void)hipEventDestroy(G.sent[q]);
         }
     }
@@ -467,8 +532,8 @@ void group_free(bhray_ctx* c) {
         (void)hipSetDevice(c->parts[c->root].device);
         for (GroupSlot& G : c->gslots) {
             if (G.frames) (void)hipFree(G.frames);
-            if (G.staging) (void)hipFree(G.staging);
             if (G.staging16) (void)hipFree(G.staging16);
+            if (G.stagingp) (void)hipFree(G.stagingp);
             if (G.frame_done) (void)hipEventDestroy(G.frame_done);
             for (auto& e : G.tev) if (e) (void)hipEventDestroy(e);
             for (auto& s : G.sky) if (s) (void)hipFree(s);
@@ -538,6 +603,9 @@ int layout_gather(bhray_ctx* c, bool headroom) {
             if (c->gather_sky) {
                 if (G.send16[q]) { GHIP(c, hipFree(G.send16[q])); G.send16[q] = nullptr; }
                 GHIP(c, hipMalloc(&G.send16[q], (size_t)c->B * rows * W * sizeof(uint2)));
+            } else {
+                if (G.sendp[q]) { GHIP(c, hipFree(G.sendp[q])); G.sendp[q] = nullptr; }
+                GHIP(c, hipMalloc(&G.sendp[q], (size_t)c->B * rows * packed_row_words(W) * sizeof(uint32_t)));
             }
         }
         c->send_alloc[q] = rows;
@@ -547,7 +615,7 @@ int layout_gather(bhray_ctx* c, bool headroom) {
         if (c->staging_rows > c->staging_alloc) {
             const size_t rows = grown(c->staging_rows, (size_t)c->B * c->cfg.frame_h);
             for (GroupSlot& G : c->gslots) {
-                if (!c->gather_sky) { if (G.staging) { GHIP(c, hipFree(G.staging)); G.staging = nullptr; } GHIP(c, hipMalloc(&G.staging, rows * W * sizeof(float4))); }
+                if (!c->gather_sky) { if (G.stagingp) { GHIP(c, hipFree(G.stagingp)); G.stagingp = nullptr; } GHIP(c, hipMalloc(&G.stagingp, rows * packed_row_words(W) * sizeof(uint32_t))); }
                 else { if (G.staging16) { GHIP(c, hipFree(G.staging16)); G.staging16 = nullptr; } GHIP(c, hipMalloc(&G.staging16, rows * W * sizeof(uint2))); }
             }
             c->staging_alloc = rows;
@@ -914,7 +982,7 @@ int bhray_create(const bhray_config* cfg_in, bhray_ctx** out) {
     c->gslots.resize(c->nslots);
     for (GroupSlot& G : c->gslots) {
         memset(G.dst, 0, sizeof G.dst); memset(G.sky, 0, sizeof G.sky);
-        G.send.assign(c->world, nullptr); G.sent.assign(c->world, nullptr); G.send16.assign(c->world, nullptr);
+        G.send.assign(c->world, nullptr); G.sent.assign(c->world, nullptr); G.send16.assign(c->world, nullptr); G.sendp.assign(c->world, nullptr);
         for (uint32_t q = 0; q < c->world; q++) {
             Part& p = c->parts[q];
             if (!p.dev || q == c->root) continue;
@@ -1209,7 +1277,7 @@ int bhray_get_gather_info(const bhray_ctx* c, bhray_gather_info* out) {
     memset(out, 0, sizeof *out);
     out->partitions = c->world;
     out->root = c->root;
-    const uint64_t rowb = (uint64_t)c->cfg.frame_w * (c->gather_sky ? 8u : 16u);
+    const uint64_t rowb = c->gather_sky ? (uint64_t)c->cfg.frame_w * 8u : (uint64_t)packed_row_words(c->cfg.frame_w) * 4u;    // bytes of one row on the wire
     for (uint32_t q = 0; q < c->parts.size(); q++) {
         const Part& p = c->parts[q];
         if (p.dev) out->local_partitions++;

@@ -230,7 +230,9 @@ enum {                                  /* bhray_config.flags */
  *     uniforms replicated, coarse ladder rows recomputed per partition, nothing exchanged during the levels), and every
  *     bhray_render also enqueues the gather of the row tiles to the GPU of partition gather_root (RCCL: grouped
  *     ncclSend/ncclRecv over xGMI, one message per partition per batch) and the de-interleave of the stripes into the
- *     frame (a HIP kernel on the root GPU).  Output calls (bhray_read_hdr, bhray_hdr_device_ptr, bhray_bind_output,
+ *     frame (a HIP kernel on the root GPU).  On the wire a row of the RGBA32F frame is its x, y, z floats plus ONE BIT of alpha per
+ *     pixel (alpha is exactly 0 or 1: ray.wgsl:589-594): 12.1 bytes per pixel instead of 16, packed behind the render on the sending
+ *     GPU and unpacked by the de-interleave - the assembled frame is the same bits (bhray_gather_info counts the bytes that travel).  Output calls (bhray_read_hdr, bhray_hdr_device_ptr, bhray_bind_output,
  *     bhray_resolve_sky) then refer to the WHOLE frame on the root GPU; bhray_local_rows = frame_h.  row_rank/row_world
  *     are ignored (row_world is set to N).  A device may appear more than once (functional tests on a one-GPU box): its
  *     partitions share one RCCL rank and their tiles travel as send/recv-to-self.

@@ -47,7 +47,7 @@ def test_set_partition_moves_the_bounds_of_a_multi_device_ctx_and_the_frames_sta
         rp.set_uniforms(*u); rp.render()
         if i % 2 == 0 or plan is not None or i == len(frames) - 1:
             assert np.array_equal(rp.read_hdr().view(np.uint32), want[i].view(np.uint32)), (kw, i, plan)
-    assert rp.gather_info()["bytes_received_per_frame"] == (110 - (108 - 104 if kw.get("gather_root") == 2 else 100)) * 200 * 16
+    assert rp.gather_info()["bytes_received_per_frame"] == (110 - (108 - 104 if kw.get("gather_root") == 2 else 100)) * (3 * 200 + 7) * 4
     with pytest.raises(B.BhrayError):
         rp.set_partition([0, 50, 40, 80, 110])
     with pytest.raises(B.BhrayError):

@@ -73,7 +73,7 @@ def test_balanced_slabs_assemble_the_single_ctx_frame(nparts, root):
     rp = B.RayPass(cfg, devices=[0] * nparts, gather_root=root, slab_row0=bounds, frames_in_flight=2, frames_per_batch=3, speculative_levels=2)
     info = rp.gather_info()
     assert info["partitions"] == nparts
-    assert info["bytes_received_per_frame"] == (110 - (bounds[root + 1] - bounds[root])) * 200 * 16
+    assert info["bytes_received_per_frame"] == (110 - (bounds[root + 1] - bounds[root])) * (3 * 200 + 7) * 4         # packed rows: x, y, z + alpha bits
     rp.set_textures(*tex)
     rp.set_uniforms(*u)
     for _ in range(7):                                       # two full batches + a partial one; slots reused
