@@ -302,7 +302,7 @@ struct bhray_ctx {
     int last_slot = 0; uint32_t last_sub = 0;
     uint64_t frames_staged = 0;
     bool rendered = false;
-    bool failed = false;                   // a collective failed half way: the communicator's state is unknown, every later gather is refused
+    std::atomic<bool> failed{false};       // a collective failed half way (on whichever thread): the communicator's state is unknown, every later gather is refused
     float gather_ms = 0, deint_ms = 0; uint32_t gathers = 0;
     std::string err;
 };

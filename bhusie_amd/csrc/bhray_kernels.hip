@@ -288,6 +288,9 @@ __device__ __forceinline__ bool hit_triangle(F3 pos, F3 dir, float t_min, float 
 #ifndef BHRAY_BVH_LDS_STACK
 #define BHRAY_BVH_LDS_STACK 8      // entries of the short traversal stack in LDS (16 KB per 256-thread block: 8 blocks per CU fit in 160 KB)
 #endif
+#ifndef BHRAY_EXPERIMENT_NO_RANGE_GUARDS
+#define BHRAY_EXPERIMENT_NO_RANGE_GUARDS 0   // 1 = an EXPERIMENT, never a product build: the short 1/x and sqrt sequences without their range guards (wrong bits for zero / denormal / huge operands) - an upper bound on what the guards' branches cost
+#endif
 #ifndef BHRAY_BVH_WHILE_WHILE
 #define BHRAY_BVH_WHILE_WHILE 0    // 1: inner nodes and leaves in loops of their own (see trace_ray_model)
 #endif
@@ -511,19 +514,25 @@ __device__ __forceinline__ bool sqrt_in_range(float x) { return x >= 0x1p-95f &&
 // alone on its SIMD pays for every branch (profiles/ubench/lone_wave.hip).
 __device__ __forceinline__ float rcp_rn(float x) {                 // == 1.0f / x
     float r = rcp_newton(x);
+#if !BHRAY_EXPERIMENT_NO_RANGE_GUARDS
     if (__builtin_expect(__ballot(!rcp_in_range(x)) != 0ull, 0)) r = 1.0f / x;
+#endif
     return r;
 }
 __device__ __forceinline__ float sqrt_rn(float x) {                // == sqrtf(x)
     float r = sqrt_corrected(x);
+#if !BHRAY_EXPERIMENT_NO_RANGE_GUARDS
     if (__builtin_expect(__ballot(!sqrt_in_range(x)) != 0ull, 0)) r = sqrtf(x);
+#endif
     return r;
 }
 // == fnormalize(a) (bhray_math.h): a * (1 / sqrt(fdot(a, a))); one guard covers both (sqrt of an in-range x is in rcp's range)
 __device__ __forceinline__ F3 fnormalize_rn(F3 a) {
     const float d = fdot(a, a);
     float r = rcp_newton(sqrt_corrected(d));
+#if !BHRAY_EXPERIMENT_NO_RANGE_GUARDS
     if (__builtin_expect(__ballot(!sqrt_in_range(d)) != 0ull, 0)) r = 1.0f / sqrtf(d);
+#endif
     return a * r;
 }
 // == bh_pow_m001(x) (bhray_math.h) for every x > 0.00002f, the only values next_ray_rk passes (all of them, +inf included, checked

@@ -124,6 +124,41 @@ def test_gather_with_mesh_and_counters(tmp_path):
     rp.close(); one.close()
 
 
+def test_per_frame_scene_state_travels_with_the_frame_through_the_issue_threads(tmp_path):
+    """A multi-device ctx hands every frame to its issue threads: uniforms AND the model's per-frame transform (mod.rs:391 re-uploads the model
+    every frame; bhray_set_model_transform replaces that) must be the ones in force when bhray_render was called, although the engines pick
+    the frame up later.  The mesh comes and goes between frames (a change of kernel variant cuts the staged batch short), frames in flight
+    and batches on; every frame against the single ctx."""
+    from bhusie_amd import assets
+    obj = tmp_path / "m.obj"
+    obj.write_text(assets.icosphere_mesh_obj(3, radius=8.0, bump=0.1, seed=4))
+    model = B.load_model(str(obj))
+    tex = T.textures()
+    cam = B.Camera(position=(0.0, 0.0, -40.0), forward=(-0.11914522, 0.0, 0.99287683), fov=1.2)
+    cfg = B.ladder_for_frame((200, 110), 3, 3)
+    steps = [((-10.0, 0.0, 30.0), 1, 1), ((-10.0, 0.0, 30.0), 1, 0), ((-6.0, 2.0, 33.0), 1, 1), ((-6.0, 2.0, 33.0), 0, 1), ((-12.0, -1.0, 28.0), 1, 1),
+             ((-12.0, -1.0, 28.0), 1, 1), ((0.0, 0.0, 60.0), 1, 0)]                          # (model position, visible, integrator)
+    one = B.RayPass(cfg, device=0); one.set_textures(*tex); one.upload_model(model)
+    want = []
+    for k, (pos, vis, method) in enumerate(steps):
+        one.set_model_transform(pos, vis); one.set_uniforms(*T.uniforms(camera=cam, integration_method=method, model_count=1, time=0.2 * k)); one.render()
+        want.append(one.read_hdr())
+    one.close()
+    for kw in (dict(devices=[0] * 3, stripe_rows=9, frames_in_flight=2, frames_per_batch=2), dict(devices=[0, 0], slab_row0=[0, 70, 110], frames_in_flight=3)):
+        rp = B.RayPass(cfg, **kw)
+        rp.set_textures(*tex); rp.upload_model(model)
+        bufs = [T.DeviceBuffer(200 * 110 * 16) for _ in steps]
+        for k, (pos, vis, method) in enumerate(steps):                                       # all frames enqueued back to back, nothing read in between
+            rp.set_model_transform(pos, vis); rp.set_uniforms(*T.uniforms(camera=cam, integration_method=method, model_count=1, time=0.2 * k))
+            rp.bind_output(bufs[k].ptr.value, bufs[k].nbytes); rp.render()
+        rp.sync()
+        for k, b in enumerate(bufs):
+            assert np.array_equal(b.read(np.uint32), want[k].view(np.uint32).ravel()), (kw, k)
+            b.free()
+        rp.close()
+    assert not np.array_equal(want[0], want[2]) and not np.array_equal(want[2], want[3])      # the mesh did move and did disappear
+
+
 def test_bench_frame_on_eight_partitions_is_the_single_gpu_frame():
     """configs[1]/[3] shape at full 1920x1080: 8 partitions x 27-row stripes, 8 frames per batch, speculative levels — the
     production multi-GPU configuration of bench.py — equals the single-ctx frame byte for byte."""
