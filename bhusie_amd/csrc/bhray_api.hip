@@ -254,10 +254,6 @@ void derive_frame(const bhray_dev* c, FrameParams& P) {
     memcpy(P.bn, bh.normal, 12);
     P.bn_len = length(ld3(bh.normal));
     P.cull_outer_pad = bh.accretion_disk_outer + 0.0501f; P.cull_plane_c1 = 1.0101f * P.bn_len; P.cull_plane_c2 = 1.01e-4f * P.bn_len;
-    {   // a segment of step_size: the bounds of black_hole_culls as constants (each a little wider than the per-step form's: rounded up)
-        const float reach = 1.0501f * d.step_size + 0.0501f;
-        P.cull_h = 1.0f + reach; P.cull_d = bh.accretion_disk_outer + reach; P.cull_p = (1.0101f * d.step_size) * P.bn_len + 1.01e-4f * P.bn_len;
-    }
     P.inner = bh.accretion_disk_inner; P.outer = bh.accretion_disk_outer;
     P.rot_speed = bh.rotation_speed; P.R = bh.relativity_sphere_radius;
     P.show_tex = bh.show_disk_texture; P.show_shift = bh.show_red_shift;

@@ -45,7 +45,6 @@ struct FrameParams {
     float bn[3];
     float bn_len;          // length(normal) (host), for the conservative disk cull
     float cull_outer_pad, cull_plane_c1, cull_plane_c2;   // black_hole_culls' folded constants: outer + 0.0501, 1.0101 |n|, 1.01e-4 |n|
-    float cull_h, cull_d, cull_p;                          // ... and, for a segment of step_size (Euler), the three bounds themselves
     float inner, outer, rot_speed, R;
     int show_tex, show_shift;
     float M[9];            // rotation matrix columns c0,c1,c2

@@ -109,7 +109,6 @@ struct HotParams {
     F3 bh, bn;
     float bn_len, inner, outer, R, ray_distance, feather, time_rot, step_size;
     float outer_pad, plane_c1, plane_c2;      // black_hole_culls: outer + 0.05, 1.01 |n|, 1e-4 |n| (slightly more than the unfolded form's margins: rounded up)
-    float cull_h, cull_d, cull_p;             // black_hole_culls<.., CONST_SEG>: the bounds for t_max = step_size
     int max_iter, show_tex, show_shift;
     float M[9];
     TexDev disk, temp;
@@ -118,7 +117,7 @@ __device__ __forceinline__ float pin_sgpr(float v) { asm volatile("" : "+s"(v));
 __device__ __forceinline__ int pin_sgpr(int v) { asm volatile("" : "+s"(v)); return v; }
 __device__ __forceinline__ const uint8_t* pin_sgpr(const uint8_t* v) { asm volatile("" : "+s"(v)); return v; }
 __device__ __forceinline__ TexDev pin_sgpr(const TexDev& t) { TexDev r; r.rgba = pin_sgpr(t.rgba); r.w = pin_sgpr(t.w); r.h = pin_sgpr(t.h); return r; }
-template <bool FOLDED_CULLS = false, bool CONST_SEG_CULLS = false>
+template <bool FOLDED_CULLS = false>
 __device__ __forceinline__ HotParams load_hot(const FrameParams& P) {
     HotParams H;
     H.bh = f3(pin_sgpr(P.bh[0]), pin_sgpr(P.bh[1]), pin_sgpr(P.bh[2]));
@@ -127,8 +126,6 @@ __device__ __forceinline__ HotParams load_hot(const FrameParams& P) {
     H.inner = pin_sgpr(P.inner); H.outer = pin_sgpr(P.outer); H.R = pin_sgpr(P.R);
     if (FOLDED_CULLS) { H.outer_pad = pin_sgpr(P.cull_outer_pad); H.plane_c1 = pin_sgpr(P.cull_plane_c1); H.plane_c2 = P.cull_plane_c2; }      // formed on the host (gfx950 has no scalar float arithmetic)
     else { H.outer_pad = 0.0f; H.plane_c1 = 0.0f; H.plane_c2 = 0.0f; }
-    if (CONST_SEG_CULLS) { H.cull_h = pin_sgpr(P.cull_h); H.cull_d = pin_sgpr(P.cull_d); H.cull_p = pin_sgpr(P.cull_p); }
-    else { H.cull_h = 0.0f; H.cull_d = 0.0f; H.cull_p = 0.0f; }
     H.ray_distance = pin_sgpr(P.ray_distance); H.feather = pin_sgpr(P.feather);
     H.time_rot = pin_sgpr(P.time_rot); H.step_size = pin_sgpr(P.step_size);
     H.max_iter = pin_sgpr(P.max_iter); H.show_tex = pin_sgpr(P.show_tex); H.show_shift = pin_sgpr(P.show_shift);
@@ -205,17 +202,12 @@ __device__ __forceinline__ void shade_disk(const HotParams& P, F3 pos, F3 dir, f
 // pos_dist - 1.05 t <= c, one fused operation for both radial tests; the plane test's bound one fused operation - 4 vector instructions
 // per step less.  Measured (profiles/r05_ab_culls_folded.txt, three rounds): the mesh variant +2.4 % (20- and 400-frame blocks), the
 // no-mesh RK kernel -0.7 % / -1.0 %, Euler -1.3 %: fewer instructions, a worse schedule.  So the mesh variant folds, the others do not.
-// CONST_SEG (the Euler kernels: the segment of every step is the uniform step size): the three bounds are constants of the frame, formed on
-// the host - three compares against scalar registers instead of eight more vector instructions, of a step that has 92.
-template <bool FOLDED, bool CONST_SEG = false>
+template <bool FOLDED>
 __device__ __forceinline__ void black_hole_culls(const HotParams& H, F3 pos, float pos_dist, float t_max, bool& near_horizon, bool& near_disk) {
     // signed plane distance from the hole-RELATIVE position: its rounding error (a few ulp of |pos - bh| <= outer + reach) does not
     // grow with |bh|, unlike n.bh - n.pos for a hole far from the origin
     const float numer = fdot(H.bh - pos, H.bn);
-    if (CONST_SEG) {
-        near_horizon = pos_dist <= H.cull_h;
-        near_disk = (pos_dist <= H.cull_d) & (fabsf(numer) <= H.cull_p);
-    } else if (FOLDED) {
+    if (FOLDED) {
         const float e = __builtin_fmaf(t_max, -1.05f, pos_dist);
         near_horizon = e <= 1.05f;
         near_disk = (e <= H.outer_pad) & (fabsf(numer) <= __builtin_fmaf(t_max, H.plane_c1, H.plane_c2));     // & : no branch
@@ -298,9 +290,6 @@ __device__ __forceinline__ bool hit_triangle(F3 pos, F3 dir, float t_min, float 
 #endif
 #ifndef BHRAY_EXPERIMENT_NO_RANGE_GUARDS
 #define BHRAY_EXPERIMENT_NO_RANGE_GUARDS 0   // 1 = an EXPERIMENT, never a product build: the short 1/x and sqrt sequences without their range guards (wrong bits for zero / denormal / huge operands) - an upper bound on what the guards' branches cost
-#endif
-#ifndef BHRAY_EULER_CONST_CULLS
-#define BHRAY_EULER_CONST_CULLS 0    // 1: the no-mesh Euler kernels compare against per-frame cull bounds (black_hole_culls<.., CONST_SEG>)
 #endif
 #ifndef BHRAY_BVH_WHILE_WHILE
 #define BHRAY_BVH_WHILE_WHILE 0    // 1: inner nodes and leaves in loops of their own (see trace_ray_model)
@@ -1085,7 +1074,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
         }
         if (thin_share != 0u && fi != 0) continue;
     }
-    const HotParams H = load_hot<MODELS, BHRAY_EULER_CONST_CULLS && METHOD == 0 && !MODELS>(P);
+    const HotParams H = load_hot<MODELS>(P);
     const F3 bpos = H.bh;
     const float t_max = 1e5f, t_min = 1e-8f;
 
