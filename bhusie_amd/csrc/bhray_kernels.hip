@@ -288,6 +288,9 @@ __device__ __forceinline__ bool hit_triangle(F3 pos, F3 dir, float t_min, float 
 #ifndef BHRAY_BVH_LDS_STACK
 #define BHRAY_BVH_LDS_STACK 8      // entries of the short traversal stack in LDS (16 KB per 256-thread block: 8 blocks per CU fit in 160 KB)
 #endif
+#ifndef BHRAY_EXPERIMENT_NO_TRAVERSAL
+#define BHRAY_EXPERIMENT_NO_TRAVERSAL 0
+#endif
 #ifndef BHRAY_EXPERIMENT_NO_RANGE_GUARDS
 #define BHRAY_EXPERIMENT_NO_RANGE_GUARDS 0   // 1 = an EXPERIMENT, never a product build: the short 1/x and sqrt sequences without their range guards (wrong bits for zero / denormal / huge operands) - an upper bound on what the guards' branches cost
 #endif
@@ -1218,7 +1221,9 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                                         if (COUNT && skip) cnt[6]++;
                                     }
                                 }
+#if !BHRAY_EXPERIMENT_NO_TRAVERSAL      // (1 = an EXPERIMENT: the mesh variant without its traversal - what the traversal's mere presence costs the march, profiles/EXPERIMENTS.md R5.8)
                                 if (!skip) trace_ray_model<COUNT>(P.models[mi], bvh_lds, cpos, cdir, t_min, t_max, r, nrm, cnt, &err);
+#endif
                                 if (r.hit && r.t < rs.t) {
                                     rs = r;
                                     const F3 light = normalize(f3(0.2f, 0.2f, -1.0f));
