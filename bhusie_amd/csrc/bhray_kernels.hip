@@ -288,6 +288,12 @@ __device__ __forceinline__ bool hit_triangle(F3 pos, F3 dir, float t_min, float 
 #ifndef BHRAY_BVH_LDS_STACK
 #define BHRAY_BVH_LDS_STACK 8      // entries of the short traversal stack in LDS (16 KB per 256-thread block: 8 blocks per CU fit in 160 KB)
 #endif
+#ifndef BHRAY_MESH_PARK
+#define BHRAY_MESH_PARK 0          // 1: the mesh variant's traversal in a region of its own, the marching state stored to scratch around it (see the flat phase)
+#endif
+#ifndef BHRAY_FLAT_COLD
+#define BHRAY_FLAT_COLD 0
+#endif
 #ifndef BHRAY_EXPERIMENT_NO_TRAVERSAL
 #define BHRAY_EXPERIMENT_NO_TRAVERSAL 0
 #endif
@@ -318,7 +324,7 @@ struct BvhLds { int2* stack; };     // stack: this lane's column (entry k at sta
 // that moment, as the reference decides it) and is recorded in `pend` - so the nodes are visited in the same order, with the same
 // pruning, and equal-t ties between triangles resolve as in the reference.  Node pairs re-read on the way down are not counted.
 // A tree deeper than 64 levels raises BHRAY_E_BVH_DEPTH (D2).
-template <bool COUNT>
+template <bool COUNT, bool WW = (BHRAY_BVH_WHILE_WHILE != 0)>
 __device__ BHRAY_MODEL_INLINE void trace_ray_model(const ModelDev& M, const BvhLds lds, F3 pos, F3 dir, float t_min, float t_max,
                                              Hit& closest, F3& normal_out, unsigned long long* cnt, int* err) {
     static_assert(BHRAY_BVH_LDS_STACK >= 2 && BHRAY_BVH_STACK <= 64, "short stack / trail sizes");
@@ -333,7 +339,7 @@ __device__ BHRAY_MODEL_INLINE void trace_ray_model(const ModelDev& M, const BvhL
     int lev = 0;                      // tree level of the decision the current node's children are (root's children: 0)
     int sp = 0, held = 0;             // ring position; valid entries in the ring (<= D)
     int target = -1;                  // >= 0: re-descending to take the pending far child of that level
-#if BHRAY_BVH_WHILE_WHILE
+    if (WW) {
     // "while-while" form: every lane first walks inner nodes until it stands at a leaf (or is done), then the lanes that hold a leaf test
     // their triangles together.  In the one-loop form below a lane at a leaf (<= 2 triangles, ~300 instructions) and a lane at an inner node
     // (two box tests, ~80) take turns within every iteration; rays of one tile reach their leaves at different iterations, so most
@@ -420,7 +426,7 @@ __device__ BHRAY_MODEL_INLINE void trace_ray_model(const ModelDev& M, const BvhL
             do_pop();
         }
     }
-#else
+    } else {
     for (;;) {
         bool pop = false;
         if (obj_count == 0) {
@@ -485,7 +491,7 @@ __device__ BHRAY_MODEL_INLINE void trace_ray_model(const ModelDev& M, const BvhL
             }
         }
     }
-#endif
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -914,6 +920,12 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #define BHRAY_TRACE_WAVES_MESH 5 // mesh variant (BVH traversal inline + short stack in LDS): 96 VGPRs.  Round 4, mesh workload, 20- / 200-frame blocks / one frame at a
                                  // time: call + 8 waves 3 747 / 4 323 Mrays/s / 3.05 ms; inline + 5 waves 3 937 / 4 359 / 2.60; inline + 4 waves 3 660 / 3 995 / 2.58
 #endif
+#ifndef BHRAY_TRACE_WAVES_MESH_DENSE
+#define BHRAY_TRACE_WAVES_MESH_DENSE 6   // the mesh variant for a saturated device (round 5): 80 VGPRs like the dense no-mesh kernel - possible because the traversal runs in a region of
+                                         // its own with the marching state stored to scratch around it (MESH_PARK below), the flat phase is marked unlikely (the allocator then keeps
+                                         // the step loop free of spills) and the traversal is the while-while form (fewer registers).  400-frame blocks 4 434 -> 4 646 Mrays/s, 20-frame
+                                         // blocks 3 941 -> 3 915; one frame at a time keeps the 5-wave build (profiles/EXPERIMENTS.md R5.8)
+#endif
 #ifndef BHRAY_TRACE_WAVES
 #define BHRAY_TRACE_WAVES 4      // waves per SIMD the trace kernel is register-budgeted for (<=128 VGPRs): the latency build
 #endif
@@ -996,7 +1008,7 @@ template <> struct ColdState<true> {
 };
 
 template <int METHOD, bool MODELS, bool COUNT, bool DENSE, int EVAL = 0, bool FUSED = false>
-__global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MESH : (DENSE ? BHRAY_TRACE_WAVES_DENSE : BHRAY_TRACE_WAVES)) void trace_kernel(const FrameParams* __restrict__ Pb, const FrameLaunch* __restrict__ Fb, const int nb, int* __restrict__ err_flag) {
+__global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_WAVES_MESH_DENSE : BHRAY_TRACE_WAVES_MESH) : (DENSE ? BHRAY_TRACE_WAVES_DENSE : BHRAY_TRACE_WAVES)) void trace_kernel(const FrameParams* __restrict__ Pb, const FrameLaunch* __restrict__ Fb, const int nb, int* __restrict__ err_flag) {
     const int lane = threadIdx.x & 63;
     int err = 0;
     // Execution span of this launch (timed batches only: Fb[0].span != nullptr): first block's start and last block's end on the
@@ -1007,6 +1019,10 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
     if (Fb[0].span && threadIdx.x == 0) atomicMax(&Fb[0].span[0], ~(unsigned long long)wall_clock64());
 #endif
     constexpr bool COLD_LDS = (DENSE && !MODELS) || (MODELS && BHRAY_MESH_COLD_LDS != 0);
+    constexpr bool MESH_DENSE = MODELS && DENSE;                                              // the mesh variant's build for a saturated device
+    constexpr bool MESH_PARK = MODELS && !COLD_LDS && (MESH_DENSE || BHRAY_MESH_PARK != 0);   // its traversal in a region of its own (see the flat phase)
+    constexpr bool FLAT_COLD = MESH_DENSE || BHRAY_FLAT_COLD != 0;
+    constexpr bool BVH_WW = MESH_DENSE || BHRAY_BVH_WHILE_WHILE != 0;
     __shared__ float cold_lds[COLD_LDS ? (8 + BHRAY_HIT_LDS) * BHRAY_TRACE_THREADS : 1];
     // Integrator steps this wave issues for the frames of the batch -> Fb[0].work at the kernel's end.  Wave-uniform: a scalar register.
     // Counted in whole batches of steps, where the step loop is entered (a batch cut short by its last ray counts in full), and for the
@@ -1194,14 +1210,73 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
             run_flat = mf != 0ull && (__popcll(mf) >= BHRAY_FLAT_MIN_LANES || !__any(mode == M_REL) || flat_round >= BHRAY_FLAT_DEFER);
             if (run_flat) flat_round = 0;
         }
-        if (run_flat && __any(mode == M_FLAT)) {
+        // BHRAY_MESH_PARK (mesh variant): the traversal runs in a region of its own in which NOTHING of the march is live - every per-lane
+        // variable of the ray state machine is stored to scratch in front of it and loaded back behind it, once per flat phase in which a
+        // lane's ray passes the root-box test at all.  The compiler would otherwise keep part of the marching state in registers across the
+        // traversal (it parks 37-47 dwords of ~70) and, at the register budget of six waves per SIMD, spill inside the traversal's loops.
+        Hit mesh_r; F3 mesh_nrm = f3(0, 0, 0);
+        mesh_r.hit = false; mesh_r.t = t_max; mesh_r.color = f3(0, 0, 0); mesh_r.opacity = 0.0f;
+        if (MESH_PARK) {
+            static_assert(BHRAY_MAX_MODELS == 1, "the parked traversal handles the reference's one model");
+            bool want = false;
+            if (__builtin_expect(run_flat && __any(mode == M_FLAT), 0)) {
+                if (mode == M_FLAT && it < H.max_iter && P.model_count > 0 && P.models[0].visible != 0) {
+                    bool skip = false;
+                    if (P.models[0].root_cull != 0) {
+                        const F3 inv = f3(1.0f / cdir.x, 1.0f / cdir.y, 1.0f / cdir.z);
+                        if (fabsf(inv.x) < INFINITY && fabsf(inv.y) < INFINITY && fabsf(inv.z) < INFINITY) {
+                            const ModelDev& Md = P.models[0];
+                            const float d0 = hit_aabb(cpos, inv, make_float4(Md.root_lo[0], Md.root_lo[1], Md.root_lo[2], 0.0f),
+                                                      make_float4(Md.root_hi[0], Md.root_hi[1], Md.root_hi[2], 0.0f), ld3(Md.pos));
+                            skip = d0 > t_max;
+                            if (COUNT && skip) cnt[6]++;
+                        }
+                    }
+                    want = !skip;
+                }
+                if (__any(want)) {
+                    float pk[40];
+                    float* pkp = pk;
+                    const F3 tpos = cpos, tdir = cdir;
+                    pk[0] = cpos.x; pk[1] = cpos.y; pk[2] = cpos.z; pk[3] = cdir.x; pk[4] = cdir.y; pk[5] = cdir.z;
+                    pk[6] = ppos.x; pk[7] = ppos.y; pk[8] = ppos.z; pk[9] = pdir.x; pk[10] = pdir.y; pk[11] = pdir.z;
+                    pk[12] = rkpos.x; pk[13] = rkpos.y; pk[14] = rkpos.z; pk[15] = rkdir.x; pk[16] = rkdir.y; pk[17] = rkdir.z;
+                    pk[18] = rkh; pk[19] = amount; pk[20] = closest; pk[21] = dist_c; pk[22] = cpos_dist;
+                    pk[23] = qrel.x; pk[24] = qrel.y; pk[25] = qrel.z;
+                    pk[26] = __int_as_float(it); pk[27] = __int_as_float((int)hit); pk[28] = __int_as_float(mode);
+                    { const F3 cc_ = cold.color(), rd_ = cold.rdir();
+                      pk[29] = __uint_as_float(cold.pix()); pk[30] = cc_.x; pk[31] = cc_.y; pk[32] = cc_.z;
+                      pk[33] = rd_.x; pk[34] = rd_.y; pk[35] = rd_.z; pk[36] = cold.pend_t(); }
+                    asm volatile("" : "+v"(pkp) : : "memory");         // what was stored may be read and changed behind the compiler's back: nothing above stays in a register
+                    if (want) trace_ray_model<COUNT, BVH_WW>(P.models[0], bvh_lds, tpos, tdir, t_min, t_max, mesh_r, mesh_nrm, cnt, &err);
+                    asm volatile("" : "+v"(pkp) : : "memory");
+                    cpos = f3(pkp[0], pkp[1], pkp[2]); cdir = f3(pkp[3], pkp[4], pkp[5]);
+                    ppos = f3(pkp[6], pkp[7], pkp[8]); pdir = f3(pkp[9], pkp[10], pkp[11]);
+                    rkpos = f3(pkp[12], pkp[13], pkp[14]); rkdir = f3(pkp[15], pkp[16], pkp[17]);
+                    rkh = pkp[18]; amount = pkp[19]; closest = pkp[20]; dist_c = pkp[21]; cpos_dist = pkp[22];
+                    qrel = f3(pkp[23], pkp[24], pkp[25]);
+                    it = __float_as_int(pkp[26]); hit = __float_as_int(pkp[27]); mode = __float_as_int(pkp[28]);
+                    cold.set_pix(__float_as_uint(pkp[29])); cold.set_color(f3(pkp[30], pkp[31], pkp[32]));
+                    cold.set_rdir(f3(pkp[33], pkp[34], pkp[35])); cold.set_pend_t(pkp[36]);
+                }
+            }
+        }
+        // (FLAT_COLD: the flat phase marked unlikely, so that the register allocator weighs the step loop above the traversal's loops)
+        const bool flat_now = run_flat && __any(mode == M_FLAT);
+        if (FLAT_COLD ? __builtin_expect(flat_now, 0) : flat_now) {
             if (mode == M_FLAT) {
                 if (it >= H.max_iter) {
                     mode = M_FINISH;
                 } else {
                     if (COUNT) cnt[5]++;
                     Hit rs; rs.hit = false; rs.t = t_max; rs.color = f3(0, 0, 0); rs.opacity = 0.0f;
-                    if (MODELS) {
+                    if (MESH_PARK) {      // the traversal has run in its own region above
+                        if (mesh_r.hit && mesh_r.t < rs.t) {
+                            rs = mesh_r;
+                            const F3 light = normalize(f3(0.2f, 0.2f, -1.0f));
+                            rs.color = rs.color * dot(mesh_nrm, light);
+                        }
+                    } else if (MODELS) {
                         for (int mi = 0; mi < P.model_count; mi++) {
                             if (P.models[mi].visible != 0) {
                                 Hit r; F3 nrm;
@@ -1222,7 +1297,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? BHRAY_TRACE_WAVES_MES
                                     }
                                 }
 #if !BHRAY_EXPERIMENT_NO_TRAVERSAL      // (1 = an EXPERIMENT: the mesh variant without its traversal - what the traversal's mere presence costs the march, profiles/EXPERIMENTS.md R5.8)
-                                if (!skip) trace_ray_model<COUNT>(P.models[mi], bvh_lds, cpos, cdir, t_min, t_max, r, nrm, cnt, &err);
+                                if (!skip) trace_ray_model<COUNT, BVH_WW>(P.models[mi], bvh_lds, cpos, cdir, t_min, t_max, r, nrm, cnt, &err);
 #endif
                                 if (r.hit && r.t < rs.t) {
                                     rs = r;
@@ -1526,13 +1601,15 @@ static hipError_t launch_trace_t(const FrameParams* Pb, const FrameLaunch* Fb, i
     return hipGetLastError();
 }
 
-// eval: 0 the numerics contract, 1 BHRAY_F_LITERAL, 2 BHRAY_F_EVAL_FMA.  The mesh variant has one register budget.
+// eval: 0 the numerics contract, 1 BHRAY_F_LITERAL, 2 BHRAY_F_EVAL_FMA.  Every variant has a build for a saturated device (dense) and one for lone launches.
 template <int EVAL>
 static hipError_t launch_trace_e(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int method, bool models, bool count, bool dense, int* err_flag,
                                  int grid_blocks, hipStream_t s) {
     if (models) {
-        return method == 0 ? launch_trace_t<0, true, false, EVAL>(Pb, Fb, nb, count, err_flag, grid_blocks, s)
-                           : launch_trace_t<1, true, false, EVAL>(Pb, Fb, nb, count, err_flag, grid_blocks, s);
+        if (method == 0) return dense ? launch_trace_t<0, true, true, EVAL>(Pb, Fb, nb, count, err_flag, grid_blocks, s)
+                                      : launch_trace_t<0, true, false, EVAL>(Pb, Fb, nb, count, err_flag, grid_blocks, s);
+        return dense ? launch_trace_t<1, true, true, EVAL>(Pb, Fb, nb, count, err_flag, grid_blocks, s)
+                     : launch_trace_t<1, true, false, EVAL>(Pb, Fb, nb, count, err_flag, grid_blocks, s);
     }
     if (method == 0) {
         return dense ? launch_trace_t<0, false, true, EVAL>(Pb, Fb, nb, count, err_flag, grid_blocks, s)
@@ -1576,6 +1653,7 @@ int fused_blocks_per_cu(int, int, int, int) { return 0; }      // 0: this build 
 template <int EVAL>
 static const void* trace_kernel_ptr(int method, int has_models, int count, int dense) {
 #define PICK(M, MD, C, D) (const void*)trace_kernel<M, MD, C, D, EVAL>
+    if (has_models && dense) return method == 0 ? (count ? PICK(0, true, true, true) : PICK(0, true, false, true)) : (count ? PICK(1, true, true, true) : PICK(1, true, false, true));
     if (has_models) return method == 0 ? (count ? PICK(0, true, true, false) : PICK(0, true, false, false)) : (count ? PICK(1, true, true, false) : PICK(1, true, false, false));
     if (dense) return method == 0 ? (count ? PICK(0, false, true, true) : PICK(0, false, false, true)) : (count ? PICK(1, false, true, true) : PICK(1, false, false, true));
     return method == 0 ? (count ? PICK(0, false, true, false) : PICK(0, false, false, false)) : (count ? PICK(1, false, true, false) : PICK(1, false, false, false));
