@@ -172,6 +172,7 @@ struct bhray_dev {
     int bpc_override = 0;                  // BHRAY_TRACE_BLOCKS_PER_CU (tuning experiments only)
     int grid_override = 0;                 // BHRAY_TRACE_GRID: absolute number of persistent trace blocks (tuning experiments only)
     int dense_override = -1;               // BHRAY_TRACE_DENSE=0/1 (tuning experiments only)
+    int coarse_build = -1;                 // BHRAY_COARSE_BUILD=0/1 (experiment): the build of the trace launches below the ladder's last level (-1: the batch's build)
     bool rendered = false;
     // asynchronous hand-off (dev_read_hdr_async)
     hipEvent_t read_ev[BHRAY_READ_RING] = {nullptr};     // ticket t -> read_ev[t % BHRAY_READ_RING]
@@ -596,6 +597,7 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
         c->temporal_radius_coarse = rc < 0 ? 0 : (rc > 4 ? 4 : (uint32_t)rc);
     }
     if (const char* e = getenv("BHRAY_TRACE_DENSE")) c->dense_override = atoi(e) != 0;
+    if (const char* e = getenv("BHRAY_COARSE_BUILD")) c->coarse_build = atoi(e);
     if (const char* e = getenv("BHRAY_DYNAMIC_DENSE")) c->dynamic_dense = atoi(e);
     const uint32_t nslots = cfg->frames_in_flight ? cfg->frames_in_flight : 4;
     c->cfg.frames_in_flight = nslots;
@@ -1105,6 +1107,7 @@ struct BatchPlan {
                 h[k].queue = R.spec_queue; h[k].qctl = R.d_qctl; h[k].counters = count ? R.d_counters : nullptr;
             }
             seq.push_back({1, d, grid, count, {}, {2}});
+            if (ns < nl) seq.back().build = c->coarse_build;
         }
         for (uint32_t l = 1; l < ns; l++) {
             FrameLaunch* h; const FrameLaunch* d; next_launch(h, d);
@@ -1204,6 +1207,7 @@ struct BatchPlan {
             }
             seq.push_back({0, d, classify_blocks(l), count, {(int)(3 * l)}, {(int)(3 * l + 1)}});
             seq.push_back({1, d, grid, count, {}, {(int)(3 * l + 2)}});
+            if (l + 1 < nl) seq.back().build = c->coarse_build;
         }
         return BHRAY_OK;
     }

@@ -297,6 +297,12 @@ __device__ __forceinline__ bool hit_triangle(F3 pos, F3 dir, float t_min, float 
 #ifndef BHRAY_EXPERIMENT_NO_TRAVERSAL
 #define BHRAY_EXPERIMENT_NO_TRAVERSAL 0
 #endif
+#ifndef BHRAY_THIN_STRIDED_BELOW
+#define BHRAY_THIN_STRIDED_BELOW 0    // thin dealing: a wave's share is taken STRIDED (every waves-th entry) when it is below this many rays (0: never; see trace_kernel and profiles/EXPERIMENTS.md R5.9: mixed, off)
+#endif
+#ifndef BHRAY_EXPERIMENT_LONGEST_TRAVERSAL
+#define BHRAY_EXPERIMENT_LONGEST_TRAVERSAL 0   // 1 = an EXPERIMENT (counting builds): bhray_counters.longest_ray holds the longest TRAVERSAL instead - loop iterations (inner nodes + leaves + re-descents) of one call
+#endif
 #ifndef BHRAY_EXPERIMENT_NO_RANGE_GUARDS
 #define BHRAY_EXPERIMENT_NO_RANGE_GUARDS 0   // 1 = an EXPERIMENT, never a product build: the short 1/x and sqrt sequences without their range guards (wrong bits for zero / denormal / huge operands) - an upper bound on what the guards' branches cost
 #endif
@@ -427,8 +433,10 @@ __device__ BHRAY_MODEL_INLINE void trace_ray_model(const ModelDev& M, const BvhL
         }
     }
     } else {
+    unsigned long long visits = 0ull;
     for (;;) {
         bool pop = false;
+        if (COUNT && BHRAY_EXPERIMENT_LONGEST_TRAVERSAL != 0) { visits++; if (visits > cnt[12]) cnt[12] = visits; }
         if (obj_count == 0) {
             if (lev >= BHRAY_BVH_STACK) { *err = BHRAY_E_BVH_DEPTH; break; }
             const float4* pair = M.nodes + 2 * (size_t)contents;
@@ -1073,13 +1081,18 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
     // A batch (nb > 1): the blocks whose OWN frame this is (blockIdx % nb == fb: every block starts with its own frame) deal the frame's
     // rays out among themselves the same way, and the blocks that come by later to help (fi > 0) leave such a frame alone - it has no
     // queue head to pull from.  (A rank of an 8-way partition renders its coarse levels in launches of ten frames x a few hundred rays.)
-    uint32_t thin_share = 0, thin_block = blockIdx.x;
+    // (BHRAY_THIN_STRIDED_BELOW > 0, an experiment: a share of fewer rays than that is taken STRIDED - wave w takes entries w, w + waves, w + 2 waves, ... -
+    // so that every wave holds an even sample of the queue instead of neighbouring pixels.  One frame at a time, levels 0+1 of 1920x1080: RK 0.285 -> 0.252 ms,
+    // Euler 0.194 -> 0.167, with the mesh 0.662 -> 0.575 - but level 2 of the sky slab of an 8-way partition 0.187 -> 0.205, and batches of a rank's frames
+    // 0.077 -> 0.081 ms per frame: neighbours finish together.  Off.)
+    uint32_t thin_share = 0, thin_block = blockIdx.x, thin_stride = 0;
     if (MODELS) {                                         // the mesh variant (96-VGPR budget: -2 % with the batch form below) keeps the single-frame form
         if (!DENSE && nb == 1 && BHRAY_THIN_WAVES > 0) {
             const uint32_t total = gridDim.x * (BHRAY_TRACE_THREADS / 64);
             const uint32_t waves = total < (uint32_t)BHRAY_THIN_WAVES ? total : (uint32_t)BHRAY_THIN_WAVES;
             const uint32_t share = (qcount + waves - 1) / waves;
             if (share < 64u) thin_share = share > 0u ? share : 1u;
+            if (share < (uint32_t)BHRAY_THIN_STRIDED_BELOW) thin_stride = waves;
         }
     } else if (!DENSE && !FZ && BHRAY_THIN_WAVES > 0 && (nb == 1 || gridDim.x >= 4u * (uint32_t)nb)) {   // (the fused ladder has its own queues and its own frame loop; every frame of a batch needs blocks of its own)
         uint32_t own_blocks = gridDim.x;
@@ -1090,6 +1103,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
         if (waves > 0u) {
             const uint32_t share = (qcount + waves - 1) / waves;
             if (share < 64u) thin_share = share > 0u ? share : 1u;
+            if (nb == 1 && share < (uint32_t)BHRAY_THIN_STRIDED_BELOW) thin_stride = waves;     // (a batch of a rank's thin frames keeps a device busy: neighbours together, 0.077 against 0.081 ms per frame on a rank of 8)
         }
         if (thin_share != 0u && fi != 0) continue;
     }
@@ -1140,7 +1154,9 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
                 uint32_t base = 0;
                 if (!DENSE && thin_share != 0u) {                 // this wave's share, once (all lanes are empty: n == 64 > share)
                     n = thin_share;
-                    base = (thin_block * (BHRAY_TRACE_THREADS / 64) + (threadIdx.x >> 6)) * thin_share;
+                    base = thin_block * (BHRAY_TRACE_THREADS / 64) + (threadIdx.x >> 6);
+                    if (thin_stride != 0u) { if (base >= thin_stride) n = 0u; }      // strided: entries base, base + waves, ... (the waves beyond `waves` take nothing)
+                    else base *= thin_share;
                     exhausted = true;
                 } else {
                     // (the lane id recomputed here - two instructions - instead of held in a VGPR across the step loop: the dense build has none to spare)
@@ -1149,7 +1165,8 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
                     if (base + n >= qcount) exhausted = true;
                 }
                 const uint32_t rank = lanes_below(need);
-                const uint32_t idx = base + rank;
+                uint32_t idx = base + rank;
+                if (!DENSE && thin_stride != 0u) idx = base + rank * thin_stride;
                 if (mode == M_EMPTY && (DENSE || rank < n) && idx < qcount) {
                     const uint32_t pix = queue[idx];
                     cold.set_pix(pix);
@@ -1339,7 +1356,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
                 float4 o;
                 F3 color = cold.color();
                 const uint32_t pix = cold.pix();
-                if (COUNT && (unsigned long long)it > cnt[12]) cnt[12] = (unsigned long long)it;
+                if (COUNT && BHRAY_EXPERIMENT_LONGEST_TRAVERSAL == 0 && (unsigned long long)it > cnt[12]) cnt[12] = (unsigned long long)it;
                 if (HIT_GET() || it <= 5) {
                     if (amount > 0.001f) {
                         if (COUNT) cnt[9]++;
