@@ -288,14 +288,16 @@ __device__ __forceinline__ bool hit_triangle(F3 pos, F3 dir, float t_min, float 
 #ifndef BHRAY_BVH_LDS_STACK
 #define BHRAY_BVH_LDS_STACK 8      // entries of the short traversal stack in LDS (16 KB per 256-thread block: 8 blocks per CU fit in 160 KB)
 #endif
+// Build flags of measured experiments (profiles/EXPERIMENTS.md R5.5, R5.8, R5.9): all off in the product; the mesh variant's build for a saturated device
+// (trace_kernel<.., MODELS = true, .., DENSE = true>) has BHRAY_MESH_PARK, BHRAY_FLAT_COLD and BHRAY_BVH_WHILE_WHILE switched on by its template parameters.
 #ifndef BHRAY_MESH_PARK
-#define BHRAY_MESH_PARK 0          // 1: the mesh variant's traversal in a region of its own, the marching state stored to scratch around it (see the flat phase)
+#define BHRAY_MESH_PARK 0          // 1: also the mesh variant's LATENCY build runs its traversal in a region of its own, the marching state stored to scratch around it (see the flat phase)
 #endif
 #ifndef BHRAY_FLAT_COLD
-#define BHRAY_FLAT_COLD 0
+#define BHRAY_FLAT_COLD 0          // 1: also the latency build marks the flat phase unlikely
 #endif
 #ifndef BHRAY_EXPERIMENT_NO_TRAVERSAL
-#define BHRAY_EXPERIMENT_NO_TRAVERSAL 0
+#define BHRAY_EXPERIMENT_NO_TRAVERSAL 0      // 1 = an EXPERIMENT: the mesh variant without its traversal - what the traversal's mere presence costs the march (R5.5)
 #endif
 #ifndef BHRAY_THIN_STRIDED_BELOW
 #define BHRAY_THIN_STRIDED_BELOW 0    // thin dealing: a wave's share is taken STRIDED (every waves-th entry) when it is below this many rays (0: never; see trace_kernel and profiles/EXPERIMENTS.md R5.9: mixed, off)
@@ -1313,7 +1315,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
                                         if (COUNT && skip) cnt[6]++;
                                     }
                                 }
-#if !BHRAY_EXPERIMENT_NO_TRAVERSAL      // (1 = an EXPERIMENT: the mesh variant without its traversal - what the traversal's mere presence costs the march, profiles/EXPERIMENTS.md R5.8)
+#if !BHRAY_EXPERIMENT_NO_TRAVERSAL      
                                 if (!skip) trace_ray_model<COUNT, BVH_WW>(P.models[mi], bvh_lds, cpos, cdir, t_min, t_max, r, nrm, cnt, &err);
 #endif
                                 if (r.hit && r.t < rs.t) {

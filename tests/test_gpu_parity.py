@@ -470,6 +470,36 @@ def test_production_configuration_is_invariant_at_full_size():
 
 
 @pytest.mark.parametrize("method", [1, 0])
+def test_the_mesh_variant_s_two_builds_deliver_the_same_frame(tmp_path, method, monkeypatch):
+    """The mesh variant has a build for lone launches (5 waves per SIMD, the traversal inline in the flat phase) and one for a saturated
+    device (6 waves: the traversal in a region of its own with the marching state stored around it, while-while form - trace_kernel's
+    MESH_DENSE).  Same pixels at every level and the same counters, with the camera outside the sphere (a traversal before the march and one
+    after it) and inside it; the build a ctx picks by itself is one of the two."""
+    tex = T.textures()
+    model = _mesh_model(tmp_path)
+    d = np.array([-0.12, 0.0, 1.0]); d /= np.linalg.norm(d)
+    for cam, pos in ((B.Camera(position=(0.0, 0.0, -40.0), forward=tuple(d), fov=1.2), None), (B.Camera(), (-6.0, 0.0, 32.0))):
+        if pos is not None:
+            model.set_transform(pos, 1)
+        u = T.uniforms(camera=cam, integration_method=method, model_count=1)
+        cfg = B.ladder_for_frame((240, 135), 3, 3)
+        got = {}
+        for name, env, fif in (("latency", "0", 1), ("dense", "1", 1), ("auto 1 slot", None, 1), ("auto 6 slots", None, 6)):
+            monkeypatch.delenv("BHRAY_TRACE_DENSE", raising=False)
+            if env is not None:
+                monkeypatch.setenv("BHRAY_TRACE_DENSE", env)
+            rp = run_gpu(cfg, *u, tex, model=model, frames_in_flight=fif, counters=True)
+            got[name] = ([rp.read_level(l) for l in range(3)], rp.counters())
+            rp.close()
+        ref_levels, ref_counters = got["latency"]
+        assert ref_counters["triangles"] > 0 and ref_counters["node_pairs"] > ref_counters["flat_iters"] // 2
+        for name, (levels, counters) in got.items():
+            for a, b in zip(levels, ref_levels):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (name, pos)
+            assert counters == ref_counters, (name, pos)
+
+
+@pytest.mark.parametrize("method", [1, 0])
 def test_latency_build_and_dense_build_deliver_the_same_frame(method, monkeypatch):
     """One frame slot selects the latency build (lean step form, short queues dealt out one wave per SIMD: bhray_step.inc, trace_kernel),
     four slots the dense build; BHRAY_TRACE_DENSE forces either.  Same pixels at every level, same counters — scheduling and control
