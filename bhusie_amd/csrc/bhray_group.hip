@@ -55,6 +55,7 @@ struct Rccl {
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;       // (optional: only a failed ctx is torn down with it)
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclSend) Send = nullptr;
@@ -85,6 +86,7 @@ Rccl* rccl() {
     SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy"); SYM(GroupStart, "ncclGroupStart");
     SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(AllGather, "ncclAllGather"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
+    *(void**)(&r.CommAbort) = dlsym(so, "ncclCommAbort");
     if (r.GetVersion(&r.version) != ncclSuccess) r.version = 0;
     g_rccl = r;
     return &g_rccl;
@@ -515,6 +517,11 @@ int group_sync(bhray_ctx* c) {
 
 void group_free(bhray_ctx* c) {
     Rccl* R = g_rccl.so ? &g_rccl : nullptr;
+    // A ctx that failed in the middle of a batch (one rank's issue thread met an error, the others have posted their sends and receives)
+    // may hold RCCL operations that will never be matched: they are aborted, or the synchronisations below would wait for them for ever.
+    if ((c->failed.load() || c->async_failed.load()) && R && R->CommAbort) {
+        for (CommRank& r : c->ranks) if (r.comm) { (void)hipSetDevice(r.device); (void)R->CommAbort(r.comm); r.comm = nullptr; }
+    }
     for (CommRank& r : c->ranks) if (r.stream) { (void)hipSetDevice(r.device); (void)hipStreamSynchronize(r.stream); }
     for (Part& p : c->parts) if (p.dev) { dev_destroy(p.dev); p.dev = nullptr; }
     for (uint32_t q = 0; q < c->parts.size(); q++) {
