@@ -302,6 +302,9 @@ __device__ __forceinline__ bool hit_triangle(F3 pos, F3 dir, float t_min, float 
 #ifndef BHRAY_THIN_STRIDED_BELOW
 #define BHRAY_THIN_STRIDED_BELOW 0    // thin dealing: a wave's share is taken STRIDED (every waves-th entry) when it is below this many rays (0: never; see trace_kernel and profiles/EXPERIMENTS.md R5.9: mixed, off)
 #endif
+#ifndef BHRAY_EXPERIMENT_FLAT_CLOCK
+#define BHRAY_EXPERIMENT_FLAT_CLOCK 0          // 1 = an EXPERIMENT (counting builds, latency mesh build): bhray_counters.max_ray_iterations holds the longest time one WAVE spent in flat phases (100 MHz ticks), rays_adopted the number of flat phases
+#endif
 #ifndef BHRAY_EXPERIMENT_LONGEST_TRAVERSAL
 #define BHRAY_EXPERIMENT_LONGEST_TRAVERSAL 0   // 1 = an EXPERIMENT (counting builds): bhray_counters.longest_ray holds the longest TRAVERSAL instead - loop iterations (inner nodes + leaves + re-descents) of one call
 #endif
@@ -1282,6 +1285,10 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
         }
         // (FLAT_COLD: the flat phase marked unlikely, so that the register allocator weighs the step loop above the traversal's loops)
         const bool flat_now = run_flat && __any(mode == M_FLAT);
+#if BHRAY_EXPERIMENT_FLAT_CLOCK
+        unsigned long long flat_t0 = 0ull;
+        if (COUNT && flat_now) flat_t0 = wall_clock64();
+#endif
         if (FLAT_COLD ? __builtin_expect(flat_now, 0) : flat_now) {
             if (mode == M_FLAT) {
                 if (it >= H.max_iter) {
@@ -1351,6 +1358,9 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
                 }
             }
         }
+#if BHRAY_EXPERIMENT_FLAT_CLOCK
+        if (COUNT && flat_now) { cnt[12] += wall_clock64() - flat_t0; if (lane == 0) cnt[11]++; }     // per wave: time in flat phases (100 MHz ticks; the maximum over waves is reported), number of flat phases (summed)
+#endif
 
         // ---- epilogue (ray.wgsl:583-595) for lanes whose loop ended
         if (__any(mode == M_FINISH)) {
@@ -1358,7 +1368,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
                 float4 o;
                 F3 color = cold.color();
                 const uint32_t pix = cold.pix();
-                if (COUNT && BHRAY_EXPERIMENT_LONGEST_TRAVERSAL == 0 && (unsigned long long)it > cnt[12]) cnt[12] = (unsigned long long)it;
+                if (COUNT && BHRAY_EXPERIMENT_LONGEST_TRAVERSAL == 0 && BHRAY_EXPERIMENT_FLAT_CLOCK == 0 && (unsigned long long)it > cnt[12]) cnt[12] = (unsigned long long)it;
                 if (HIT_GET() || it <= 5) {
                     if (amount > 0.001f) {
                         if (COUNT) cnt[9]++;
