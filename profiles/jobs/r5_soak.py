@@ -18,6 +18,11 @@ one = B.RayPass(cfg, device=0); one.set_textures(*tex)
 rp = B.RayPass(cfg, devices=[0] * 8, frames_in_flight=22, frames_per_batch=5, speculative_levels=2)
 rp.set_textures(*tex)
 rng = np.random.default_rng(7)
+if len(sys.argv) > 2 and sys.argv[2] == "worst-first":          # every partition holds the whole frame once: after that nothing may grow any more
+    rp.set_uniforms(*uniforms(0))
+    for p in range(8):
+        rp.set_partition([0] * (p + 1) + [720] * (8 - p)); rp.render()
+    rp.sync()
 mem, checked, applied, t0 = [], 0, 0, time.perf_counter()
 for i in range(N):
     if i and i % 20 == 0:
