@@ -1320,7 +1320,12 @@ int launch_batch(bhray_dev* c) {
     int bpc = trace_blocks_per_cu(S.method, S.models, count, dense, literal);
     if (c->slots.size() > 1 && bpc > 1) bpc = bpc > 4 ? 2 : (bpc / 2 > 1 ? bpc / 2 : 1);     // measured: 2 blocks per CU is best at 8-16 slots
     if (c->bpc_override > 0) bpc = c->bpc_override;
-    const int grid = c->grid_override > 0 ? c->grid_override : c->num_cus * bpc;
+    int grid = c->num_cus * bpc;
+    // ... and one and a half for the Euler kernels (their steps are short: a block's share of a queue is used up sooner, and a smaller grid leaves the later launches'
+    // blocks room beside it): 512 -> 384 blocks at 22 slots +1.5 % (20- and 400-frame blocks), with the mesh +2.4-3 %, a rank of 8 0 / +2 %; the RK kernels: nothing
+    // (profiles/r05_ab_euler_grid.txt, EXPERIMENTS.md R5.9)
+    if (S.method == 0 && c->slots.size() >= 8 && bpc == 2 && c->bpc_override <= 0) grid = c->num_cus * 3 / 2;      // (measured at 22 slots only: from 8 slots on)
+    if (c->grid_override > 0) grid = c->grid_override;
     BatchPlan plan{c, S, nb, nl, count, literal, grid, st, (size_t)B * sizeof(FrameParams)};
     const uint32_t ns = c->cfg.speculative_levels;
     const bool any_rows = !c->levels[nl - 1].rows.empty();    // a partition without rows has nothing to launch (then no level has rows)
