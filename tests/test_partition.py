@@ -151,3 +151,36 @@ def test_rebalance_slabs_gives_the_root_fewer_rows_for_its_extra_work_and_reject
         args.update(bad)
         with pytest.raises(B.BhrayError):
             B.rebalance_slabs(h, args["slab_row0"], args["part_ms"], np.zeros(h))
+
+
+def test_rebalance_slabs_on_random_input_keeps_its_invariants_and_finds_the_best_bounds():
+    """Random frames, worlds, bounds (empty slabs included), costs, root extras and shifts: the bounds stay a partition of the frame, the row
+    weights carry the measured total, the prediction is the largest (weights of the slab + extra) of the bounds returned - and no other
+    contiguous partition of those weights does better (brute force on small frames)."""
+    import itertools
+    rng = np.random.default_rng(11)
+    for trial in range(300):
+        small = trial < 120
+        h = int(rng.integers(3, 14)) if small else int(rng.integers(20, 1500))
+        world = int(rng.integers(2, 5)) if small else int(rng.integers(2, 17))
+        cuts = np.sort(rng.integers(0, h + 1, size=world - 1))
+        b = [0] + [int(v) for v in cuts] + [h]
+        w = np.zeros(h) if trial % 3 == 0 else rng.uniform(0.0, 2.0, size=h)
+        ms = [float(rng.uniform(0.1, 5.0)) if b[p + 1] > b[p] or rng.random() < 0.5 else 0.0 for p in range(world)]
+        extra = None if trial % 2 else [float(rng.uniform(0.0, 1.5)) if rng.random() < 0.3 else 0.0 for _ in range(world)]
+        shift = 0.0 if trial % 4 else float(rng.uniform(-0.3, 0.3) * h)
+        prior = w.copy() if w.any() else np.ones(h)                       # (weights that are all zero start as equal rows)
+        nb, pred = B.rebalance_slabs(h, b, ms, w, extra_ms=extra, shift_rows=shift)
+        assert nb[0] == 0 and nb[-1] == h and all(x <= y for x, y in zip(nb, nb[1:])), (trial, nb)
+        assert np.all(w >= 0.0) and np.all(np.isfinite(w))
+        if shift == 0.0:      # a slab with rows and a measurement now weighs what it was measured at; every other row keeps its weight
+            want = sum(ms[p] if ms[p] > 0.0 else float(prior[b[p]:b[p + 1]].sum()) for p in range(world) if b[p + 1] > b[p])
+            assert abs(float(w.sum()) - want) <= 1e-9 * max(1.0, want), (trial, float(w.sum()), want)
+        ex = extra if extra is not None else [0.0] * world
+        wf = np.maximum(w, 1e-6 * float(w.sum()) / h)                      # a row costs something: the floor the packing works with
+        load = [float(wf[nb[p]:nb[p + 1]].sum()) + ex[p] for p in range(world)]
+        assert abs(max(load) - pred) <= 1e-6 * max(1.0, pred), (trial, load, pred)
+        if small:
+            best = min(max(float(wf[c[p]:c[p + 1]].sum()) + ex[p] for p in range(world))
+                       for mid in itertools.combinations_with_replacement(range(h + 1), world - 1) for c in [(0,) + mid + (h,)])
+            assert pred <= best * (1.0 + 1e-6) + 1e-12, (trial, pred, best, nb)
