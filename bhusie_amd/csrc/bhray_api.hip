@@ -1364,6 +1364,8 @@ int launch_batch(bhray_dev* c) {
         if (Ln.kind != 1) continue;
         FrameLaunch* hl = (FrameLaunch*)(S.h_args + ((const uint8_t*)Ln.d - S.d_args));
         for (uint32_t k = 0; k < nb; k++) hl[k].work = S.fr[k].d_work;
+        // a whole frame, one frame per launch: thin shares are dealt strided (bhray_kernels.hip, thin_stride; bit 1 of probe_empty)
+        if (c->cfg.row_world <= 1 && nb == 1) hl[0].probe_empty |= 2;
     }
     S.launched_frames = nb;
     // enqueue

@@ -166,7 +166,7 @@ struct FrameLaunch {
     int radius;            // predict_kernel: dilation of the previous frame's traced set, in pixels of this level
     const uint32_t* stamp; // this level's stamp image (classify); nullptr outside temporal mode
     uint32_t stamp_value;  // stamp of the current frame
-    int probe_empty;       // trace: this launch is expected to find its queue (nearly) used up - look before the first atomic
+    int probe_empty;       // trace, bit 0: this launch is expected to find its queue (nearly) used up - look before the first atomic; bit 1: thin shares are dealt strided (a whole frame, one frame per launch)
     int blocks;            // predict (one launch, all levels): this level's own block count
     const FusedFrame* fz;  // fused ladder: this frame's tile graph and queues (nullptr otherwise)
     unsigned long long* span; // trace, entry 0 of a timed launch: [0] max(~first block start) [1] max(last block end), device wall clock; nullptr: untimed

@@ -300,7 +300,7 @@ __device__ __forceinline__ bool hit_triangle(F3 pos, F3 dir, float t_min, float 
 #define BHRAY_EXPERIMENT_NO_TRAVERSAL 0      // 1 = an EXPERIMENT: the mesh variant without its traversal - what the traversal's mere presence costs the march (R5.5)
 #endif
 #ifndef BHRAY_THIN_STRIDED_BELOW
-#define BHRAY_THIN_STRIDED_BELOW 0    // thin dealing: a wave's share is taken STRIDED (every waves-th entry) when it is below this many rays (0: never; see trace_kernel and profiles/EXPERIMENTS.md R5.9: mixed, off)
+#define BHRAY_THIN_STRIDED_BELOW 32   // thin dealing of a whole frame: a wave's share is taken STRIDED (every waves-th entry) when it is below this many rays (see trace_kernel)
 #endif
 #ifndef BHRAY_EXPERIMENT_FLAT_CLOCK
 #define BHRAY_EXPERIMENT_FLAT_CLOCK 0          // 1 = an EXPERIMENT (counting builds, latency mesh build): bhray_counters.max_ray_iterations holds the longest time one WAVE spent in flat phases (100 MHz ticks), rays_adopted the number of flat phases
@@ -1075,7 +1075,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
     // used to take.  Only here (a load in front of every refill doubles the refill's round trips: -6 % throughput, measured) and only
     // in the latency build and in launches the host expects to be nearly empty (probe_empty): in the dense build even the untaken
     // branch costs a saturated device 2 % (measured: 4 930 -> 4 835 Mrays/s).
-    if (!DENSE && F.probe_empty && __hip_atomic_load(qhead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= qcount) continue;
+    if (!DENSE && (F.probe_empty & 1) && __hip_atomic_load(qhead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= qcount) continue;
     // Latency build, a queue with fewer rays than one wave per SIMD has lanes (coarse ladder levels, fix-up launches): the rays are dealt
     // out evenly over the first BHRAY_THIN_WAVES waves (one per SIMD: the first blocks of a grid land on different CUs) - wave w takes
     // entries [w * share, (w + 1) * share) once, without an atomic - instead of 64 to each of the first waves.  (Over ALL waves of the
@@ -1086,10 +1086,11 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
     // A batch (nb > 1): the blocks whose OWN frame this is (blockIdx % nb == fb: every block starts with its own frame) deal the frame's
     // rays out among themselves the same way, and the blocks that come by later to help (fi > 0) leave such a frame alone - it has no
     // queue head to pull from.  (A rank of an 8-way partition renders its coarse levels in launches of ten frames x a few hundred rays.)
-    // (BHRAY_THIN_STRIDED_BELOW > 0, an experiment: a share of fewer rays than that is taken STRIDED - wave w takes entries w, w + waves, w + 2 waves, ... -
-    // so that every wave holds an even sample of the queue instead of neighbouring pixels.  One frame at a time, levels 0+1 of 1920x1080: RK 0.285 -> 0.252 ms,
-    // Euler 0.194 -> 0.167, with the mesh 0.662 -> 0.575 - but level 2 of the sky slab of an 8-way partition 0.187 -> 0.205, and batches of a rank's frames
-    // 0.077 -> 0.081 ms per frame: neighbours finish together.  Off.)
+    // A WHOLE frame, one frame per launch (the host says so: bit 1 of probe_empty): a share of fewer than BHRAY_THIN_STRIDED_BELOW rays is taken STRIDED - wave w takes
+    // entries w, w + waves, w + 2 waves, ... - so that every wave holds an even sample of the frame instead of neighbouring pixels: no wave is left with nothing but the photon
+    // ring's rays.  One frame at a time, levels 0+1 of 1920x1080: RK 0.285 -> 0.247 ms, Euler 0.194 -> 0.162, with the mesh 0.66 -> 0.57 (the frame 1.21 -> 1.18, 0.805 -> 0.762 ms).
+    // Not for a rank of a partition (the sky slab of an 8-way partition: level 2 0.187 -> 0.205) nor for batches (0.077 -> 0.081 ms per frame): neighbouring rays finish
+    // together, and an even sample only helps the launch that holds the ring and nothing else (profiles/EXPERIMENTS.md R5.9).
     uint32_t thin_share = 0, thin_block = blockIdx.x, thin_stride = 0;
     if (MODELS) {                                         // the mesh variant (96-VGPR budget: -2 % with the batch form below) keeps the single-frame form
         if (!DENSE && nb == 1 && BHRAY_THIN_WAVES > 0) {
@@ -1097,7 +1098,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
             const uint32_t waves = total < (uint32_t)BHRAY_THIN_WAVES ? total : (uint32_t)BHRAY_THIN_WAVES;
             const uint32_t share = (qcount + waves - 1) / waves;
             if (share < 64u) thin_share = share > 0u ? share : 1u;
-            if (share < (uint32_t)BHRAY_THIN_STRIDED_BELOW) thin_stride = waves;
+            if ((F.probe_empty & 2) && share < (uint32_t)BHRAY_THIN_STRIDED_BELOW) thin_stride = waves;
         }
     } else if (!DENSE && !FZ && BHRAY_THIN_WAVES > 0 && (nb == 1 || gridDim.x >= 4u * (uint32_t)nb)) {   // (the fused ladder has its own queues and its own frame loop; every frame of a batch needs blocks of its own)
         uint32_t own_blocks = gridDim.x;
@@ -1108,7 +1109,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
         if (waves > 0u) {
             const uint32_t share = (qcount + waves - 1) / waves;
             if (share < 64u) thin_share = share > 0u ? share : 1u;
-            if (nb == 1 && share < (uint32_t)BHRAY_THIN_STRIDED_BELOW) thin_stride = waves;     // (a batch of a rank's thin frames keeps a device busy: neighbours together, 0.077 against 0.081 ms per frame on a rank of 8)
+            if ((F.probe_empty & 2) && share < (uint32_t)BHRAY_THIN_STRIDED_BELOW) thin_stride = waves;
         }
         if (thin_share != 0u && fi != 0) continue;
     }
