@@ -83,6 +83,10 @@ def balance_slabs(cfg: BhrayConfig, row_work, world: int):
 def rebalance_slabs(frame_h: int, slab_row0, part_ms, row_weight: np.ndarray, extra_ms=None, shift_rows: float = 0.0):
     """bhray_rebalance_slabs: (new bounds, predicted slowest partition); row_weight (float64[frame_h], zeros before the first call) is updated in place."""
     world = len(part_ms)
+    if len(slab_row0) != world + 1:
+        raise ValueError(f"rebalance_slabs: {world} partitions need {world + 1} bounds, got {len(slab_row0)}")
+    if extra_ms is not None and len(extra_ms) != world:
+        raise ValueError(f"rebalance_slabs: extra_ms has {len(extra_ms)} entries for {world} partitions")
     assert row_weight.dtype == np.float64 and row_weight.shape == (frame_h,) and row_weight.flags.c_contiguous
     b_in = (C.c_uint32 * (world + 1))(*[int(v) for v in slab_row0])
     ms = (C.c_double * world)(*[float(v) for v in part_ms])
@@ -177,7 +181,10 @@ class RayPass:
     # -- run-time partition (multi-GPU balance that follows the scene)
     def set_partition(self, slab_row0):
         """From the next render on partition p owns frame rows [slab_row0[p], slab_row0[p + 1]) - no re-create (bhray_set_partition)."""
-        a = (C.c_uint32 * len(slab_row0))(*[int(v) for v in slab_row0])
+        parts = int(self.cfg.device_count) if self.cfg.device_count >= 2 else max(1, int(self.cfg.row_world))
+        if len(slab_row0) != parts + 1:                     # the library reads partitions + 1 entries whatever it is handed
+            raise ValueError(f"set_partition: {parts} partitions need {parts + 1} bounds, got {len(slab_row0)}")
+        a = (C.c_uint32 * (parts + 1))(*[int(v) for v in slab_row0])
         check(self._L.bhray_set_partition(self._h, a), self._h, self._L)
 
     def get_partition(self):

@@ -68,6 +68,8 @@ def test_set_partition_on_a_ctx_created_with_stripes_and_on_one_rank_of_a_partit
     with pytest.raises(B.BhrayError):
         rp.get_partition()                                       # interleaved stripes have no bounds
     rp.set_partition([0, 40, 70, 110])
+    with pytest.raises(ValueError):                        # a short list never reaches the library
+        rp.set_partition([0, 40, 110])
     rp.render()
     assert np.array_equal(rp.read_hdr().view(np.uint32), want.view(np.uint32))
     rp.close()
