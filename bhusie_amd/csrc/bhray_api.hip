@@ -70,10 +70,6 @@ struct FrameRes {
     uint64_t sky_frame_id = ~0ull;      // frame_id of the frame sky_out was resolved from (a slot position is reused: an older frame's image is stale)
     uint64_t frame_id = 0;              // frame_counter value of the frame held here
     int row_variant = -1;               // which ordering of the level rows this frame classifies in (Level::d_rows_near), -1: ascending
-    // fused ladder: per-frame tile state and queues (bhray_internal.h)
-    FusedCtl* fz_ctl = nullptr; uint32_t* fz_deps = nullptr; uint32_t* fz_pending = nullptr; unsigned long long* fz_cq = nullptr;
-    std::vector<unsigned long long*> fz_rq;
-    uint32_t fz_stamp = 0;
 };
 
 // One batch in flight: a HIP stream, the frames of the batch (frames_per_batch of them) and the argument block of its
@@ -95,18 +91,6 @@ struct Slot {
     uint8_t* d_args = nullptr;
     size_t args_cap = 0;
     uint64_t batch_id = 0;              // batch_counter value of the batch this slot holds
-};
-
-// Fused ladder (BHRAY_F_FUSED): the tile graph of the ctx's geometry - which coarse tile columns / rows every tile column / row reads,
-// and the transposed lists (who depends on a coarse tile column / row).  Separable: a tile's dependencies are (its column's) x (its row's).
-struct FusedTables {
-    bool on = false;
-    uint32_t tile_base[BHRAY_MAX_SPEC_LEVELS] = {0}, tiles_x[BHRAY_MAX_SPEC_LEVELS] = {0}, tiles_y[BHRAY_MAX_SPEC_LEVELS] = {0};
-    uint32_t total_tiles = 0, n_initial = 0, init_end[BHRAY_MAX_SPEC_LEVELS] = {0};
-    int32_t* d_row_index[BHRAY_MAX_SPEC_LEVELS] = {nullptr};
-    uint8_t* d_xdep[BHRAY_MAX_SPEC_LEVELS] = {nullptr}; uint8_t* d_ydep[BHRAY_MAX_SPEC_LEVELS] = {nullptr};
-    uint32_t* d_nx_off[BHRAY_MAX_SPEC_LEVELS] = {nullptr}; uint16_t* d_nx_list[BHRAY_MAX_SPEC_LEVELS] = {nullptr};
-    uint32_t* d_ny_off[BHRAY_MAX_SPEC_LEVELS] = {nullptr}; uint16_t* d_ny_list[BHRAY_MAX_SPEC_LEVELS] = {nullptr};
 };
 
 struct ModelStore {
@@ -145,7 +129,6 @@ struct bhray_dev {
     uint8_t* tex[3] = {nullptr, nullptr, nullptr};
     int tex_w[3] = {0, 0, 0}, tex_h[3] = {0, 0, 0};
     ModelStore models[BHRAY_MAX_MODELS];
-    FusedTables fz;
     bhray_camera_uniform cam{};
     bhray_black_hole_uniform bh{};
     bhray_details det{};
@@ -389,11 +372,6 @@ void dev_destroy(bhray_dev* c) {
             if (R.own_out) (void)hipFree(R.own_out);
             if (R.d_row_work) (void)hipFree(R.d_row_work);
             if (R.sky_out) (void)hipFree(R.sky_out);
-            if (R.fz_ctl) (void)hipFree(R.fz_ctl);
-            if (R.fz_deps) (void)hipFree(R.fz_deps);
-            if (R.fz_pending) (void)hipFree(R.fz_pending);
-            if (R.fz_cq) (void)hipFree(R.fz_cq);
-            for (auto q : R.fz_rq) if (q) (void)hipFree(q);
         }
         if (S.d_qctl) (void)hipFree(S.d_qctl);
         if (S.d_counters) (void)hipFree(S.d_counters);
@@ -407,10 +385,6 @@ void dev_destroy(bhray_dev* c) {
         if (L.d_rows) (void)hipFree(L.d_rows);
         if (L.d_rows_near) (void)hipFree(L.d_rows_near);
         if (L.d_rowmap) (void)hipFree(L.d_rowmap);
-    }
-    for (int l = 0; l < BHRAY_MAX_SPEC_LEVELS; l++) {
-        void* ps[] = {c->fz.d_row_index[l], c->fz.d_xdep[l], c->fz.d_ydep[l], c->fz.d_nx_off[l], c->fz.d_nx_list[l], c->fz.d_ny_off[l], c->fz.d_ny_list[l]};
-        for (void* q : ps) if (q) (void)hipFree(q);
     }
     for (auto& t : c->tex) if (t) (void)hipFree(t);
     for (auto& m : c->models) free_model(m);
@@ -442,7 +416,7 @@ int build_row_tables(bhray_dev* c) {
         if (!L.d_rows) HIPCHK(c, hipMalloc(&L.d_rows, (size_t)L.h * sizeof(int32_t)));
         if (nrows) {
             HIPCHK(c, hipMemcpy(L.d_rows, L.rows.data(), nrows * sizeof(int32_t), hipMemcpyHostToDevice));
-            if (BHRAY_ROW_VARIANTS >= 2 && !(cfg->flags & BHRAY_F_FUSED)) {
+            if (BHRAY_ROW_VARIANTS >= 2) {
                 // The same rows with the tile rows (8 list entries) nearest a centre row first: the rays that pass closest to the hole are the
                 // longest, and a launch lasts as long as its last rays - classified first they enter the queue first and are traced first
                 // (every pixel is classified independently of the others: the order changes nothing else).  One ordering per centre row;
@@ -559,10 +533,8 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
         return fail(nullptr, BHRAY_E_INVALID, "superset_levels must be 0 or 2..%d and leave at least one coarser level (beyond the speculative ones)", BHRAY_MAX_SPEC_LEVELS);
     if ((cfg->flags & BHRAY_F_TEMPORAL) && (cfg->levels > BHRAY_MAX_SPEC_LEVELS || cfg->speculative_levels || cfg->superset_levels))
         return fail(nullptr, BHRAY_E_INVALID, "BHRAY_F_TEMPORAL needs levels <= %d and no speculative / superset levels", BHRAY_MAX_SPEC_LEVELS);
-    if ((cfg->flags & BHRAY_F_FUSED) && fused_blocks_per_cu(0, 0, 0, 0) == 0)
-        return fail(nullptr, BHRAY_E_INVALID, "this build of libbhray has no fused ladder (BHRAY_F_FUSED): it is a build option, `make -C bhusie_amd/csrc fused` -> libbhray_fused.so");
-    if ((cfg->flags & BHRAY_F_FUSED) && (cfg->levels > BHRAY_MAX_SPEC_LEVELS || cfg->superset_levels || (cfg->flags & BHRAY_F_TEMPORAL)))
-        return fail(nullptr, BHRAY_E_INVALID, "BHRAY_F_FUSED needs levels <= %d and neither superset levels nor BHRAY_F_TEMPORAL", BHRAY_MAX_SPEC_LEVELS);
+    if (cfg->flags & ~(uint32_t)BHRAY_F_ALL)
+        return fail(nullptr, BHRAY_E_INVALID, "unknown bits in bhray_config.flags (0x%x; bit 6 was BHRAY_F_FUSED, the fused ladder of rounds 3-5: measured slower, removed - profiles/variants_src/)", cfg->flags & ~(uint32_t)BHRAY_F_ALL);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(nullptr, BHRAY_E_NO_DEVICE, "no HIP device visible (libbhray has no CPU path)");
@@ -611,68 +583,6 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
     for (uint32_t l = 0; l < nl; l++) c->row_work_off[l + 1] = c->row_work_off[l] + (size_t)cfg->level_h[l];
     // rows of the frame owned by this partition, the level rows they depend on, their device tables
     { int rc_ = build_row_tables(c); if (rc_) { g_create_error = c->err; dev_destroy(c); return rc_; } }
-    if ((cfg->flags & BHRAY_F_FUSED) && !c->levels[nl - 1].rows.empty()) {
-        FusedTables& Z = c->fz;
-        Z.on = true;
-        const uint32_t nall = cfg->speculative_levels ? cfg->speculative_levels : 1;      // all-traced levels
-        std::vector<std::vector<int32_t>> row_index(nl);
-        uint32_t base = 0;
-        for (uint32_t l = 0; l < nl; l++) {
-            const Level& L = c->levels[l];
-            const bool last = l == nl - 1;
-            const int X0 = last ? (int)cfg->crop_x : 0, X1 = last ? (int)(cfg->crop_x + cfg->frame_w) : L.w;
-            Z.tile_base[l] = base; Z.tiles_x[l] = (uint32_t)((X1 - X0 + 7) / 8); Z.tiles_y[l] = (uint32_t)((L.rows.size() + 7) / 8);
-            base += Z.tiles_x[l] * Z.tiles_y[l];
-            if (l < nall) { Z.n_initial += Z.tiles_x[l] * Z.tiles_y[l]; }
-            Z.init_end[l] = Z.n_initial;
-            row_index[l].assign((size_t)L.h, -1);
-            for (size_t j = 0; j < L.rows.size(); j++) row_index[l][(size_t)L.rows[j]] = (int32_t)j;
-            CHK(hipMalloc(&Z.d_row_index[l], (size_t)L.h * sizeof(int32_t)));
-            CHK(hipMemcpy(Z.d_row_index[l], row_index[l].data(), (size_t)L.h * sizeof(int32_t), hipMemcpyHostToDevice));
-        }
-        Z.total_tiles = base;
-        for (uint32_t l = 1; l < nl; l++) {
-            const Level& L = c->levels[l]; const Level& Pv = c->levels[l - 1];
-            const bool last = l == nl - 1;
-            const int X0 = last ? (int)cfg->crop_x : 0, X1 = last ? (int)(cfg->crop_x + cfg->frame_w) : L.w;
-            const int sfx = (L.w - 1) / (Pv.w - 1), sfy = (L.h - 1) / (Pv.h - 1);                  // ray.wgsl:185
-            const float rx = (float)Pv.w / (float)(L.w + (sfx - 1)), ry = (float)Pv.h / (float)(L.h + (sfy - 1));   // ray.wgsl:187 - as level_params
-            auto clampi = [](int v, int n) { return v < 0 ? 0 : (v > n - 1 ? n - 1 : v); };
-            std::vector<std::vector<uint16_t>> xs(Z.tiles_x[l]), ys(Z.tiles_y[l]);
-            auto add = [](std::vector<uint16_t>& v, int t) { for (uint16_t e : v) if (e == (uint16_t)t) return; v.push_back((uint16_t)t); };
-            for (int x = X0; x < X1; x++) {
-                const float tl = floorf((float)x * rx);
-                add(xs[(size_t)((x - X0) >> 3)], clampi((int)tl, Pv.w) >> 3);
-                add(xs[(size_t)((x - X0) >> 3)], clampi((int)(tl + 1.0f), Pv.w) >> 3);
-            }
-            for (size_t j = 0; j < L.rows.size(); j++) {
-                const float tl = floorf((float)L.rows[j] * ry);
-                const int ja = row_index[l - 1][(size_t)clampi((int)tl, Pv.h)], jb = row_index[l - 1][(size_t)clampi((int)(tl + 1.0f), Pv.h)];
-                if (ja < 0 || jb < 0) { int rc_ = fail(nullptr, BHRAY_E_STATE, "internal: fused ladder: level %u row %d reads a coarse row this partition does not compute", l, L.rows[j]); dev_destroy(c); return rc_; }
-                add(ys[j >> 3], ja >> 3); add(ys[j >> 3], jb >> 3);
-            }
-            std::vector<uint8_t> xd(xs.size()), yd(ys.size());
-            for (size_t t = 0; t < xs.size(); t++) xd[t] = (uint8_t)xs[t].size();
-            for (size_t t = 0; t < ys.size(); t++) yd[t] = (uint8_t)ys[t].size();
-            CHK(hipMalloc(&Z.d_xdep[l], xd.size())); CHK(hipMemcpy(Z.d_xdep[l], xd.data(), xd.size(), hipMemcpyHostToDevice));
-            CHK(hipMalloc(&Z.d_ydep[l], yd.size())); CHK(hipMemcpy(Z.d_ydep[l], yd.data(), yd.size(), hipMemcpyHostToDevice));
-            // transposed: dependents of every coarse tile column / row (CSR), stored with the COARSE level l-1
-            auto transpose = [&](const std::vector<std::vector<uint16_t>>& sets, uint32_t ncoarse, uint32_t*& d_off, uint16_t*& d_list) -> hipError_t {
-                std::vector<uint32_t> off(ncoarse + 1, 0);
-                for (const auto& v : sets) for (uint16_t e : v) off[(size_t)e + 1]++;
-                for (uint32_t i = 0; i < ncoarse; i++) off[i + 1] += off[i];
-                std::vector<uint16_t> list(off[ncoarse] ? off[ncoarse] : 1);
-                std::vector<uint32_t> fill(off.begin(), off.end() - 1);
-                for (size_t t = 0; t < sets.size(); t++) for (uint16_t e : sets[t]) list[fill[e]++] = (uint16_t)t;
-                hipError_t e_ = hipMalloc(&d_off, off.size() * sizeof(uint32_t)); if (e_ != hipSuccess) return e_;
-                e_ = hipMemcpy(d_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice); if (e_ != hipSuccess) return e_;
-                e_ = hipMalloc(&d_list, list.size() * sizeof(uint16_t)); if (e_ != hipSuccess) return e_;
-                return hipMemcpy(d_list, list.data(), list.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
-            };
-            CHK(transpose(xs, Z.tiles_x[l - 1], Z.d_nx_off[l - 1], Z.d_nx_list[l - 1]));
-            CHK(transpose(ys, Z.tiles_y[l - 1], Z.d_ny_off[l - 1], Z.d_ny_list[l - 1]));
-        }
-    }
     const size_t nlaunch = 5 * (size_t)nl + 3;                            // upper bound of launches per batch
     // Streams beyond the hardware queues ROCm maps them onto (GPU_MAX_HW_QUEUES, default 4; two are left to the null stream and a
     // communication stream) do not add concurrency, they alias - and a device with MORE streams than queues collapses (24 slots on 24
@@ -692,7 +602,7 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
         CHK(hipMemset(S.d_qctl, 0, B * BHRAY_QCTL_WORDS * sizeof(uint32_t)));
         CHK(hipMalloc(&S.d_counters, B * BHRAY_MAX_LEVELS * sizeof(Counters64)));
         CHK(hipMemset(S.d_counters, 0, B * BHRAY_MAX_LEVELS * sizeof(Counters64)));
-        S.args_cap = (B * (sizeof(FrameParams) + nlaunch * sizeof(FrameLaunch) + sizeof(FusedFrame) + 16) + 15) & ~(size_t)15;
+        S.args_cap = (B * (sizeof(FrameParams) + nlaunch * sizeof(FrameLaunch) + 16) + 15) & ~(size_t)15;
         CHK(hipHostMalloc((void**)&S.h_args, S.args_cap, hipHostMallocDefault));
         CHK(hipMalloc(&S.d_args, S.args_cap));
         S.fr.resize(B);
@@ -736,20 +646,7 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
                 static_assert(BHRAY_MAX_SPEC_LEVELS < BHRAY_MAX_LEVELS, "the predicted queue borrows the last level's control words");
                 R.pred_ctl = R.d_qctl + 2 * (BHRAY_MAX_LEVELS - 1);
             }
-            if (c->fz.on) {
-                const FusedTables& Z = c->fz;
-                CHK(hipMalloc(&R.fz_ctl, sizeof(FusedCtl))); CHK(hipMemset(R.fz_ctl, 0, sizeof(FusedCtl)));
-                CHK(hipMalloc(&R.fz_deps, (size_t)Z.total_tiles * sizeof(uint32_t)));
-                CHK(hipMalloc(&R.fz_pending, (size_t)Z.total_tiles * sizeof(uint32_t)));
-                const size_t ncq = (size_t)Z.total_tiles + Z.n_initial + 64;
-                CHK(hipMalloc(&R.fz_cq, ncq * sizeof(unsigned long long))); CHK(hipMemset(R.fz_cq, 0, ncq * sizeof(unsigned long long)));
-                R.fz_rq.assign(nl, nullptr);
-                for (uint32_t l = 0; l < nl; l++) {
-                    const size_t cap = c->levels[l].queue_cap + 64;
-                    CHK(hipMalloc(&R.fz_rq[l], cap * sizeof(unsigned long long))); CHK(hipMemset(R.fz_rq[l], 0, cap * sizeof(unsigned long long)));
-                }
-            }
-            if ((cfg->flags & BHRAY_F_COUNTERS) && !(cfg->flags & BHRAY_F_FUSED)) {
+            if (cfg->flags & BHRAY_F_COUNTERS) {
                 CHK(hipMalloc(&R.d_row_work, c->row_work_off[nl] * sizeof(unsigned long long)));
                 CHK(hipMemset(R.d_row_work, 0, c->row_work_off[nl] * sizeof(unsigned long long)));
             }
@@ -954,7 +851,6 @@ int dev_set_uniforms(bhray_dev* c, const void* cam32, const void* bh132, const v
 // have none: their first frame is the plain ladder's).
 int dev_set_partition(bhray_dev* c, uint32_t partition, uint32_t stripe_rows, const uint32_t* slab_row0, uint32_t row_rank, uint32_t row_world) {
     if (!c) return BHRAY_E_INVALID;
-    if (c->cfg.flags & BHRAY_F_FUSED) return fail(c, BHRAY_E_STATE, "the partition of a BHRAY_F_FUSED ctx is fixed (its tile graph is built at bhray_create)");
     bhray_config n = c->cfg;
     n.partition = partition; n.row_rank = row_rank; n.row_world = row_world;
     if (stripe_rows) n.stripe_rows = stripe_rows;
@@ -1024,57 +920,6 @@ struct BatchPlan {
         const int span = (l == nl - 1) ? (int)c->cfg.frame_w : Lv.w;
         const int tiles_x = (span + 7) / 8, tiles_y = ((int)Lv.rows.size() + 7) / 8;
         return ((tiles_x + BHRAY_CLASSIFY_BX - 1) / BHRAY_CLASSIFY_BX) * ((tiles_y + BHRAY_CLASSIFY_BY - 1) / BHRAY_CLASSIFY_BY);
-    }
-
-    // BHRAY_F_FUSED: one persistent launch runs every level (bhray_fused.inc; a build option)
-    int fused(uint32_t ns) {
-        // ONE launch for the whole ladder of the batch's frames (bhray_internal.h: fused ladder): the tile state is reset, then the
-        // persistent kernel classifies tiles and traces rays as their dependencies resolve.
-        const FusedTables& Z = c->fz;
-        FrameLaunch* h; const FrameLaunch* d; next_launch(h, d);
-        args_used = (args_used + 15) & ~(size_t)15;
-        FusedFrame* hz = (FusedFrame*)(S.h_args + args_used); const FusedFrame* dz = (const FusedFrame*)(S.d_args + args_used);
-        args_used += (size_t)nb * sizeof(FusedFrame);
-        if (args_used > S.args_cap) return fail(c, BHRAY_E_STATE, "internal: argument block overflow");
-        const uint32_t nall = ns ? ns : 1;
-        for (uint32_t k = 0; k < nb; k++) {
-            FrameRes& R = S.fr[k];
-            if (++R.fz_stamp == 0) R.fz_stamp = 1;                 // queue entries of this launch carry this tag (0 = never written)
-            FusedFrame& F = hz[k];
-            memset(&F, 0, sizeof F);
-            F.nl = (int)nl; F.ns = (int)ns; F.stamp = R.fz_stamp; F.n_initial = Z.n_initial; F.total_tiles = Z.total_tiles;
-            F.n_items = Z.n_initial + (Z.total_tiles - Z.tiles_x[0] * Z.tiles_y[0]);
-            for (uint32_t l = 0; l < BHRAY_MAX_SPEC_LEVELS; l++) F.init_end[l] = l < nl ? Z.init_end[l] : Z.n_initial;
-            F.ctl = R.fz_ctl; F.deps = R.fz_deps; F.pending = R.fz_pending; F.cq = R.fz_cq;
-            for (uint32_t l = 0; l < nl; l++) {
-                FusedLevel& V = F.lv[l];
-                level_params(R, l, V.L);
-                V.L.tag = (int)l;
-                V.all_traced = l < nall ? 1 : 0;
-                if (V.all_traced && l > 0) V.L.spec = R.spec_out[l];
-                V.row_index = Z.d_row_index[l];
-                V.tile_base = Z.tile_base[l]; V.tiles_x = Z.tiles_x[l]; V.tiles_y = Z.tiles_y[l];
-                V.xdep = Z.d_xdep[l]; V.ydep = Z.d_ydep[l];
-                V.nx_off = Z.d_nx_off[l]; V.nx_list = Z.d_nx_list[l]; V.ny_off = Z.d_ny_off[l]; V.ny_list = Z.d_ny_list[l];
-                V.rq = R.fz_rq[l]; V.rq_cap = (uint32_t)(c->levels[l].queue_cap + 64);
-                V.counters = count ? R.d_counters + l : nullptr;
-                if (V.all_traced && l > 0) { V.ray_out = R.spec_out[l]; V.ray_pitch = V.L.w; V.ray_x0 = 0; V.ray_rowmap = nullptr; }
-                else { V.ray_out = V.L.out; V.ray_pitch = V.L.out_pitch; V.ray_x0 = V.L.out_x0; V.ray_rowmap = V.L.rowmap; }
-            }
-            level_params(R, 0, h[k].L);
-            h[k].queue = R.queue[0]; h[k].qctl = R.d_qctl; h[k].counters = count ? R.d_counters : nullptr;
-            h[k].fz = dz + k;
-        }
-        seq.push_back({3, d, (int)Z.total_tiles, false, {0, 1}, {}});
-        std::vector<int> after = {2};
-        for (uint32_t l = 1; l < nl; l++) { after.push_back((int)(3 * l)); after.push_back((int)(3 * l + 1)); after.push_back((int)(3 * l + 2)); }
-        // 2 blocks of 256 threads per CU: every hand-off of the fused ladder is a round trip through the CU's memory queue, whose price grows
-        // with the number of memory-active waves on the CU (one 1080p frame at a time: 4 blocks 2.47 ms, 2 blocks 2.09, 1 block 2.27)
-        int fb_ = fused_blocks_per_cu(S.method, S.models, count, literal);
-        fb_ = fb_ > 2 ? 2 : fb_;
-        if (c->bpc_override > 0) fb_ = c->bpc_override;
-        seq.push_back({4, d, (c->grid_override > 0 ? c->grid_override : c->num_cus * fb_), count, {}, after});
-        return BHRAY_OK;
     }
 
     // speculative_levels = ns: every needed pixel of levels 0..ns-1 traced in ONE launch, then classified
@@ -1334,8 +1179,7 @@ int launch_batch(bhray_dev* c) {
     const uint32_t u0 = nu ? nl - nu : nl;                     // first level of the superset group
     if (any_rows) {
         int rc = BHRAY_OK;
-        if (c->fz.on) rc = plan.fused(ns);
-        else {
+        {
             if (ns) rc = plan.speculative(ns);
             if (!rc && temporal) rc = plan.temporal();
             if (!rc) rc = plan.levels(u0);
@@ -1350,7 +1194,7 @@ int launch_batch(bhray_dev* c) {
     if (timing && c->d_span) {                 // execution spans of this batch's trace launches (entry 0 of each launch's FrameLaunch array)
         int nt = 0;
         for (const Launch& Ln : seq) {
-            if ((Ln.kind != 1 && Ln.kind != 4) || nt >= SPAN_MAX) continue;
+            if (Ln.kind != 1 || nt >= SPAN_MAX) continue;
             FrameLaunch* h0 = (FrameLaunch*)(S.h_args + ((const uint8_t*)Ln.d - S.d_args));
             h0->span = c->d_span + (ring * SPAN_MAX + (size_t)nt) * 2;
             nt++;
@@ -1377,9 +1221,7 @@ int launch_batch(bhray_dev* c) {
     if (timing) { c->sky_recorded[ring] = 0; c->ring_frames[ring] = (uint8_t)nb; }
     for (const Launch& Ln : seq) {
         if (timing) for (int e : Ln.ev_before) HIPCHK(c, hipEventRecord(fev[e], st));
-        if (Ln.kind == 3) HIPCHK(c, launch_fused_reset(Ln.d, (int)nb, Ln.blocks, st));
-        else if (Ln.kind == 4) HIPCHK(c, launch_fused(dP, Ln.d, (int)nb, S.method, S.models, Ln.count, literal, c->d_err, Ln.blocks, st));
-        else if (Ln.kind == 2) HIPCHK(c, launch_predict(dP, Ln.d, (int)nb, Ln.levels, Ln.blocks, st));
+        if (Ln.kind == 2) HIPCHK(c, launch_predict(dP, Ln.d, (int)nb, Ln.levels, Ln.blocks, st));
         else if (Ln.kind == 0) HIPCHK(c, launch_classify(dP, Ln.d, (int)nb, Ln.blocks, Ln.count, Ln.fixup, st));
         else HIPCHK(c, launch_trace(dP, Ln.d, (int)nb, S.method, S.models, Ln.count, Ln.build < 0 ? dense : Ln.build != 0, literal, c->d_err, Ln.blocks, st));
         if (timing) for (int e : Ln.ev_after) HIPCHK(c, hipEventRecord(fev[e], st));
@@ -1740,7 +1582,6 @@ int dev_get_level_counters(bhray_dev* c, uint32_t level, bhray_counters* out) {
 int dev_add_row_work(bhray_dev* c, uint32_t level, uint64_t* acc, uint32_t n) {
     if (!c || !acc) return BHRAY_E_INVALID;
     if (!(c->cfg.flags & BHRAY_F_COUNTERS)) return fail(c, BHRAY_E_STATE, "ctx created without BHRAY_F_COUNTERS");
-    if (c->cfg.flags & BHRAY_F_FUSED) return fail(c, BHRAY_E_STATE, "bhray_get_row_work is not available with BHRAY_F_FUSED");
     if (level >= c->cfg.levels || n != c->cfg.level_h[level]) return fail(c, BHRAY_E_INVALID, "level out of range, or n is not the level's height");
     int rc = dev_sync(c);
     if (rc) return rc;
@@ -1826,7 +1667,6 @@ int dev_get_timing(bhray_dev* c, bhray_timing* out) {
             float a = 0, b = 0;
             HIPCHK(c, hipEventElapsedTime(&a, ev[3 * l], ev[3 * l + 1]));
             HIPCHK(c, hipEventElapsedTime(&b, ev[3 * l + 1], ev[3 * l + 2]));
-            if (c->fz.on && l > 0) { if (!first) first = ev[3 * l]; last = ev[3 * l + 2]; continue; }      // fused ladder: one launch, booked as level 0's
             const bool spec_classified = (c->cfg.speculative_levels && l >= 1 && l < c->cfg.speculative_levels) ||
                                          (c->cfg.superset_levels && l > nl - c->cfg.superset_levels);               // no trace launch of its own
             out->classify_ms += a; out->level_classify_ms[l] += a; out->classify_launches++;

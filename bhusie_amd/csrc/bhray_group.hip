@@ -1043,7 +1043,6 @@ int bhray_set_partition(bhray_ctx* c, const uint32_t* slab_row0) {
     if (!c || !slab_row0) return BHRAY_E_INVALID;
     ENTER(c);
     if (c->world > BHRAY_MAX_DEVICES) return gfail(c, BHRAY_E_INVALID, "more partitions than slab_row0 holds");
-    if (c->cfg.flags & BHRAY_F_FUSED) return gfail(c, BHRAY_E_STATE, "the partition of a BHRAY_F_FUSED ctx is fixed (its tile graph is built at bhray_create)");
     bhray_config n = c->cfg;
     n.partition = BHRAY_PARTITION_SLABS;
     for (uint32_t p = 0; p <= c->world; p++) n.slab_row0[p] = slab_row0[p];
@@ -1209,7 +1208,6 @@ int bhray_rebalance(bhray_ctx* c, bhray_rebalance_info* out) {
     ENTER(c);
     if (out) memset(out, 0, sizeof *out);
     if (c->world < 2 || c->single) return gfail(c, BHRAY_E_STATE, "bhray_rebalance needs a ctx that gathers (device_count >= 2, or gather = BHRAY_GATHER_RCCL); a host that moves the tiles itself balances with bhray_get_work + bhray_rebalance_slabs");
-    if (c->cfg.flags & BHRAY_F_FUSED) return gfail(c, BHRAY_E_STATE, "the partition of a BHRAY_F_FUSED ctx is fixed");
     const uint32_t N = c->world, H = c->cfg.frame_h;
     // a ctx created with interleaved stripes starts from equal slabs
     uint32_t cur[BHRAY_MAX_DEVICES + 1];

@@ -103,54 +103,6 @@ struct SpecLevels { int n; SpecLevel l[BHRAY_MAX_SPEC_LEVELS]; };   // n == 0: o
 
 struct Counters64 { unsigned long long v[13]; };   // order = bhray_counters
 
-// ------------------------------------------------------------------------------------------
-// Fused ladder (BHRAY_F_FUSED): ONE persistent launch runs every level of a batch's frames.  The grid classification
-// (ray.wgsl:167-243) is folded into the trace kernel as work items of 8x8-pixel tiles with explicit dependencies:
-//   - a tile of level l is FINAL when it has been classified and every ray queued from it has stored its pixel;
-//   - a tile of level l+1 may be classified when every level-l tile holding a texel it reads is final.
-// Nothing waits for a whole level: a level's tail (its few longest rays) overlaps the next level's head.  All hand-offs between
-// workgroups are 8-byte agent-scope atomics both sides (MI355X: per-XCD L2s are not coherent, L1s are never refreshed by other
-// CUs): queue entries are {stamp, payload} granules, pixels of non-final levels are stored and loaded as two 8-byte halves.
-// ------------------------------------------------------------------------------------------
-// Every control word sits on its own 128-byte line: they are hit by atomics and polled from every CU, and words that share a line
-// share one L2 channel's queue (the first version kept them in one line: a 1080p frame took 14 ms instead of 1).
-struct alignas(128) FusedWord { uint32_t v; uint32_t pad[31]; };
-struct FusedCtl {                  // per frame, reset before every launch (fused_reset_kernel)
-    FusedWord cq_tail, cq_head;    // work ring of tiles (classify / enqueue-all items): entries published / tickets handed out
-    FusedWord tiles_left;          // tiles that are not final yet (all levels); 0 <=> the frame is complete
-    FusedWord done;                // set by whoever finalises the last tile
-    // ray queue of each level: entries reserved by producers / slots handed out / (entries in total) + 1 once every tile of the level
-    // has been processed (0: open) / tiles not processed yet
-    struct { FusedWord reserve, head, final, unprocessed; } rq[BHRAY_MAX_SPEC_LEVELS];
-};
-struct FusedLevel {
-    LevelParams L;                 // geometry, prev / out, rows - what the classification of this level needs (L.spec: traced image of a speculative level >= 1)
-    const int32_t* row_index;      // level row y -> index j into L.rows (or -1)
-    uint32_t tile_base;            // first tile id of this level (tile ids are per frame: base + ty * tiles_x + tx)
-    uint32_t tiles_x, tiles_y;
-    int all_traced;                // 1: every pixel of the level is traced (level 0, speculative levels): its tiles start as enqueue-all items
-    const uint8_t* xdep; const uint8_t* ydep;          // l >= 1: number of coarse tile columns / rows a tile column / row reads
-    // dependents at level l+1 of a tile column / row of THIS level (CSR); nullptr at the last level
-    const uint32_t* nx_off; const uint16_t* nx_list; const uint32_t* ny_off; const uint16_t* ny_list;
-    unsigned long long* rq;        // ray queue: {stamp << 32 | tag<<30 | y<<15 | x} granules
-    uint32_t rq_cap;               // slots of rq (>= the level's pixels: a slot at or beyond it can never be filled)
-    float4* ray_out; int ray_pitch, ray_x0; const int32_t* ray_rowmap;     // where a ray of this level stores its pixel (the level image / the speculative image / the frame)
-    Counters64* counters;          // this level's counters (nullptr unless BHRAY_F_COUNTERS)
-};
-struct FusedFrame {
-    int nl, ns;                    // levels; levels 0..max(ns,1)-1 are all-traced
-    uint32_t stamp;                // this launch's tag of queue entries (never 0)
-    uint32_t n_initial;            // enqueue-all items: ring positions [0, n_initial) are implicit (position -> tile through init_end)
-    uint32_t n_items;              // items the ring will ever hold: n_initial + one classify item per tile of the levels >= 1
-    uint32_t total_tiles;
-    uint32_t init_end[BHRAY_MAX_SPEC_LEVELS];   // prefix sums of the all-traced levels' tile counts
-    FusedCtl* ctl;
-    uint32_t* deps;                // [total_tiles] unmet dependencies of a tile (coarse tiles; + its own speculative rays)
-    uint32_t* pending;             // [total_tiles] rays queued from the tile that have not stored their pixel yet
-    unsigned long long* cq;        // [total_tiles] work ring granules {stamp << 32 | tile id}
-    FusedLevel lv[BHRAY_MAX_SPEC_LEVELS];
-};
-
 // One frame's share of one launch.  A launch covers the `nb` frames of a batch: classify uses blockIdx.y as the frame
 // index, the persistent trace blocks start on frame blockIdx.x % nb and move on to the other frames when theirs runs dry.
 struct FrameLaunch {
@@ -168,7 +120,6 @@ struct FrameLaunch {
     uint32_t stamp_value;  // stamp of the current frame
     int probe_empty;       // trace, bit 0: this launch is expected to find its queue (nearly) used up - look before the first atomic; bit 1: thin shares are dealt strided (a whole frame, one frame per launch)
     int blocks;            // predict (one launch, all levels): this level's own block count
-    const FusedFrame* fz;  // fused ladder: this frame's tile graph and queues (nullptr otherwise)
     unsigned long long* span; // trace, entry 0 of a timed launch: [0] max(~first block start) [1] max(last block end), device wall clock; nullptr: untimed
     unsigned long long* work; // trace, entry 0 of a launch: work[blockIdx & (BHRAY_WORK_WORDS - 1)] += integrator steps this wave ISSUED for the frames of the batch
                               // (a step costs the wave the same whether 1 or 64 of its lanes march): what the batch's rays cost this GPU, whatever else shares
@@ -188,10 +139,6 @@ struct FrameLaunch {
 hipError_t launch_classify(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int blocks, bool count, bool fixup, hipStream_t s);
 hipError_t launch_trace(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int method, bool models, bool count, bool dense, int eval, int* err_flag,
                         int grid_blocks, hipStream_t s);
-// fused ladder: reset of the batch's tile state, then the one launch (no-mesh and mesh; the latency build's register budget)
-hipError_t launch_fused_reset(const FrameLaunch* Fb, int nb, int max_tiles, hipStream_t s);
-hipError_t launch_fused(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int method, bool models, bool count, int eval, int* err_flag, int grid_blocks, hipStream_t s);
-int fused_blocks_per_cu(int method, int has_models, int count, int eval);
 int trace_blocks_per_cu(int method, int has_models, int count, int dense, int eval);   // eval: 0 contract, 1 BHRAY_F_LITERAL, 2 BHRAY_F_EVAL_FMA
 // copies n16 16-byte words from pinned host memory to device memory with a kernel (stays on the compute queue: a DMA copy
 // between the launches of a stream costs a cross-engine handshake each time)

@@ -288,34 +288,11 @@ __device__ __forceinline__ bool hit_triangle(F3 pos, F3 dir, float t_min, float 
 #ifndef BHRAY_BVH_LDS_STACK
 #define BHRAY_BVH_LDS_STACK 8      // entries of the short traversal stack in LDS (16 KB per 256-thread block: 8 blocks per CU fit in 160 KB)
 #endif
-// Build flags of measured experiments (profiles/EXPERIMENTS.md R5.5, R5.8, R5.9): all off in the product; the mesh variant's build for a saturated device
-// (trace_kernel<.., MODELS = true, .., DENSE = true>) has BHRAY_MESH_PARK, BHRAY_FLAT_COLD and BHRAY_BVH_WHILE_WHILE switched on by its template parameters.
-#ifndef BHRAY_MESH_PARK
-#define BHRAY_MESH_PARK 0          // 1: also the mesh variant's LATENCY build runs its traversal in a region of its own, the marching state stored to scratch around it (see the flat phase)
-#endif
-#ifndef BHRAY_FLAT_COLD
-#define BHRAY_FLAT_COLD 0          // 1: also the latency build marks the flat phase unlikely
-#endif
-#ifndef BHRAY_EXPERIMENT_NO_TRAVERSAL
-#define BHRAY_EXPERIMENT_NO_TRAVERSAL 0      // 1 = an EXPERIMENT: the mesh variant without its traversal - what the traversal's mere presence costs the march (R5.5)
-#endif
+// (The build flags of rounds 3-5's measured experiments - BHRAY_EXPERIMENT_*, BHRAY_BVH_PREFETCH, BHRAY_MESH_PARK / BHRAY_FLAT_COLD / BHRAY_BVH_WHILE_WHILE for the
+// latency build - are gone from the source; what each measured is in profiles/EXPERIMENTS.md R5.5, R5.6, R5.8, R5.9.  The mesh variant's build for a saturated
+// device, trace_kernel<.., MODELS = true, .., DENSE = true>, is the one that parks its marching state, marks the flat phase unlikely and traverses while-while.)
 #ifndef BHRAY_THIN_STRIDED_BELOW
 #define BHRAY_THIN_STRIDED_BELOW 32   // thin dealing of a whole frame: a wave's share is taken STRIDED (every waves-th entry) when it is below this many rays (see trace_kernel)
-#endif
-#ifndef BHRAY_EXPERIMENT_FLAT_CLOCK
-#define BHRAY_EXPERIMENT_FLAT_CLOCK 0          // 1 = an EXPERIMENT (counting builds, latency mesh build): bhray_counters.max_ray_iterations holds the longest time one WAVE spent in flat phases (100 MHz ticks), rays_adopted the number of flat phases
-#endif
-#ifndef BHRAY_EXPERIMENT_LONGEST_TRAVERSAL
-#define BHRAY_EXPERIMENT_LONGEST_TRAVERSAL 0   // 1 = an EXPERIMENT (counting builds): bhray_counters.longest_ray holds the longest TRAVERSAL instead - loop iterations (inner nodes + leaves + re-descents) of one call
-#endif
-#ifndef BHRAY_EXPERIMENT_NO_RANGE_GUARDS
-#define BHRAY_EXPERIMENT_NO_RANGE_GUARDS 0   // 1 = an EXPERIMENT, never a product build: the short 1/x and sqrt sequences without their range guards (wrong bits for zero / denormal / huge operands) - an upper bound on what the guards' branches cost
-#endif
-#ifndef BHRAY_BVH_WHILE_WHILE
-#define BHRAY_BVH_WHILE_WHILE 0    // 1: inner nodes and leaves in loops of their own (see trace_ray_model)
-#endif
-#ifndef BHRAY_BVH_PREFETCH
-#define BHRAY_BVH_PREFETCH 0       // 1 (with BHRAY_BVH_WHILE_WHILE): request a dword of both children's data as soon as a pair has arrived (see trace_ray_model)
 #endif
 #ifndef BHRAY_MODEL_INLINE
 #define BHRAY_MODEL_INLINE __forceinline__   // the traversal inline, in a kernel budgeted for 5 waves per SIMD (96 VGPRs): the step loop stays free of spills and what is
@@ -335,7 +312,7 @@ struct BvhLds { int2* stack; };     // stack: this lane's column (entry k at sta
 // that moment, as the reference decides it) and is recorded in `pend` - so the nodes are visited in the same order, with the same
 // pruning, and equal-t ties between triangles resolve as in the reference.  Node pairs re-read on the way down are not counted.
 // A tree deeper than 64 levels raises BHRAY_E_BVH_DEPTH (D2).
-template <bool COUNT, bool WW = (BHRAY_BVH_WHILE_WHILE != 0)>
+template <bool COUNT, bool WW>
 __device__ BHRAY_MODEL_INLINE void trace_ray_model(const ModelDev& M, const BvhLds lds, F3 pos, F3 dir, float t_min, float t_max,
                                              Hit& closest, F3& normal_out, unsigned long long* cnt, int* err) {
     static_assert(BHRAY_BVH_LDS_STACK >= 2 && BHRAY_BVH_STACK <= 64, "short stack / trail sizes");
@@ -356,9 +333,6 @@ __device__ BHRAY_MODEL_INLINE void trace_ray_model(const ModelDev& M, const BvhL
     // (two box tests, ~80) take turns within every iteration; rays of one tile reach their leaves at different iterations, so most
     // iterations paid for both.  Every lane still visits its own nodes in its own order: same hits, same counters, same equal-t ties.
     bool alive = true;
-#if BHRAY_BVH_PREFETCH
-    int pf0 = 0, pf1 = 0;
-#endif
     // the pop of the one-loop form: the next node for this lane, or the end of its traversal
     auto do_pop = [&]() {
         if (pend == 0ull) { alive = false; return; }
@@ -382,19 +356,6 @@ __device__ BHRAY_MODEL_INLINE void trace_ray_model(const ModelDev& M, const BvhL
             float d2 = hit_aabb(pos, inv, b_lo, b_hi, mpos);
             int2 n1 = make_int2(__float_as_int(a_lo.w), __float_as_int(a_hi.w));
             int2 n2 = make_int2(__float_as_int(b_lo.w), __float_as_int(b_hi.w));
-#if BHRAY_BVH_PREFETCH
-            // The traversal is a chain of dependent 64-byte loads: the next pair's address is known as soon as this pair has arrived, before the
-            // two box tests and the bookkeeping (~100 instructions) that decide WHICH child is next.  One dword of each child's own pair (or
-            // leaf) is requested now into two registers nobody reads: by the time the decision is made its line is in the CU's L1, and the real
-            // load of the next iteration hits there instead of in L2 / HBM.  (The registers stay reserved for the whole loop - "+v" on every
-            // iteration - so a late write-back lands nowhere else; the compiler's vmcnt accounting only ever over-waits for loads it does not know.)
-            {
-                const float4* c1 = n1.y == 0 ? M.nodes + 2 * (size_t)n1.x : M.leaf + 6 * (size_t)n1.x;
-                const float4* c2 = n2.y == 0 ? M.nodes + 2 * (size_t)n2.x : M.leaf + 6 * (size_t)n2.x;
-                asm volatile("global_load_dword %0, %1, off" : "+v"(pf0) : "v"(c1) : "memory");
-                asm volatile("global_load_dword %0, %1, off" : "+v"(pf1) : "v"(c2) : "memory");
-            }
-#endif
             if (d1 > d2) { float td = d1; d1 = d2; d2 = td; int2 tn = n1; n1 = n2; n2 = tn; }
             const unsigned long long bit = 1ull << lev;
             if (target >= 0) {                                      // re-descent: follow the recorded path, decide nothing
@@ -438,10 +399,8 @@ __device__ BHRAY_MODEL_INLINE void trace_ray_model(const ModelDev& M, const BvhL
         }
     }
     } else {
-    unsigned long long visits = 0ull;
     for (;;) {
         bool pop = false;
-        if (COUNT && BHRAY_EXPERIMENT_LONGEST_TRAVERSAL != 0) { visits++; if (visits > cnt[12]) cnt[12] = visits; }
         if (obj_count == 0) {
             if (lev >= BHRAY_BVH_STACK) { *err = BHRAY_E_BVH_DEPTH; break; }
             const float4* pair = M.nodes + 2 * (size_t)contents;
@@ -536,25 +495,19 @@ __device__ __forceinline__ bool sqrt_in_range(float x) { return x >= 0x1p-95f &&
 // alone on its SIMD pays for every branch (profiles/ubench/lone_wave.hip).
 __device__ __forceinline__ float rcp_rn(float x) {                 // == 1.0f / x
     float r = rcp_newton(x);
-#if !BHRAY_EXPERIMENT_NO_RANGE_GUARDS
     if (__builtin_expect(__ballot(!rcp_in_range(x)) != 0ull, 0)) r = 1.0f / x;
-#endif
     return r;
 }
 __device__ __forceinline__ float sqrt_rn(float x) {                // == sqrtf(x)
     float r = sqrt_corrected(x);
-#if !BHRAY_EXPERIMENT_NO_RANGE_GUARDS
     if (__builtin_expect(__ballot(!sqrt_in_range(x)) != 0ull, 0)) r = sqrtf(x);
-#endif
     return r;
 }
 // == fnormalize(a) (bhray_math.h): a * (1 / sqrt(fdot(a, a))); one guard covers both (sqrt of an in-range x is in rcp's range)
 __device__ __forceinline__ F3 fnormalize_rn(F3 a) {
     const float d = fdot(a, a);
     float r = rcp_newton(sqrt_corrected(d));
-#if !BHRAY_EXPERIMENT_NO_RANGE_GUARDS
     if (__builtin_expect(__ballot(!sqrt_in_range(d)) != 0ull, 0)) r = 1.0f / sqrtf(d);
-#endif
     return a * r;
 }
 // == bh_pow_m001(x) (bhray_math.h) for every x > 0.00002f, the only values next_ray_rk passes (all of them, +inf included, checked
@@ -915,8 +868,7 @@ __global__ __launch_bounds__(BHRAY_CLASSIFY_THREADS) void classify_kernel(const 
 // ------------------------------------------------------------------------------------------
 // trace: ray.wgsl:269-285 + 482-596
 // ------------------------------------------------------------------------------------------
-enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, M_SHADE_FLAT = 5,
-             M_WAIT = -1 };   // fused ladder: the lane holds a slot of a ray queue whose entry has not been published yet (cold pix = slot, it = level)   // M_SHADE_x: a disk hit waits for its shading, then continues in mode x
+enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, M_SHADE_FLAT = 5 };   // M_SHADE_x: a disk hit waits for its shading, then continues in mode x
 #ifndef BHRAY_THIN_WAVES
 #define BHRAY_THIN_WAVES 1024    // latency build: a short queue is dealt out evenly over this many waves (MI355X: 256 CUs x 4 SIMDs); 0 = off
 #endif
@@ -956,32 +908,8 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #ifndef BHRAY_MESH_COLD_LDS
 #define BHRAY_MESH_COLD_LDS 0    // mesh variant: the cold per-lane state in LDS as in the dense build
 #endif
-#ifndef BHRAY_WITH_PAIR
-#define BHRAY_WITH_PAIR 0        // 1 (make pair -> libbhray_pair.so): the dense RK kernel without meshes marches TWO rays per lane on packed FP32 (bhray_pair.inc)
-#endif
-#ifndef BHRAY_PAIR_RK
-#define BHRAY_PAIR_RK 1          // pair build: the dense RK kernel marches two rays per lane ...
-#endif
-#ifndef BHRAY_PAIR_RK_V
-#define BHRAY_PAIR_RK_V v2       // ... on packed FP32 (v2) or as two interleaved scalar streams (s2)
-#endif
-#ifndef BHRAY_PAIR_EULER
-#define BHRAY_PAIR_EULER 1       // pair build: the dense Euler kernel too ...
-#endif
-#ifndef BHRAY_PAIR_EULER_V
-#define BHRAY_PAIR_EULER_V s2    // ... as two interleaved scalar streams (the Euler step is almost all one dependent chain per ray)
-#endif
-#ifndef BHRAY_WITH_FUSED
-#define BHRAY_WITH_FUSED 0       // 1 (make fused -> libbhray_fused.so): the fused ladder, BHRAY_F_FUSED - measured slower than the launch-per-level ladder, a tested option
-#endif
 #ifndef BHRAY_HIT_LDS
 #define BHRAY_HIT_LDS 1         // dense build: "a hit happened" in the cold LDS state rather than an SGPR pair merged at every join of the step loop (+0.3 %, A/B in two sessions: profiles/EXPERIMENTS.md R3.9)
-#endif
-
-#if BHRAY_WITH_FUSED
-#define BHRAY_FUSED_PART 0
-#include "bhray_fused.inc"
-#undef BHRAY_FUSED_PART
 #endif
 
 // Cold per-lane ray state: values the integrator step loop reads or writes only on its rare paths (sphere exit, an actual hit)
@@ -1020,7 +948,7 @@ template <> struct ColdState<true> {
     __device__ __forceinline__ void set_hit(bool v) { b[8 * S] = v ? 1.0f : 0.0f; }
 };
 
-template <int METHOD, bool MODELS, bool COUNT, bool DENSE, int EVAL = 0, bool FUSED = false>
+template <int METHOD, bool MODELS, bool COUNT, bool DENSE, int EVAL = 0>
 __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_WAVES_MESH_DENSE : BHRAY_TRACE_WAVES_MESH) : (DENSE ? BHRAY_TRACE_WAVES_DENSE : BHRAY_TRACE_WAVES)) void trace_kernel(const FrameParams* __restrict__ Pb, const FrameLaunch* __restrict__ Fb, const int nb, int* __restrict__ err_flag) {
     const int lane = threadIdx.x & 63;
     int err = 0;
@@ -1033,9 +961,9 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
 #endif
     constexpr bool COLD_LDS = (DENSE && !MODELS) || (MODELS && BHRAY_MESH_COLD_LDS != 0);
     constexpr bool MESH_DENSE = MODELS && DENSE;                                              // the mesh variant's build for a saturated device
-    constexpr bool MESH_PARK = MODELS && !COLD_LDS && (MESH_DENSE || BHRAY_MESH_PARK != 0);   // its traversal in a region of its own (see the flat phase)
-    constexpr bool FLAT_COLD = MESH_DENSE || BHRAY_FLAT_COLD != 0;
-    constexpr bool BVH_WW = MESH_DENSE || BHRAY_BVH_WHILE_WHILE != 0;
+    constexpr bool MESH_PARK = MESH_DENSE && !COLD_LDS;   // its traversal in a region of its own (see the flat phase)
+    constexpr bool FLAT_COLD = MESH_DENSE;                // ... the flat phase marked unlikely
+    constexpr bool BVH_WW = MESH_DENSE;                   // ... and the while-while traversal
     __shared__ float cold_lds[COLD_LDS ? (8 + BHRAY_HIT_LDS) * BHRAY_TRACE_THREADS : 1];
     // Integrator steps this wave issues for the frames of the batch -> Fb[0].work at the kernel's end.  Wave-uniform: a scalar register.
     // Counted in whole batches of steps, where the step loop is entered (a batch cut short by its last ray counts in full), and for the
@@ -1047,21 +975,9 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
     // LDS-limited and gives up the 64-VGPR budget of 8 waves per SIMD: 142-152 VGPRs, 3 waves)
     extern __shared__ float4 bvh_dyn_lds[];
     BvhLds bvh_lds; bvh_lds.stack = reinterpret_cast<int2*>(bvh_dyn_lds) + threadIdx.x;
-    constexpr bool FZ = BHRAY_WITH_FUSED && FUSED;      // the fused ladder is a build option (make fused): bhray_fused.inc
-#if BHRAY_WITH_FUSED
-#define BHRAY_FUSED_PART 1
-#include "bhray_fused.inc"
-#undef BHRAY_FUSED_PART
-#endif
     // the frames of the batch, starting with this block's own: a block whose frame has run dry helps with the others
-    for (int fi = 0; FZ || fi < nb; fi++) {
+    for (int fi = 0; fi < nb; fi++) {
     const int fb = (int)((blockIdx.x + (unsigned)fi) % (unsigned)nb);
-#if BHRAY_WITH_FUSED
-    if (FZ) {
-        if (fused_done_mask == (nb >= 32 ? 0xffffffffu : ((1u << nb) - 1u))) break;
-        if (fused_done_mask & (1u << fb)) continue;
-    }
-#endif
     const FrameParams& P = Pb[fb];
     const FrameLaunch& F = Fb[fb];
     const LevelParams& L = F.L;
@@ -1100,7 +1016,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
             if (share < 64u) thin_share = share > 0u ? share : 1u;
             if ((F.probe_empty & 2) && share < (uint32_t)BHRAY_THIN_STRIDED_BELOW) thin_stride = waves;
         }
-    } else if (!DENSE && !FZ && BHRAY_THIN_WAVES > 0 && (nb == 1 || gridDim.x >= 4u * (uint32_t)nb)) {   // (the fused ladder has its own queues and its own frame loop; every frame of a batch needs blocks of its own)
+    } else if (!DENSE && BHRAY_THIN_WAVES > 0 && (nb == 1 || gridDim.x >= 4u * (uint32_t)nb)) {   // (every frame of a batch needs blocks of its own)
         uint32_t own_blocks = gridDim.x;
         if (nb > 1) { own_blocks = (gridDim.x - (uint32_t)fb + (uint32_t)nb - 1u) / (uint32_t)nb; thin_block = blockIdx.x / (uint32_t)nb; }
         const uint32_t total = own_blocks * (BHRAY_TRACE_THREADS / 64);
@@ -1136,23 +1052,12 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
 #define HIT_SET(v) do { if (HIT_IN_LDS) cold.set_hit(v); else hit = (v); } while (0)
 #define HIT_GET() (HIT_IN_LDS ? cold.hit() : (bool)hit)
     bool exhausted = false;
-#if BHRAY_WITH_FUSED
-    int fused_wait_round = 0, fused_lo = 0, fused_skip = 0, fused_backoff = 0;     // fused tracer: rounds waited on slots; first level still worth a look; rounds until the next look at the queues
-    uint32_t fused_tile = 0; int fused_lv = 0; bool fused_fin = false;      // fused: the tile the ray that has just finished belongs to
-#endif
     int flat_round = 0;
     unsigned long long cnt[13];           // [0..9] = bhray_counters' frame counters, [10] wave steps (lane 0), [11] unused (rays adopted by the drain merging of round 2), [12] longest ray
     if (COUNT) { for (int k = 0; k < 13; k++) cnt[k] = 0; }
 
     for (;;) {
         // ---- refill finished lanes from the queue (wave ballot + prefix popcount)
-#if BHRAY_WITH_FUSED
-        if (FZ) {
-#define BHRAY_FUSED_PART 2
-#include "bhray_fused.inc"
-#undef BHRAY_FUSED_PART
-        } else
-#endif
         {
             const unsigned long long need = __ballot(mode == M_EMPTY);
             if (need != 0ull && !exhausted && (BHRAY_REFILL_MIN <= 1 || __popcll(need) >= BHRAY_REFILL_MIN || !__any(mode == M_REL))) {
@@ -1286,10 +1191,6 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
         }
         // (FLAT_COLD: the flat phase marked unlikely, so that the register allocator weighs the step loop above the traversal's loops)
         const bool flat_now = run_flat && __any(mode == M_FLAT);
-#if BHRAY_EXPERIMENT_FLAT_CLOCK
-        unsigned long long flat_t0 = 0ull;
-        if (COUNT && flat_now) flat_t0 = wall_clock64();
-#endif
         if (FLAT_COLD ? __builtin_expect(flat_now, 0) : flat_now) {
             if (mode == M_FLAT) {
                 if (it >= H.max_iter) {
@@ -1323,9 +1224,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
                                         if (COUNT && skip) cnt[6]++;
                                     }
                                 }
-#if !BHRAY_EXPERIMENT_NO_TRAVERSAL      
                                 if (!skip) trace_ray_model<COUNT, BVH_WW>(P.models[mi], bvh_lds, cpos, cdir, t_min, t_max, r, nrm, cnt, &err);
-#endif
                                 if (r.hit && r.t < rs.t) {
                                     rs = r;
                                     const F3 light = normalize(f3(0.2f, 0.2f, -1.0f));
@@ -1359,9 +1258,6 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
                 }
             }
         }
-#if BHRAY_EXPERIMENT_FLAT_CLOCK
-        if (COUNT && flat_now) { cnt[12] += wall_clock64() - flat_t0; if (lane == 0) cnt[11]++; }     // per wave: time in flat phases (100 MHz ticks; the maximum over waves is reported), number of flat phases (summed)
-#endif
 
         // ---- epilogue (ray.wgsl:583-595) for lanes whose loop ended
         if (__any(mode == M_FINISH)) {
@@ -1369,7 +1265,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
                 float4 o;
                 F3 color = cold.color();
                 const uint32_t pix = cold.pix();
-                if (COUNT && BHRAY_EXPERIMENT_LONGEST_TRAVERSAL == 0 && BHRAY_EXPERIMENT_FLAT_CLOCK == 0 && (unsigned long long)it > cnt[12]) cnt[12] = (unsigned long long)it;
+                if (COUNT && (unsigned long long)it > cnt[12]) cnt[12] = (unsigned long long)it;
                 if (HIT_GET() || it <= 5) {
                     if (amount > 0.001f) {
                         if (COUNT) cnt[9]++;
@@ -1388,13 +1284,6 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
                 } else {
                     o = make_float4(cdir.x, cdir.y, cdir.z, 0.0f);
                 }
-#if BHRAY_WITH_FUSED
-                if (FZ) {
-#define BHRAY_FUSED_PART 3
-#include "bhray_fused.inc"
-#undef BHRAY_FUSED_PART
-                } else
-#endif
                 {
                     const int ox = (int)(pix & 0x7fffu), oy = (int)((pix >> 15) & 0x7fffu);
                     if (SL.n > 0) {
@@ -1423,13 +1312,6 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
                 }
                 mode = M_EMPTY;
             }
-#if BHRAY_WITH_FUSED
-            if (FZ) {
-#define BHRAY_FUSED_PART 4
-#include "bhray_fused.inc"
-#undef BHRAY_FUSED_PART
-            }
-#endif
         }
 
         // ---- a batch of integrator steps (ray.wgsl:522-553) for lanes inside the sphere
@@ -1462,14 +1344,12 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
         }
     }
     }   // frames of the batch
-    if (!FZ && work_steps != 0u && Fb[0].work && lanes_below(~0ull) == 0u) atomicAdd(&Fb[0].work[blockIdx.x & (BHRAY_WORK_WORDS - 1)], (unsigned long long)work_steps);
+    if (work_steps != 0u && Fb[0].work && lanes_below(~0ull) == 0u) atomicAdd(&Fb[0].work[blockIdx.x & (BHRAY_WORK_WORDS - 1)], (unsigned long long)work_steps);
 #ifndef BHRAY_NO_SPAN
     if (Fb[0].span && threadIdx.x == 0) atomicMax(&Fb[0].span[1], (unsigned long long)wall_clock64());
 #endif
     if (err) *err_flag = err;
 }
-
-#include "bhray_pair.inc"
 
 // ------------------------------------------------------------------------------------------
 // sky resolve: sky.wgsl:1-38 (the pass after the ray levels, mod.rs:419)
@@ -1622,88 +1502,53 @@ hipError_t launch_classify(const FrameParams* Pb, const FrameLaunch* Fb, int nb,
     return hipGetLastError();
 }
 
-template <int METHOD, bool MODELS, bool DENSE, int EVAL = 0>
-static hipError_t launch_trace_t(const FrameParams* Pb, const FrameLaunch* Fb, int nb, bool count, int* err_flag, int grid_blocks, hipStream_t s) {
-    (void)hipGetLastError();
-    constexpr size_t dyn_lds = MODELS ? (size_t)BHRAY_BVH_LDS_STACK * BHRAY_TRACE_THREADS * 8 : 0;   // trace_ray_model's LDS
-    if (count) hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, true, DENSE, EVAL>), dim3((grid_blocks * 256 + BHRAY_TRACE_THREADS - 1) / BHRAY_TRACE_THREADS), dim3(BHRAY_TRACE_THREADS), dyn_lds, s, Pb, Fb, nb, err_flag);
-    else hipLaunchKernelGGL((trace_kernel<METHOD, MODELS, false, DENSE, EVAL>), dim3((grid_blocks * 256 + BHRAY_TRACE_THREADS - 1) / BHRAY_TRACE_THREADS), dim3(BHRAY_TRACE_THREADS), dyn_lds, s, Pb, Fb, nb, err_flag);
-    return hipGetLastError();
+// Which builds of trace_kernel<METHOD, MODELS, COUNT, DENSE, EVAL> exist (x 2 integrators = 32 instantiations; 48 in round 5, 72 in round 3).
+// eval: 0 the numerics contract, 1 BHRAY_F_LITERAL, 2 BHRAY_F_EVAL_FMA.  Every variant has a build for lone launches (the latency build);
+// the build for a saturated device (dense) exists where throughput is reported: not for counting kernels (BHRAY_F_COUNTERS is a diagnosis
+// mode: the same counts whichever build marches) and, of the two measurement-only evaluations, not for the mesh variant.  A launch that
+// asks for a build that does not exist gets the latency build of the same variant: the same pixels, bit for bit (every build is).
+constexpr bool trace_variant_exists(int eval, bool models, bool dense, bool count) {
+    return !(count && dense) && !(eval != 0 && models && dense);
 }
-
-// eval: 0 the numerics contract, 1 BHRAY_F_LITERAL, 2 BHRAY_F_EVAL_FMA.  Every variant has a build for a saturated device (dense) and one for lone launches.
-template <int EVAL>
-static hipError_t launch_trace_e(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int method, bool models, bool count, bool dense, int* err_flag,
-                                 int grid_blocks, hipStream_t s) {
+template <int METHOD, bool MODELS, bool COUNT, bool DENSE, int EVAL>
+static const void* trace_kernel_ptr_t() {
+    if constexpr (trace_variant_exists(EVAL, MODELS, DENSE, COUNT)) return (const void*)trace_kernel<METHOD, MODELS, COUNT, DENSE, EVAL>;
+    else return trace_kernel_ptr_t<METHOD, MODELS, COUNT, false, EVAL>();
+}
+template <int METHOD, int EVAL>
+static const void* trace_kernel_ptr_me(bool models, bool count, bool dense) {
     if (models) {
-        if (method == 0) return dense ? launch_trace_t<0, true, true, EVAL>(Pb, Fb, nb, count, err_flag, grid_blocks, s)
-                                      : launch_trace_t<0, true, false, EVAL>(Pb, Fb, nb, count, err_flag, grid_blocks, s);
-        return dense ? launch_trace_t<1, true, true, EVAL>(Pb, Fb, nb, count, err_flag, grid_blocks, s)
-                     : launch_trace_t<1, true, false, EVAL>(Pb, Fb, nb, count, err_flag, grid_blocks, s);
+        if (dense) return count ? trace_kernel_ptr_t<METHOD, true, true, true, EVAL>() : trace_kernel_ptr_t<METHOD, true, false, true, EVAL>();
+        return count ? trace_kernel_ptr_t<METHOD, true, true, false, EVAL>() : trace_kernel_ptr_t<METHOD, true, false, false, EVAL>();
     }
-    if (method == 0) {
-        return dense ? launch_trace_t<0, false, true, EVAL>(Pb, Fb, nb, count, err_flag, grid_blocks, s)
-                     : launch_trace_t<0, false, false, EVAL>(Pb, Fb, nb, count, err_flag, grid_blocks, s);
-    }
-    return dense ? launch_trace_t<1, false, true, EVAL>(Pb, Fb, nb, count, err_flag, grid_blocks, s)
-                 : launch_trace_t<1, false, false, EVAL>(Pb, Fb, nb, count, err_flag, grid_blocks, s);
+    if (dense) return count ? trace_kernel_ptr_t<METHOD, false, true, true, EVAL>() : trace_kernel_ptr_t<METHOD, false, false, true, EVAL>();
+    return count ? trace_kernel_ptr_t<METHOD, false, true, false, EVAL>() : trace_kernel_ptr_t<METHOD, false, false, false, EVAL>();
 }
+static const void* trace_kernel_ptr(int method, bool models, bool count, bool dense, int eval) {
+    if (method == 0) {
+        if (eval == 1) return trace_kernel_ptr_me<0, 1>(models, count, dense);
+        if (eval == 2) return trace_kernel_ptr_me<0, 2>(models, count, dense);
+        return trace_kernel_ptr_me<0, 0>(models, count, dense);
+    }
+    if (eval == 1) return trace_kernel_ptr_me<1, 1>(models, count, dense);
+    if (eval == 2) return trace_kernel_ptr_me<1, 2>(models, count, dense);
+    return trace_kernel_ptr_me<1, 0>(models, count, dense);
+}
+static size_t trace_dyn_lds(bool models) { return models ? (size_t)BHRAY_BVH_LDS_STACK * BHRAY_TRACE_THREADS * 8 : 0; }   // trace_ray_model's traversal ring
+
 hipError_t launch_trace(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int method, bool models, bool count, bool dense, int eval, int* err_flag,
                         int grid_blocks, hipStream_t s) {
     if (nb <= 0) return hipSuccess;
-#if BHRAY_WITH_PAIR
-    if (eval == 0 && !models && dense && (method == 1 ? BHRAY_PAIR_RK != 0 : BHRAY_PAIR_EULER != 0)) {
-        (void)hipGetLastError();
-        const dim3 grid((grid_blocks * 256 + BHRAY_TRACE_THREADS - 1) / BHRAY_TRACE_THREADS);
-        if (method == 1) {
-            if (count) hipLaunchKernelGGL((trace_pair_kernel<true, 1, BHRAY_PAIR_RK_V>), grid, dim3(BHRAY_TRACE_THREADS), pair_dyn_lds_bytes, s, Pb, Fb, nb, err_flag);
-            else hipLaunchKernelGGL((trace_pair_kernel<false, 1, BHRAY_PAIR_RK_V>), grid, dim3(BHRAY_TRACE_THREADS), pair_dyn_lds_bytes, s, Pb, Fb, nb, err_flag);
-        } else {
-            if (count) hipLaunchKernelGGL((trace_pair_kernel<true, 0, BHRAY_PAIR_EULER_V>), grid, dim3(BHRAY_TRACE_THREADS), pair_dyn_lds_bytes, s, Pb, Fb, nb, err_flag);
-            else hipLaunchKernelGGL((trace_pair_kernel<false, 0, BHRAY_PAIR_EULER_V>), grid, dim3(BHRAY_TRACE_THREADS), pair_dyn_lds_bytes, s, Pb, Fb, nb, err_flag);
-        }
-        return hipGetLastError();
-    }
-#endif
-    if (eval == 1) return launch_trace_e<1>(Pb, Fb, nb, method, models, count, dense, err_flag, grid_blocks, s);
-    if (eval == 2) return launch_trace_e<2>(Pb, Fb, nb, method, models, count, dense, err_flag, grid_blocks, s);
-    return launch_trace_e<0>(Pb, Fb, nb, method, models, count, dense, err_flag, grid_blocks, s);
+    (void)hipGetLastError();
+    void* args[] = {(void*)&Pb, (void*)&Fb, (void*)&nb, (void*)&err_flag};
+    return hipLaunchKernel(trace_kernel_ptr(method, models, count, dense, eval), dim3((grid_blocks * 256 + BHRAY_TRACE_THREADS - 1) / BHRAY_TRACE_THREADS),
+                           dim3(BHRAY_TRACE_THREADS), args, trace_dyn_lds(models), s);
 }
 
-#if BHRAY_WITH_FUSED
-#define BHRAY_FUSED_PART 5
-#include "bhray_fused.inc"
-#undef BHRAY_FUSED_PART
-#else
-hipError_t launch_fused_reset(const FrameLaunch*, int, int, hipStream_t) { return hipErrorNotSupported; }
-hipError_t launch_fused(const FrameParams*, const FrameLaunch*, int, int, bool, bool, int, int*, int, hipStream_t) { return hipErrorNotSupported; }
-int fused_blocks_per_cu(int, int, int, int) { return 0; }      // 0: this build has no fused ladder (bhray_create refuses BHRAY_F_FUSED)
-#endif
-
-template <int EVAL>
-static const void* trace_kernel_ptr(int method, int has_models, int count, int dense) {
-#define PICK(M, MD, C, D) (const void*)trace_kernel<M, MD, C, D, EVAL>
-    if (has_models && dense) return method == 0 ? (count ? PICK(0, true, true, true) : PICK(0, true, false, true)) : (count ? PICK(1, true, true, true) : PICK(1, true, false, true));
-    if (has_models) return method == 0 ? (count ? PICK(0, true, true, false) : PICK(0, true, false, false)) : (count ? PICK(1, true, true, false) : PICK(1, true, false, false));
-    if (dense) return method == 0 ? (count ? PICK(0, false, true, true) : PICK(0, false, false, true)) : (count ? PICK(1, false, true, true) : PICK(1, false, false, true));
-    return method == 0 ? (count ? PICK(0, false, true, false) : PICK(0, false, false, false)) : (count ? PICK(1, false, true, false) : PICK(1, false, false, false));
-#undef PICK
-}
 int trace_blocks_per_cu(int method, int has_models, int count, int dense, int eval) {
     int n = 0;
-#if BHRAY_WITH_PAIR
-    if (eval == 0 && !has_models && dense && (method == 1 ? BHRAY_PAIR_RK != 0 : BHRAY_PAIR_EULER != 0)) {
-        const void* fp = method == 1 ? (count ? (const void*)trace_pair_kernel<true, 1, BHRAY_PAIR_RK_V> : (const void*)trace_pair_kernel<false, 1, BHRAY_PAIR_RK_V>)
-                                     : (count ? (const void*)trace_pair_kernel<true, 0, BHRAY_PAIR_EULER_V> : (const void*)trace_pair_kernel<false, 0, BHRAY_PAIR_EULER_V>);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fp, BHRAY_TRACE_THREADS, pair_dyn_lds_bytes) != hipSuccess || n < 1) n = 2;
-        n = n * BHRAY_TRACE_THREADS / 256;
-        return n < 1 ? 1 : n;
-    }
-#endif
-    const void* f = eval == 1 ? trace_kernel_ptr<1>(method, has_models, count, dense)
-                  : eval == 2 ? trace_kernel_ptr<2>(method, has_models, count, dense) : trace_kernel_ptr<0>(method, has_models, count, dense);
-    const size_t dyn_lds = has_models ? (size_t)BHRAY_BVH_LDS_STACK * BHRAY_TRACE_THREADS * 8 : 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, BHRAY_TRACE_THREADS, dyn_lds) != hipSuccess || n < 1) n = 2;
+    const void* f = trace_kernel_ptr(method, has_models != 0, count != 0, dense != 0, eval);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, BHRAY_TRACE_THREADS, trace_dyn_lds(has_models != 0)) != hipSuccess || n < 1) n = 2;
     n = n * BHRAY_TRACE_THREADS / 256;            // in units of 256 threads (the grid is sized in those)
     return n < 1 ? 1 : n;
 }

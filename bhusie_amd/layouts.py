@@ -16,7 +16,6 @@ F_LITERAL = 4
 F_TEMPORAL = 8
 F_TIMING_SPARSE = 16
 F_EVAL_FMA = 32
-F_FUSED = 64
 F_GATHER_SKY = 128
 TEX_TEMP_LUT, TEX_DISK, TEX_SKY = 0, 1, 2
 

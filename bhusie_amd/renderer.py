@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 
 from ._lib import lib
-from .layouts import (PARTITION_SLABS, F_COUNTERS, F_EVAL_FMA, F_FUSED, F_GATHER_SKY, F_LITERAL, F_TEMPORAL, F_TIMING, F_TIMING_SPARSE, GATHER_RCCL, TEX_DISK, TEX_SKY, TEX_TEMP_LUT, BhrayConfig, BhrayCounters,
+from .layouts import (PARTITION_SLABS, F_COUNTERS, F_EVAL_FMA, F_GATHER_SKY, F_LITERAL, F_TEMPORAL, F_TIMING, F_TIMING_SPARSE, GATHER_RCCL, TEX_DISK, TEX_SKY, TEX_TEMP_LUT, BhrayConfig, BhrayCounters,
                       BhrayGatherInfo, BhrayRebalanceInfo, BhrayTiming, check)
 from .model import Model
 from .scene import BlackHole, Camera, RayDetails
@@ -104,7 +104,7 @@ class RayPass:
 
     def __init__(self, cfg: BhrayConfig, device=0, counters=False, timing=False, row_rank=0, row_world=1, stripe_rows=27,
                  frames_in_flight=0, speculative_levels=0, frames_per_batch=0, devices=None, gather_root=0, comm_id=None,
-                 literal=False, superset_levels=0, temporal=False, eval_fma=False, fused=False, slab_row0=None, gather_sky=False):
+                 literal=False, superset_levels=0, temporal=False, eval_fma=False, slab_row0=None, gather_sky=False):
         cfg = BhrayConfig.from_buffer_copy(bytes(cfg))
         cfg.struct_size = C.sizeof(BhrayConfig)
         cfg.device = device
@@ -117,7 +117,7 @@ class RayPass:
             assert len(comm_id) == 128
             cfg.gather = GATHER_RCCL
             C.memmove(cfg.comm_id, bytes(comm_id), 128)
-        cfg.flags = (F_COUNTERS if counters else 0) | (F_TIMING_SPARSE if timing == "sparse" else (F_TIMING if timing else 0)) | (F_LITERAL if literal else 0) | (F_TEMPORAL if temporal else 0) | (F_EVAL_FMA if eval_fma else 0) | (F_FUSED if fused else 0) | (F_GATHER_SKY if gather_sky else 0)
+        cfg.flags = (F_COUNTERS if counters else 0) | (F_TIMING_SPARSE if timing == "sparse" else (F_TIMING if timing else 0)) | (F_LITERAL if literal else 0) | (F_TEMPORAL if temporal else 0) | (F_EVAL_FMA if eval_fma else 0) | (F_GATHER_SKY if gather_sky else 0)
         cfg.row_rank, cfg.row_world, cfg.stripe_rows = row_rank, row_world, stripe_rows
         if slab_row0 is not None:                                # contiguous slabs instead of interleaved stripes (bhray_config.partition)
             cfg.partition = PARTITION_SLABS

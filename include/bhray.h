@@ -158,15 +158,9 @@ enum {                                  /* bhray_config.flags */
                                            border pixels: DESIGN.md §4), +8 % rays; 1080p, one frame at a time: 0.78 ms with a static
                                            camera, 0.84-0.87 ms with a moving one, 1.20 ms without the flag.  levels <= 4, no
                                            speculative / superset levels.                                                    */
-    BHRAY_F_FUSED      = 1u << 6,       /* fused ladder (an OPTION, off by default): ONE persistent launch per batch runs every level.
-                                           The grid classification (ray.wgsl:167-243) becomes work items of 8x8-pixel tiles inside the
-                                           trace kernel; a tile of level l+1 is classified as soon as the level-l tiles it reads are
-                                           final (classified and all their rays stored), so a level's tail overlaps the next level's
-                                           head.  Same pixels (tests/test_gpu_fused.py).  MEASURED SLOWER than the launch-per-level
-                                           ladder on MI355X - 2.1 against 1.2 ms for one 1080p frame at a time: 43 000 tile hand-offs
-                                           through the memory system cost more than the launch boundaries they replace (DESIGN.md §4.6,
-                                           profiles/EXPERIMENTS.md R3.1).  levels <= 4; combines with speculative_levels and
-                                           frames_per_batch; not with superset levels or BHRAY_F_TEMPORAL.                          */
+    /* (1u << 6 was BHRAY_F_FUSED, the fused ladder of rounds 3-5 - one persistent launch per batch with tile dependencies instead of
+       launch boundaries: measured slower on MI355X, 2.1 against 1.2 ms for one 1080p frame at a time, profiles/EXPERIMENTS.md R3.1 - removed
+       in round 6, kept as a patch: profiles/variants_src/.  bhray_create refuses the bit.)                                              */
     BHRAY_F_EVAL_FMA   = 1u << 5,       /* a THIRD evaluation of the integrator: the shader text with fused multiply-add contraction only
                                            (every `x*y + z` of ray.wgsl:401-480 one fma), none of the contract's reassociations (N9/N10).
                                            Like BHRAY_F_LITERAL it exists for measurement: the pixels on which it differs from the literal
@@ -180,6 +174,7 @@ enum {                                  /* bhray_config.flags */
                                            assembled image; the RGBA32F frame is NOT assembled: bhray_read_hdr, bhray_read_hdr_async,
                                            bhray_hdr_device_ptr and bhray_bind_output return BHRAY_E_STATE.  For a host that lets the library
                                            run the sky pass.  Same pixels as the sky pass over the assembled frame.  */
+    BHRAY_F_ALL        = 0xbfu,         /* every flag above and below: bhray_create refuses any other bit                    */
     BHRAY_F_LITERAL    = 1u << 2        /* the integrator (ray.wgsl:401-480, 533) operator by operator: one binary32 operation per
                                            WGSL operator in source order, no fused multiply-add, no reassociation.  Slower; exists
                                            to MEASURE how far the default evaluation (DESIGN.md §2, N3/N7/N9/N10 — permitted by
@@ -311,7 +306,7 @@ int bhray_balance_slabs(const bhray_config* cfg, const uint64_t* const* row_work
  *   slabs whatever the ctx was created with; partitions = device_count, or row_world; a partition may own no rows).  Waits for
  *   everything enqueued so far, rewrites the row tables of the engines and the gather tables in place; per-frame queues, send and
  *   staging buffers grow when the new rows need more (by a quarter more than needed, so that bounds that keep moving a few rows do
- *   not reallocate).  One process per GPU: every rank calls it with the same bounds before its next bhray_render.  Not with BHRAY_F_FUSED.
+ *   not reallocate).  One process per GPU: every rank calls it with the same bounds before its next bhray_render. 
  * bhray_rebalance_slabs: pure host arithmetic behind bhray_rebalance, exposed so that a host can balance by its own measurements.
  *   row_weight[frame_h] is the caller's persistent estimate of what every frame row costs (all zero before the first call); the call
  *   rescales the rows of every partition so that their sum is that partition's measured part_cost (the shape inside a partition is
@@ -502,8 +497,8 @@ typedef struct bhray_counters {        /* summed over all levels of the last ren
 int bhray_get_counters(bhray_ctx* ctx, bhray_counters* out);   /* needs BHRAY_F_COUNTERS     */
 int bhray_get_level_counters(bhray_ctx* ctx, uint32_t level, bhray_counters* out);
 /* Where the work of the last render lies: out[y] = iterations of all rays traced for row y of ladder level `level` (n = level_h[level]
- * numbers; rows this ctx did not render are 0; a multi-partition ctx sums its local partitions).  Needs BHRAY_F_COUNTERS; not with
- * BHRAY_F_FUSED.  The input of bhray_balance_slabs.                                                                                */
+ * numbers; rows this ctx did not render are 0; a multi-partition ctx sums its local partitions).  Needs BHRAY_F_COUNTERS.
+ * The input of bhray_balance_slabs.                                                                                              */
 int bhray_get_row_work(bhray_ctx* ctx, uint32_t level, uint64_t* out, uint32_t n);
 
 /* Device self-test of the properties two exact shortcuts rest on: (i) the integrator computes the correctly

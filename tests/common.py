@@ -71,8 +71,8 @@ class DeviceBuffer:
 
 
 def variant_library(target: str) -> str:
-    """Path of bhusie_amd/libbhray_<target>.so - another in-tree build of the SAME sources (`make -C bhusie_amd/csrc <target>`: fused, stack2,
-    pair; __graft_entry__.build() makes them all).  Built here if it is missing (a fresh checkout on a box with hipcc): never a fallback."""
+    """Path of bhusie_amd/libbhray_<target>.so - another in-tree build of the SAME sources (`make -C bhusie_amd/csrc <target>`: stack2;
+    __graft_entry__.build() makes it).  Built here if it is missing (a fresh checkout on a box with hipcc): never a fallback."""
     import os
     import subprocess
     from bhusie_amd import _lib

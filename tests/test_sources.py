@@ -48,52 +48,34 @@ def test_the_two_forms_of_the_integrator_step_are_the_same_operations():
         assert not re.search(r"\b(cpos|cdir|ppos|pdir|rkpos|rkdir|rkh|qrel|dist_c|cpos_dist|closest|cold|next_ray|hit_black_hole|black_hole_culls)\b", line), line
 
 
-def test_default_build_instantiates_no_fused_ladder_and_no_experiment_macros():
-    src = open(os.path.join(ROOT, "bhusie_amd", "csrc", "bhray_kernels.hip")).read()
-    assert "BHRAY_EXP_" not in src and "#define BHRAY_WITH_FUSED 0" in src
-    # the fused ladder's code lives in its own include, reached only under BHRAY_WITH_FUSED
-    for m in re.finditer(r'#include "bhray_fused.inc"', src):
-        before = src[:m.start()]
-        assert before.rfind("#if BHRAY_WITH_FUSED") > before.rfind("#endif"), "bhray_fused.inc included outside an #if BHRAY_WITH_FUSED block"
-    mk = open(os.path.join(ROOT, "bhusie_amd", "csrc", "Makefile")).read()
-    assert "-DBHRAY_WITH_FUSED=1" in mk and "fused:" in mk
+def test_the_product_tree_holds_no_measured_and_rejected_variants():
+    """the fused ladder (BHRAY_F_FUSED), the pair march and the experiment flags of rounds 3-5 are patches under
+    profiles/variants_src/, not code the product builds; the trace kernel has at most 32 instantiations."""
+    csrc = os.path.join(ROOT, "bhusie_amd", "csrc")
+    src = open(os.path.join(csrc, "bhray_kernels.hip")).read()
+    for gone in ("BHRAY_EXP_", "BHRAY_EXPERIMENT_", "BHRAY_WITH_FUSED", "BHRAY_WITH_PAIR", "BHRAY_BVH_PREFETCH", "bhray_fused.inc", "bhray_pair.inc"):
+        assert not re.search(r"^\s*#\s*(if|ifdef|ifndef|define|include).*" + re.escape(gone), src, re.M), gone
+    assert not os.path.exists(os.path.join(csrc, "bhray_fused.inc")) and not os.path.exists(os.path.join(csrc, "bhray_pair.inc"))
+    assert "BHRAY_F_FUSED " not in open(os.path.join(ROOT, "include", "bhray.h")).read().replace("(1u << 6 was BHRAY_F_FUSED,", "")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    assert "fused:" not in mk and "pair:" not in mk and "stack2:" in mk
+    vs = os.path.join(ROOT, "profiles", "variants_src")
+    assert os.path.exists(os.path.join(vs, "r06_fused_ladder_and_pair_march.patch")) and os.path.exists(os.path.join(vs, "README.md"))
+    # instantiations: every explicit trace_kernel<...> the launchers can reach
+    combos = set()
+    for meth in (0, 1):
+        for models in (False, True):
+            for dense in (False, True):
+                for count in (False, True):
+                    for ev in (0, 1, 2):
+                        if _trace_variant_exists(src, ev, models, dense, count):
+                            combos.add((meth, models, dense, count, ev))
+    assert 16 <= len(combos) <= 32, len(combos)
 
 
-def test_default_build_has_no_pair_march_and_the_pair_step_is_next_ray_rk_on_2_vectors():
-    """bhray_pair.inc is a build option (make pair).  Its integrator step must be next_ray_rk line for line with the scalar helpers
-    replaced by their 2-vector counterparts - the GPU tests compare frames byte for byte, this catches a drift between the two texts
-    at review time."""
-    src = open(os.path.join(ROOT, "bhusie_amd", "csrc", "bhray_kernels.hip")).read()
-    assert "#define BHRAY_WITH_PAIR 0" in src
-    inc = open(os.path.join(ROOT, "bhusie_amd", "csrc", "bhray_pair.inc")).read()
-    assert inc.lstrip().startswith("//") and "#if BHRAY_WITH_PAIR" in inc and inc.rstrip().endswith("#endif  // BHRAY_WITH_PAIR")
-    code = inc[inc.index("#if BHRAY_WITH_PAIR"):]
-    assert "__global__" in code                                   # the kernel lives entirely inside the #if
-
-    def body(text, name):
-        i = text.index(name)
-        i = text.index("{", i)
-        depth, j = 0, i
-        while True:
-            depth += {"{": 1, "}": -1}.get(text[j], 0)
-            if depth == 0:
-                return text[i + 1:j]
-            j += 1
-
-    def stage_lines(b):
-        out = []
-        for line in b.splitlines():
-            line = line.split("//")[0].strip()
-            if re.match(r"const (F3|P3) (K[1-6]|e|ds|cr) =", line):
-                out.append(line)
-        return out
-
-    scalar = stage_lines(body(src, "void next_ray_rk(F3 q0"))
-    packed = stage_lines(body(inc, "void next_ray_rk_pair(P3T<V> q0"))
-    assert len(scalar) == len(packed) == 9
-    for a, b in zip(scalar, packed):
-        b = b.replace("P3", "F3").replace("pmadd3", "fmadd3").replace("pcross", "fcross")
-        b = re.sub(r"sp<V>\(([A-Z0-9]+)\)", r"\1", b)
-        assert a == b, (a, b)
-    mk = open(os.path.join(ROOT, "bhusie_amd", "csrc", "Makefile")).read()
-    assert "-DBHRAY_WITH_PAIR=1" in mk and "pair:" in mk
+def _trace_variant_exists(src, ev, models, dense, count):
+    """mirrors trace_variant_exists() of bhray_kernels.hip: which (evaluation, mesh, dense, counting) builds are instantiated"""
+    m = re.search(r"constexpr bool trace_variant_exists\(int eval, bool models, bool dense, bool count\) \{\s*return (.*?);\s*\}", src, re.S)
+    assert m, "trace_variant_exists() not found in bhray_kernels.hip"
+    expr = m.group(1).replace("&&", " and ").replace("||", " or ").replace("!", " not ").replace("not =", "!=")
+    return bool(eval(expr, {}, {"eval": ev, "models": models, "dense": dense, "count": count}))
