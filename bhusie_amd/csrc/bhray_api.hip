@@ -154,6 +154,7 @@ struct bhray_dev {
                                            // radius of 1-2 adds 2-4 % rays and does not shorten a moving camera's frames - the misses are scattered interpolate/trace flips)
     int bpc_override = 0;                  // BHRAY_TRACE_BLOCKS_PER_CU (tuning experiments only)
     int grid_override = 0;                 // BHRAY_TRACE_GRID: absolute number of persistent trace blocks (tuning experiments only)
+    int quad_wps = -1;                     // BHRAY_QUAD: waves per SIMD the quad march may use for a short queue (bhray_quad.inc); 0 = the scalar thin shares only; -1 = the measured default (RK 2, Euler 1)
     int dense_override = -1;               // BHRAY_TRACE_DENSE=0/1 (tuning experiments only)
     int coarse_build = -1;                 // BHRAY_COARSE_BUILD=0/1 (experiment): the build of the trace launches below the ladder's last level (-1: the batch's build)
     bool rendered = false;
@@ -560,6 +561,7 @@ int dev_create(const bhray_config* cfg, const bhray::DevOptions& opt, bhray_dev*
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = getenv("BHRAY_TRACE_BLOCKS_PER_CU")) c->bpc_override = atoi(e);
     if (const char* e = getenv("BHRAY_TRACE_GRID")) c->grid_override = atoi(e);
+    if (const char* e = getenv("BHRAY_QUAD")) { const int q = atoi(e); c->quad_wps = q < 0 ? 0 : (q > 4 ? 4 : q); }
     if (const char* e = getenv("BHRAY_TEMPORAL_MARGIN")) { const float m = (float)atof(e); c->temporal_margin = m < 0.05f ? 0.05f : (m > 1.0f ? 1.0f : m); }
     if (const char* e = getenv("BHRAY_TEMPORAL_RADIUS")) {          // "fine[,coarse]": the last level, the levels below it
         int rf = 0, rc = -1;
@@ -1210,6 +1212,11 @@ int launch_batch(bhray_dev* c) {
         for (uint32_t k = 0; k < nb; k++) hl[k].work = S.fr[k].d_work;
         // a whole frame, one frame per launch: thin shares are dealt strided (bhray_kernels.hip, thin_stride; bit 1 of probe_empty)
         if (c->cfg.row_world <= 1 && nb == 1) hl[0].probe_empty |= 2;
+        // the quad march (bhray_quad.inc) for launches whose queue turns out short: how many waves per SIMD it may use (bits 2-4; 0 = off)
+        // Measured (profiles/EXPERIMENTS.md R6.1): one wave per SIMD -21 % per launch (RK, a level-0-sized queue), two -10 %, three +10 %: a second wave on a
+        // SIMD slows both, and from the third on a scalar wave with four times the rays is faster.  The Euler step has too little 3-vector work to gain at two.
+        const int quad_wps = c->quad_wps >= 0 ? c->quad_wps : (S.method == 0 ? 1 : 2);
+        for (uint32_t k = 0; k < nb; k++) hl[k].probe_empty |= (quad_wps & 7) << 2;
     }
     S.launched_frames = nb;
     // enqueue

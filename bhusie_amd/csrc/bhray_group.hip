@@ -29,6 +29,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -213,6 +214,8 @@ struct CommRank {                  // a local rank of the communicator: one GPU 
 
 struct WaitEvent { hipEvent_t ev = nullptr; int device = -1; bool in_use = false; };
 
+#define BHRAY_WATCH_SCOPES 24         // concurrently armed scopes: the caller's thread + one per issue thread (BHRAY_MAX_DEVICES) + slack
+
 struct GroupSlot {                 // per batch slot (same index as the devices' slots)
     float4* frames = nullptr;                 // root: B assembled frames
     std::vector<float4*> send;                // per partition: packed rows of the batch's frames (local non-root partitions)
@@ -305,6 +308,16 @@ struct bhray_ctx {
     uint64_t frames_staged = 0;
     bool rendered = false;
     std::atomic<bool> failed{false};       // a collective failed half way (on whichever thread): the communicator's state is unknown, every later gather is refused
+    // communication watchdog (see "Watchdog" below): armed scopes, the thread, what it did
+    std::atomic<int64_t> watch_deadline[BHRAY_WATCH_SCOPES];   // steady-clock ns by which an armed scope must have ended; 0 = free
+    const char* watch_what[BHRAY_WATCH_SCOPES] = {nullptr};
+    std::thread watch_thread;
+    std::mutex watch_m; std::condition_variable watch_cv; bool watch_stop = false;
+    int64_t watch_timeout_ms = 0;          // BHRAY_COMM_TIMEOUT_MS (default 30 000; 0 = no watchdog)
+    std::atomic<bool> watch_fired{false};
+    std::atomic<bool> comms_aborted{false}; // ncclCommAbort has been called on this ctx's communicators (by the watchdog, by drain / stop_workers of a failed ctx): never again, and no ncclCommDestroy
+    std::string watch_msg;                  // written once, before watch_fired is set
+    int* h_abort = nullptr;                 // pinned, device-visible: set to 1 when the watchdog fires (the test stall of BHRAY_TEST_FAULT leaves on it)
     float gather_ms = 0, deint_ms = 0; uint32_t gathers = 0;
     std::string err;
 };
@@ -316,7 +329,9 @@ thread_local std::string* tl_err = nullptr;
 int gfail(bhray_ctx* c, int code, const char* fmt, ...) {
     char buf[640];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
-    if (tl_err) *tl_err = buf; else if (c) c->err = buf; else dev_set_create_error(buf);
+    std::string msg = buf;
+    if (c && c->watch_fired.load(std::memory_order_acquire)) { msg = c->watch_msg + " [then: " + msg + "]"; code = BHRAY_E_COMM; }   // what the aborted call reports is a consequence
+    if (tl_err) *tl_err = msg; else if (c) c->err = msg; else dev_set_create_error(msg.c_str());
     return code;
 }
 // error of a per-device call: carry the device's message
@@ -333,6 +348,101 @@ int dfail(bhray_ctx* c, const bhray_dev* d, int rc) { if (rc) { if (tl_err) *tl_
         if (r_ != ncclSuccess) return gfail(c, BHRAY_E_COMM, "%s: %s", #call, (R)->GetErrorString(r_));          \
     } while (0)
 #define DEV(c, d, call) do { int rc_ = (call); if (rc_) return dfail(c, d, rc_); } while (0)
+
+// ------------------------------------------------------------------------------------------
+// Watchdog.  The gather has only ever run between partitions of ONE device; the first time it meets real links it may
+// meet a peer that never posts (a rank that failed, a mis-wired launcher), and then ncclGroupEnd (connection set-up on the first batch)
+// or the communication stream (an ncclRecv kernel that spins) waits for ever - and so does every bhray_sync, the bench, and the
+// driver's clock.  So: every call of the ABI on a ctx that gathers, and every frame an issue thread enqueues, is an ARMED SCOPE with a
+// deadline of BHRAY_COMM_TIMEOUT_MS (environment, default 30 000; 0 = no watchdog).  A thread of the ctx looks at the armed scopes ten
+// times a second; when one is overdue it writes the message, marks the ctx failed, raises the device-visible abort word and calls
+// ncclCommAbort on the ctx's communicators - which makes RCCL's blocked host calls return an error and its kernels leave their spin
+// loops.  The overdue call then returns BHRAY_E_COMM with the watchdog's message (a host call that RCCL failed, or the check behind the
+// wait it was blocked in); every later call of the ctx does too; bhray_destroy tears down without ncclCommDestroy.
+// What it cannot reach: ncclCommInitRank / ncclCommInitAll inside bhray_create (no communicator to abort yet).
+// ------------------------------------------------------------------------------------------
+int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+void abort_comms(bhray_ctx* c) {
+    if (c->comms_aborted.exchange(true)) return;
+    Rccl* R = g_rccl.so ? &g_rccl : nullptr;
+    if (!R || !R->CommAbort) return;
+    for (CommRank& r : c->ranks) if (r.comm) (void)R->CommAbort(r.comm);      // (the handles stay: a thread inside a call still holds them; nothing destroys them later)
+}
+
+void watch_main(bhray_ctx* c) {
+    std::unique_lock<std::mutex> lk(c->watch_m);
+    while (!c->watch_stop) {
+        c->watch_cv.wait_for(lk, std::chrono::milliseconds(100));
+        if (c->watch_stop || c->watch_fired.load()) continue;
+        const int64_t t = now_ns();
+        for (int i = 0; i < BHRAY_WATCH_SCOPES; i++) {
+            const int64_t d = c->watch_deadline[i].load(std::memory_order_acquire);
+            if (d == 0 || t < d) continue;
+            char buf[512];
+            snprintf(buf, sizeof buf, "watchdog: %s did not finish within BHRAY_COMM_TIMEOUT_MS = %lld ms - a peer of the RCCL gather never posted its share, or the "
+                     "links are down; the communicator has been aborted (ncclCommAbort), the ctx is failed: destroy it", c->watch_what[i] ? c->watch_what[i] : "a call", (long long)c->watch_timeout_ms);
+            c->watch_msg = buf;
+            c->failed = true;
+            c->watch_fired.store(true, std::memory_order_release);
+            fprintf(stderr, "bhray: %s\n", buf); fflush(stderr);
+            if (c->h_abort) __atomic_store_n(c->h_abort, 1, __ATOMIC_RELEASE);
+            abort_comms(c);
+            break;
+        }
+    }
+}
+
+struct WatchScope {                // arms a scope for the lifetime of the object (a ctx without a watchdog: nothing)
+    bhray_ctx* c; int slot = -1;
+    WatchScope(bhray_ctx* c_, const char* what) : c(c_) {
+        if (!c || c->watch_timeout_ms <= 0 || !c->watch_thread.joinable()) return;
+        const int64_t d = now_ns() + c->watch_timeout_ms * 1000000ll;
+        for (int i = 0; i < BHRAY_WATCH_SCOPES; i++) {
+            int64_t zero = 0;
+            if (c->watch_deadline[i].load(std::memory_order_relaxed) == 0) {
+                c->watch_what[i] = what;               // (written before the deadline is published; read only behind it)
+                if (c->watch_deadline[i].compare_exchange_strong(zero, d, std::memory_order_acq_rel)) { slot = i; return; }
+            }
+        }
+    }
+    ~WatchScope() { if (slot >= 0) c->watch_deadline[slot].store(0, std::memory_order_release); }
+    WatchScope(const WatchScope&) = delete; WatchScope& operator=(const WatchScope&) = delete;
+};
+// behind a wait that the watchdog may have cut short: the frames are not what they should be, say so
+#define WATCH_CHECK(c) do { if ((c)->watch_fired.load(std::memory_order_acquire)) return gfail(c, BHRAY_E_COMM, "the wait ended because the communicator was aborted"); } while (0)
+
+void watch_start(bhray_ctx* c) {
+    const char* e = getenv("BHRAY_COMM_TIMEOUT_MS");
+    c->watch_timeout_ms = e ? atoll(e) : 30000;
+    if (c->watch_timeout_ms <= 0) return;
+    if (hipHostMalloc((void**)&c->h_abort, sizeof(int), hipHostMallocMapped) == hipSuccess && c->h_abort) *c->h_abort = 0; else c->h_abort = nullptr;
+    c->watch_thread = std::thread(watch_main, c);
+}
+void watch_stop(bhray_ctx* c) {
+    if (c->watch_thread.joinable()) {
+        { std::lock_guard<std::mutex> lk(c->watch_m); c->watch_stop = true; }
+        c->watch_cv.notify_all();
+        c->watch_thread.join();
+    }
+    if (c->h_abort) { (void)hipHostFree(c->h_abort); c->h_abort = nullptr; }
+}
+
+// BHRAY_TEST_FAULT (tests only; tests/test_gpu_comm_watchdog.py): "stall_gather:<n>" - the n-th gather of the process enqueues, in front of its
+// RCCL group, a kernel that spins on the communication stream until the watchdog raises the abort word (at most ~20 s: never a hung GPU) -
+// what a receive that is never matched looks like from the host; "fail_render:<n>" - the n-th frame an issue thread enqueues fails.
+__global__ void test_stall_kernel(const int* abort_word, long long limit_ticks) {
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0 && wall_clock64() - t0 < limit_ticks) __builtin_amdgcn_s_sleep(127);
+}
+std::atomic<int> g_fault_gathers{0}, g_fault_renders{0};
+int test_fault(const char* kind) {            // 0: off, n >= 1: at the n-th event
+    const char* e = getenv("BHRAY_TEST_FAULT");
+    if (!e) return 0;
+    const size_t k = strlen(kind);
+    if (strncmp(e, kind, k) != 0 || e[k] != ':') return 0;
+    return atoi(e + k + 1);
+}
 
 Part* root_part(bhray_ctx* c) { return &c->parts[c->root]; }
 CommRank* rank_of(bhray_ctx* c, const Part& p) {
@@ -407,6 +517,12 @@ int group_gather(bhray_ctx* c, int si, uint32_t nb, const CommRank* only = nullp
         }
     }
     if (rr && timing) { GHIP(c, hipSetDevice(rr->device)); GHIP(c, hipEventRecord(G.tev[0], rr->stream)); }
+    if (const int at = test_fault("stall_gather")) {
+        if (rr && c->h_abort && ++g_fault_gathers == at) {
+            GHIP(c, hipSetDevice(rr->device));
+            hipLaunchKernelGGL(test_stall_kernel, dim3(1), dim3(1), 0, rr->stream, (const int*)c->h_abort, 20ll * 100000000ll);
+        }
+    }
     // ONE group: every tile of the batch.  Sends and receives are issued in partition order, so the messages between
     // a pair of ranks (several partitions may share a rank) match in order.
     GNCCL(c, R, R->GroupStart());
@@ -496,6 +612,7 @@ int after_launch(bhray_ctx* c, const CommRank* only = nullptr) {
         CommRank* rr = rank_of(c, *root_part(c));
         GHIP(c, hipSetDevice(rr->device));
         GHIP(c, hipEventSynchronize(G.tev[2]));
+        WATCH_CHECK(c);
         float a = 0, b = 0;
         GHIP(c, hipEventElapsedTime(&a, G.tev[0], G.tev[1])); GHIP(c, hipEventElapsedTime(&b, G.tev[1], G.tev[2]));
         c->gather_ms += a; c->deint_ms += b; G.timed = false;
@@ -512,6 +629,7 @@ int group_sync(bhray_ctx* c) {
     { int rc = group_flush(c); if (rc) return rc; }
     for (Part& p : c->parts) if (p.dev) DEV(c, p.dev, dev_sync(p.dev));
     for (CommRank& r : c->ranks) { GHIP(c, hipSetDevice(r.device)); GHIP(c, hipStreamSynchronize(r.stream)); }
+    WATCH_CHECK(c);
     return BHRAY_OK;
 }
 
@@ -519,9 +637,7 @@ void group_free(bhray_ctx* c) {
     Rccl* R = g_rccl.so ? &g_rccl : nullptr;
     // A ctx that failed in the middle of a batch (one rank's issue thread met an error, the others have posted their sends and receives)
     // may hold RCCL operations that will never be matched: they are aborted, or the synchronisations below would wait for them for ever.
-    if ((c->failed.load() || c->async_failed.load()) && R && R->CommAbort) {
-        for (CommRank& r : c->ranks) if (r.comm) { (void)hipSetDevice(r.device); (void)R->CommAbort(r.comm); r.comm = nullptr; }
-    }
+    if (c->failed.load() || c->async_failed.load()) abort_comms(c);
     for (CommRank& r : c->ranks) if (r.stream) { (void)hipSetDevice(r.device); (void)hipStreamSynchronize(r.stream); }
     for (Part& p : c->parts) if (p.dev) { dev_destroy(p.dev); p.dev = nullptr; }
     for (uint32_t q = 0; q < c->parts.size(); q++) {
@@ -549,7 +665,7 @@ void group_free(bhray_ctx* c) {
     }
     for (CommRank& r : c->ranks) {
         (void)hipSetDevice(r.device);
-        if (r.comm && R) (void)R->CommDestroy(r.comm);
+        if (r.comm && R && !c->comms_aborted.load()) (void)R->CommDestroy(r.comm);
         if (r.stream) (void)hipStreamDestroy(r.stream);
     }
     for (auto& e : c->read_ev) if (e) (void)hipEventDestroy(e);
@@ -669,7 +785,12 @@ void worker_main(bhray_ctx* c, Worker* w) {
         lk.unlock();
         int rc = BHRAY_OK; std::string msg;
         tl_err = &msg;                 // gfail / dfail of this thread write here
-        if (!c->async_failed.load(std::memory_order_acquire)) rc = worker_render(c, cr, cmd);
+        if (!c->async_failed.load(std::memory_order_acquire)) {
+            WatchScope ws(c, "a frame's launches and gather on an issue thread");
+            const int at = test_fault("fail_render");
+            if (at && ++g_fault_renders == at) rc = gfail(c, BHRAY_E_STATE, "BHRAY_TEST_FAULT: frame %d fails on the issue thread of GPU %d", at, cr->device);
+            else rc = worker_render(c, cr, cmd);
+        }
         lk.lock();
         if (rc != BHRAY_OK && w->rc == BHRAY_OK) { w->rc = rc; w->err = msg; c->async_failed.store(true, std::memory_order_release); }
         w->busy = false;
@@ -683,7 +804,11 @@ int drain(bhray_ctx* c) {
     if (!c->threaded) return BHRAY_OK;
     for (auto& w : c->workers) {
         std::unique_lock<std::mutex> lk(w->m);
-        w->idle_cv.wait(lk, [&] { return w->q.empty() && !w->busy; });
+        // One thread failed before its sends: the others' ncclGroupEnd (connection set-up on the first batch) would wait for that peer for
+        // ever, and this wait with them.  A failed ctx's communicators are aborted as soon as the failure is seen - here, not in
+        // bhray_destroy behind the join.
+        while (!w->idle_cv.wait_for(lk, std::chrono::milliseconds(50), [&] { return w->q.empty() && !w->busy; }))
+            if (c->async_failed.load(std::memory_order_acquire) || c->failed.load()) { lk.unlock(); abort_comms(c); lk.lock(); }
     }
     c->mirror_stale = true;          // whatever the caller does next on its own thread may launch staged frames
     if (c->async_failed.load(std::memory_order_acquire)) {
@@ -696,9 +821,13 @@ int drain(bhray_ctx* c) {
     }
     return BHRAY_OK;
 }
-#define ENTER(c) do { if ((c)->threaded) { int rc_ = drain(c); if (rc_) return rc_; } } while (0)
+// every call of the ABI on a ctx that gathers: an armed scope (Watchdog above) for as long as the call lasts; a ctx the watchdog failed answers with its message
+#define ENTER(c) WatchScope watch_scope_((c)->gather ? (c) : nullptr, __func__);                                        \
+    do { if ((c)->watch_fired.load(std::memory_order_acquire)) return gfail(c, BHRAY_E_COMM, "%s refused", __func__);  \
+         if ((c)->threaded) { int rc_ = drain(c); if (rc_) return rc_; } } while (0)
 
 void stop_workers(bhray_ctx* c) {
+    if (c->async_failed.load() || c->failed.load()) abort_comms(c);     // (a thread blocked in RCCL behind a failed peer would never be joined)
     for (auto& w : c->workers) {
         { std::lock_guard<std::mutex> lk(w->m); w->stop = true; }
         w->cv.notify_all();
@@ -868,7 +997,11 @@ const char* bhray_last_error(const bhray_ctx* c) { return c ? c->err.c_str() : d
 
 void bhray_destroy(bhray_ctx* c) {
     if (!c) return;
-    stop_workers(c);                 // (the issue threads finish what they hold first)
+    {
+        WatchScope ws(c->gather ? c : nullptr, "bhray_destroy");     // (issue threads that finish what they hold may wait for a peer)
+        stop_workers(c);             // (the issue threads finish what they hold first)
+    }
+    watch_stop(c);
     group_free(c);
     delete c;
 }
@@ -985,6 +1118,7 @@ int bhray_create(const bhray_config* cfg_in, bhray_ctx** out) {
         c->ranks.push_back(r);
     }
     for (CommRank& r : c->ranks) { CH(hipSetDevice(r.device)); CH(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking)); }
+    watch_start(c);
     // ---- buffers
     c->gslots.resize(c->nslots);
     for (GroupSlot& G : c->gslots) {
@@ -1217,6 +1351,15 @@ int bhray_rebalance(bhray_ctx* c, bhray_rebalance_info* out) {
     double cost[BHRAY_MAX_DEVICES] = {0}, extra[BHRAY_MAX_DEVICES] = {0};
     uint32_t frames = 0;
     bool have[BHRAY_MAX_DEVICES] = {false};
+    if (!was_slabs) {
+        // A ctx created with interleaved stripes has measured STRIPE SETS, and their costs say nothing about contiguous slabs (rescaling
+        // the rows of slab p by the cost of stripe set p polluted the learned row weights and made the first bounds arbitrary).  The first call
+        // only moves the ctx to equal slabs - every rank takes this branch, there is nothing to exchange - and learning starts with the next.
+        c->rebalances++;
+        { int rc = bhray_set_partition(c, cur); if (rc) return rc; }
+        if (out) { out->partitions = N; out->applied = 1u; for (uint32_t p = 0; p <= N; p++) out->slab_row0[p] = cur[p]; }
+        return BHRAY_OK;
+    }
     { int rc = partition_costs(c, cur, cost, extra, have, &frames); if (rc) return rc; }
     if (c->ranks.size() == 1 && c->comm_size > 1) {
         // one process per GPU: everybody learns everybody's number over the communicator, on the communication stream
@@ -1232,6 +1375,7 @@ int bhray_rebalance(bhray_ctx* c, bhray_rebalance_info* out) {
         std::vector<float> all(2 * (size_t)N);
         GHIP(c, hipMemcpyAsync(all.data(), c->d_xchg + 2, all.size() * sizeof(float), hipMemcpyDeviceToHost, cr.stream));
         GHIP(c, hipStreamSynchronize(cr.stream));
+        WATCH_CHECK(c);
         for (uint32_t q = 0; q < N; q++) { have[q] = all[2 * q] >= 0.0f; cost[q] = have[q] ? all[2 * q] : 0.0; extra[q] = all[2 * q + 1]; }
     }
     // a partition without rows measures nothing and that is fine; a partition WITH rows and no measurement means it has not rendered yet
@@ -1247,7 +1391,7 @@ int bhray_rebalance(bhray_ctx* c, bhray_rebalance_info* out) {
     for (uint32_t q = 0; q < N; q++) before = std::max(before, cost[q] + extra[q]);
     { int rc = bhray_rebalance_slabs(H, N, cur, cost, extra, shift, c->row_weight.data(), next, &predicted); if (rc) return gfail(c, rc, "bhray_rebalance_slabs failed"); }
     c->rebalances++;
-    bool differ = !was_slabs;
+    bool differ = false;
     for (uint32_t p = 0; p <= N; p++) differ = differ || next[p] != cur[p];
     const bool apply = differ && predicted < 0.98 * before;
     if (apply) { int rc = bhray_set_partition(c, next); if (rc) return rc; }
@@ -1405,6 +1549,8 @@ int bhray_render(bhray_ctx* c) {
         return BHRAY_OK;
     }
     // staged frames of another kernel variant are launched (and gathered) first: the staging position is then final
+    WatchScope watch_scope_(c, "bhray_render");
+    if (c->watch_fired.load(std::memory_order_acquire)) return gfail(c, BHRAY_E_COMM, "bhray_render refused");
     int si = -1; uint32_t sub = 0;
     for (Part& p : c->parts) {
         if (!p.dev) continue;
@@ -1547,7 +1693,7 @@ int bhray_read_hdr_async(bhray_ctx* c, float* dst, size_t pitch, uint64_t* ticke
     GHIP(c, hipSetDevice(rp.device));
     hipEvent_t& ev = c->read_ev[t % 64];
     if (!ev) GHIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    else if (t >= 64) GHIP(c, hipEventSynchronize(ev));
+    else if (t >= 64) { GHIP(c, hipEventSynchronize(ev)); WATCH_CHECK(c); }
     GroupSlot& G = c->gslots[(size_t)c->last_slot];
     // in stream order on the root's communication stream: behind the de-interleave (and the sky pass, if it was resolved) of this batch,
     // ahead of the next batch's receive.  (Cross-stream event ordering made ROCm 7.2 serialise copies and kernels: see dev_read_hdr_async.)
@@ -1578,7 +1724,7 @@ int bhray_read_sky_async(bhray_ctx* c, uint16_t* dst, size_t pitch, uint64_t* ti
     GHIP(c, hipSetDevice(rp.device));
     hipEvent_t& ev = c->read_ev[t % 64];
     if (!ev) GHIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    else if (t >= 64) GHIP(c, hipEventSynchronize(ev));
+    else if (t >= 64) { GHIP(c, hipEventSynchronize(ev)); WATCH_CHECK(c); }
     if (pitch == rowb) GHIP(c, hipMemcpyAsync(dst, src, rowb * c->cfg.frame_h, hipMemcpyDeviceToHost, rr->stream));     // behind the sky pass, in stream order
     else GHIP(c, hipMemcpy2DAsync(dst, pitch, src, rowb, rowb, c->cfg.frame_h, hipMemcpyDeviceToHost, rr->stream));
     GHIP(c, hipEventRecord(ev, rr->stream));
@@ -1593,6 +1739,7 @@ int bhray_wait_read(bhray_ctx* c, uint64_t ticket) {
     if (!c->root_local || c->read_tickets - ticket > 64 || !c->read_ev[ticket % 64]) return BHRAY_OK;
     GHIP(c, hipSetDevice(root_part(c)->device));
     GHIP(c, hipEventSynchronize(c->read_ev[ticket % 64]));
+    WATCH_CHECK(c);
     return BHRAY_OK;
 }
 

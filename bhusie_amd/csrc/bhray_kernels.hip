@@ -948,6 +948,8 @@ template <> struct ColdState<true> {
     __device__ __forceinline__ void set_hit(bool v) { b[8 * S] = v ? 1.0f : 0.0f; }
 };
 
+#include "bhray_quad.inc"
+
 template <int METHOD, bool MODELS, bool COUNT, bool DENSE, int EVAL = 0>
 __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_WAVES_MESH_DENSE : BHRAY_TRACE_WAVES_MESH) : (DENSE ? BHRAY_TRACE_WAVES_DENSE : BHRAY_TRACE_WAVES)) void trace_kernel(const FrameParams* __restrict__ Pb, const FrameLaunch* __restrict__ Fb, const int nb, int* __restrict__ err_flag) {
     const int lane = threadIdx.x & 63;
@@ -1030,6 +1032,31 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
         if (thin_share != 0u && fi != 0) continue;
     }
     const HotParams H = load_hot<MODELS>(P);
+    // The quad march (bhray_quad.inc): a queue that fits 16 rays per wave on the waves the host allows it (bits 2-4 of probe_empty: waves per
+    // SIMD; 0 = off) is marched with one ray per QUAD of lanes - x, y, z on three lanes - instead of one per lane: fewer instructions per
+    // iteration of the launch's longest ray, the same operations per ray.  Dealt out once like a scalar thin share; whole rounds of one wave per SIMD.
+    if constexpr (!DENSE && !MODELS && !COUNT && EVAL == 0) {
+        const uint32_t q_wps = ((uint32_t)F.probe_empty >> 2) & 7u;
+        if (q_wps != 0u && BHRAY_THIN_WAVES > 0 && (nb == 1 || gridDim.x >= 4u * (uint32_t)nb)) {
+            uint32_t own_blocks = gridDim.x, my_block = blockIdx.x;
+            if (nb > 1) { own_blocks = (gridDim.x - (uint32_t)fb + (uint32_t)nb - 1u) / (uint32_t)nb; my_block = blockIdx.x / (uint32_t)nb; }
+            const uint32_t total = own_blocks * (BHRAY_TRACE_THREADS / 64);
+            const uint32_t round = nb > 1 ? ((uint32_t)BHRAY_THIN_WAVES + (uint32_t)nb - 1u) / (uint32_t)nb : (uint32_t)BHRAY_THIN_WAVES;     // one wave per SIMD
+            const uint32_t rounds = ((qcount + 15u) / 16u + round - 1u) / round;
+            uint32_t waves = rounds * round;
+            if (waves > total) waves = total;
+            if (rounds <= q_wps && rounds <= (uint32_t)BHRAY_QUAD_MAX_WPS && (unsigned long long)waves * 16ull >= (unsigned long long)qcount) {
+                if (fi != 0) continue;                                    // (a block that comes by to help leaves such a frame alone, as with the scalar thin shares)
+                const uint32_t w = my_block * (BHRAY_TRACE_THREADS / 64) + (threadIdx.x >> 6);
+                if (w < waves && qcount != 0u) {
+                    const uint32_t share = (qcount + waves - 1u) / waves;          // <= 16
+                    const bool strided = (F.probe_empty & 2) != 0;                 // a whole frame, one frame per launch: entries w, w + waves, ... (see the thin shares below)
+                    quad_march<METHOD>(P, F, H, qcount, strided ? w : w * share, share, strided ? waves : 0u, work_steps);
+                }
+                continue;
+            }
+        }
+    }
     const F3 bpos = H.bh;
     const float t_max = 1e5f, t_min = 1e-8f;
 

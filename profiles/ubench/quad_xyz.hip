@@ -6,6 +6,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -Wno-unused-value -I../../include quad_xyz.hip -o quad_xyz
 #include "../../bhusie_amd/csrc/bhray_kernels.hip"
 #include <cstdio>
+#include <vector>
 using namespace bhray;
 
 // quad_perm control words: lane i of a quad reads lane sel[i]
@@ -16,8 +17,8 @@ template <int CTRL> __device__ __forceinline__ float qperm(float v) {
 __device__ __forceinline__ float bx(float v) { return qperm<QP(0, 0, 0, 0)>(v); }     // component x of the lane's ray, in every lane of the quad
 __device__ __forceinline__ float by(float v) { return qperm<QP(1, 1, 1, 1)>(v); }
 __device__ __forceinline__ float bz(float v) { return qperm<QP(2, 2, 2, 2)>(v); }
-__device__ __forceinline__ float r1(float v) { return qperm<QP(1, 2, 0, 3)>(v); }     // component c + 1 (cyclic)
-__device__ __forceinline__ float r2(float v) { return qperm<QP(2, 0, 1, 3)>(v); }     // component c + 2
+__device__ __forceinline__ float r1(float v) { return qperm<QP(1, 2, 0, 0)>(v); }     // component c + 1 (cyclic); lane 3 of a quad follows lane 2 (it carries a copy of z: no garbage in the range guards' ballots)
+__device__ __forceinline__ float r2(float v) { return qperm<QP(2, 0, 1, 1)>(v); }     // component c + 2
 // fdot(a, b) = fma(a.z, b.z, fma(a.y, b.y, a.x * b.x)) in every lane of the quad
 __device__ __forceinline__ float qdot(float a, float b) {
     const float p = a * b;
@@ -60,7 +61,8 @@ __device__ __forceinline__ void quad_rk(float q0, float& pos, float& dir, float&
 
 // MODE 0: the product's scalar step, one ray per lane; MODE 1: one ray per quad
 template <int MODE>
-__global__ void k(float* out, long long* cyc, int steps, float x0) {
+__global__ void k(float* out, long long* cyc, int steps, float x0, long long* wall = nullptr) {
+    const long long w0 = wall_clock64();
     const F3 bpos = f3(0.0f, 0.0f, 0.0f);
     const int ray = MODE == 0 ? (int)threadIdx.x : (int)(threadIdx.x >> 2);          // the quad build marches rays 0 .. 15 of the scalar build's 64
     const int c = threadIdx.x & 3;
@@ -92,34 +94,39 @@ __global__ void k(float* out, long long* cyc, int steps, float x0) {
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = o;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+    if (wall && (threadIdx.x & 63) == 0) wall[blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)] = wall_clock64() - w0;      // 100 MHz, constant rate
 }
 
 template <int MODE>
 void run(const char* what, int blocks, int threads, float* first16) {
-    float* out; long long* cyc;
-    (void)hipMalloc(&out, (size_t)blocks * threads * sizeof(float)); (void)hipMalloc(&cyc, blocks * sizeof(long long));
-    const int steps = 300;
+    float* out; long long* cyc; long long* wall;
+    const int nw = blocks * threads / 64;
+    (void)hipMalloc(&out, (size_t)(blocks > 1024 ? blocks : 1024) * 256 * sizeof(float)); (void)hipMalloc(&cyc, (blocks > 1024 ? blocks : 1024) * sizeof(long long)); (void)hipMalloc(&wall, nw * sizeof(long long));
+    const int steps = 3000;
+    for (int rep = 0; rep < 20; rep++) hipLaunchKernelGGL((k<MODE>), dim3(1024), dim3(256), 0, 0, out, cyc, 300, 0.5f, (long long*)nullptr);     // the whole chip busy first: the clocks are up when the measured launches run
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<MODE>), dim3(blocks), dim3(threads), 0, 0, out, cyc, steps, 0.5f); (void)hipDeviceSynchronize();
+    hipLaunchKernelGGL((k<MODE>), dim3(blocks), dim3(threads), 0, 0, out, cyc, steps, 0.5f, wall); (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0);
-    for (int rep = 0; rep < 5; rep++) hipLaunchKernelGGL((k<MODE>), dim3(blocks), dim3(threads), 0, 0, out, cyc, steps, 0.5f);
+    for (int rep = 0; rep < 5; rep++) hipLaunchKernelGGL((k<MODE>), dim3(blocks), dim3(threads), 0, 0, out, cyc, steps, 0.5f, wall);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    std::vector<long long> hw(nw); (void)hipMemcpy(hw.data(), wall, nw * sizeof(long long), hipMemcpyDeviceToHost);
+    long long wmax = 0, wsum = 0; for (long long v : hw) { wmax = v > wmax ? v : wmax; wsum += v; }
     long long h; (void)hipMemcpy(&h, cyc, sizeof h, hipMemcpyDeviceToHost);
     float o[64]; (void)hipMemcpy(o, out, sizeof o, hipMemcpyDeviceToHost);
     for (int r = 0; r < 16; r++) first16[r] = MODE == 0 ? o[r] : o[4 * r];
     const double rays = (double)blocks * threads / (MODE == 0 ? 1 : 4);
-    printf("%-34s %5d waves: %6.0f ticks per step (wave 0), %.1f G ray-steps/s, out[0] = %.9g\n", what, blocks * threads / 64, (double)h / steps,
-           rays * steps / (ms * 1e-3) / 1e9, o[0]);
-    (void)hipFree(out); (void)hipFree(cyc);
+    printf("%-34s %5d waves: %6.0f clock64 ticks per step (wave 0); wall clock per step: mean %.1f ns, slowest wave %.1f ns; launch %.1f ns per step; %.1f G ray-steps/s, out[0] = %.9g\n", what, nw, (double)h / steps,
+           (double)wsum / nw * 10.0 / steps, (double)wmax * 10.0 / steps, ms * 1e6 / steps, rays * steps / (ms * 1e-3) / 1e9, o[0]);
+    (void)hipFree(out); (void)hipFree(cyc); (void)hipFree(wall);
 }
 
 int main() {
     float a[16], b[16];
     run<0>("scalar: one ray per lane", 1, 64, a); run<1>("quad: x, y, z on three lanes", 1, 64, b);
     int same = 0; for (int r = 0; r < 16; r++) same += __builtin_bit_cast(unsigned, a[r]) == __builtin_bit_cast(unsigned, b[r]);
-    printf("rays 0..15 after 300 steps: %d of 16 bit-identical between the two layouts\n", same);
-    run<0>("scalar: one ray per lane", 1024, 64, a); run<1>("quad: x, y, z on three lanes", 1024, 64, b);     // one wave per SIMD, the whole chip
-    run<0>("scalar: one ray per lane", 1024, 256, a); run<1>("quad: x, y, z on three lanes", 1024, 256, b);   // four waves per SIMD
+    printf("rays 0..15 after the steps: %d of 16 bit-identical between the two layouts\n", same);
+    // the whole chip (256 CUs), 1 / 2 / 3 / 4 waves per SIMD: blocks of 256 threads, one / two / three / four blocks per CU
+    for (int bpc = 1; bpc <= 4; bpc++) { run<0>("scalar: one ray per lane", 256 * bpc, 256, a); run<1>("quad: x, y, z on three lanes", 256 * bpc, 256, b); }
     return 0;
 }

