@@ -43,7 +43,8 @@ enum {
     BHRAY_E_BVH_DEPTH   = -6,  /* BVH deeper than BHRAY_BVH_STACK levels                     */
     BHRAY_E_IO          = -7,  /* file could not be read / parsed (OBJ loader)               */
     BHRAY_E_CAPACITY    = -8,  /* model exceeds the reference's fixed capacities             */
-    BHRAY_E_COMM        = -9   /* RCCL could not be loaded / a collective call failed        */
+    BHRAY_E_COMM        = -9   /* RCCL could not be loaded / a collective call failed / the gather did not complete within
+                                      BHRAY_COMM_TIMEOUT_MS (watchdog, below): the ctx is failed, destroy it                    */
 };
 
 /* ------------------------------------------------------------------------------------------
@@ -209,6 +210,15 @@ enum {                                  /* bhray_config.flags */
  * launch.  Frames of a batch may have different uniforms; pixels are identical to B = 1.  For throughput rendering of
  * small per-GPU frames (row-tiled multi-GPU, offline sequences); an interactive host keeps B = 1.  A consumer that
  * orders its own work after a frame through bhray_next_stream must call bhray_flush before enqueueing that work.
+ *
+ * Watchdog (a ctx that gathers: device_count >= 2 or gather = BHRAY_GATHER_RCCL).  A peer that never posts its share of a batch's
+ * RCCL group would make ncclGroupEnd or the communication stream - and with it bhray_sync and every read - wait for ever.  Every call
+ * of the ABI on such a ctx, and every frame one of its issue threads enqueues, therefore carries a deadline of BHRAY_COMM_TIMEOUT_MS
+ * milliseconds (environment, read by bhray_create; default 30000, 0 = no watchdog).  When a call is overdue a thread of the ctx aborts
+ * its communicators (ncclCommAbort: RCCL's blocked host calls return, its kernels leave their spin loops), writes one line to stderr
+ * and fails the ctx: the overdue call and every later one return BHRAY_E_COMM with the watchdog's message in bhray_last_error;
+ * bhray_destroy still works.  Pick the deadline above the longest single call the host makes (a bhray_sync behind hundreds of staged
+ * 8K frames is seconds).  Not covered: ncclCommInitRank / ncclCommInitAll inside bhray_create (no communicator to abort yet).
  *
  * Row partition (multi-GPU row tiling).  partition = BHRAY_PARTITION_STRIPES (default): frame row r belongs to partition
  * (r / stripe_rows) % row_world - interleaved stripes, balanced whatever the scene, at the price of coarse ladder rows that

@@ -1,0 +1,113 @@
+"""-m gpu: a gather that never completes, or an issue thread that fails mid-block, surfaces as an error - it does not hang.
+
+The gather has only ever run between partitions of one device, so the first run on real links may meet a peer that never posts.  libbhray
+arms every call of a gathering ctx with a deadline (BHRAY_COMM_TIMEOUT_MS, default 30 s); a watchdog thread aborts the communicator when a
+call is overdue and the ctx answers BHRAY_E_COMM with the watchdog's message from then on.  Here, on one GPU (8 partitions on device 0,
+tiles as RCCL send/recv-to-self), the never-matched receive is played by BHRAY_TEST_FAULT=stall_gather:n - the n-th gather enqueues a
+kernel in front of its RCCL group that spins on the communication stream until the watchdog raises the device-visible abort word (or
+20 s pass: never a hung GPU).  Each scenario runs in a process of its own with a hard timeout: a hang is a failed test, not a hung suite.
+"""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+PRELUDE = """
+import sys, time
+sys.path.insert(0, %r)
+import numpy as np
+import bhusie_amd as B
+from bhusie_amd.layouts import BhrayError
+from tests import common as T
+E_COMM = -9
+cfg = B.ladder_for_frame((200, 110), 3, 3)
+u = T.uniforms(integration_method=1)
+def ctx(**kw):
+    rp = B.RayPass(cfg, devices=[0] * 8, frames_in_flight=2, **kw)
+    rp.set_textures(*T.textures()); rp.set_uniforms(*u)
+    return rp
+""" % ROOT
+
+
+def _run(body, env, timeout=180):
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, "-c", PRELUDE + textwrap.dedent(body)], capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=e)
+    assert r.returncode == 0, "stdout:\n" + r.stdout[-3000:] + "\nstderr:\n" + r.stderr[-3000:]
+    return r
+
+
+def test_error_code_of_the_python_layer_is_the_headers():
+    import re
+    h = open(os.path.join(ROOT, "include", "bhray.h")).read()
+    assert re.search(r"BHRAY_E_COMM\s*=\s*-9\b", h), "tests/test_gpu_comm_watchdog.py assumes BHRAY_E_COMM = -9"
+
+
+@pytest.mark.parametrize("threads", ["1", "0"])
+def test_a_gather_that_never_completes_times_out_with_a_message(threads):
+    r = _run("""
+        rp = ctx()
+        rp.render(); rp.sync()                          # gather 1: fine
+        want = rp.read_hdr().copy()
+        t0 = time.perf_counter()
+        try:
+            rp.render(); rp.sync()                      # gather 2 stalls on the communication stream
+            raise SystemExit("the stalled gather was not reported")
+        except BhrayError as e:
+            dt = time.perf_counter() - t0
+            assert e.code == E_COMM, e
+            assert "watchdog" in str(e) and "BHRAY_COMM_TIMEOUT_MS = 1500" in str(e), str(e)
+            assert 1.0 < dt < 15.0, dt                  # the deadline, not the stall kernel's own 20 s limit
+        for call in (rp.render, rp.sync, rp.read_hdr, rp.flush):     # the ctx stays failed: every later call says why
+            try:
+                call(); raise SystemExit(call.__name__ + " on the failed ctx was not refused")
+            except BhrayError as e:
+                assert e.code == E_COMM and "watchdog" in str(e), str(e)
+        t0 = time.perf_counter(); rp.close(); assert time.perf_counter() - t0 < 30.0    # teardown without ncclCommDestroy on the aborted communicator
+        # the process is fine: a new ctx with a new communicator renders the same frame
+        import os
+        os.environ.pop("BHRAY_TEST_FAULT")
+        rp = ctx(); rp.render(); rp.sync()
+        assert np.array_equal(rp.read_hdr().view(np.uint32), want.view(np.uint32))
+        rp.close()
+        print("ok")
+    """, {"BHRAY_TEST_FAULT": "stall_gather:2", "BHRAY_COMM_TIMEOUT_MS": "1500", "BHRAY_ISSUE_THREADS": threads})
+    assert "ok" in r.stdout and "bhray: watchdog:" in r.stderr
+
+
+def test_an_issue_thread_that_fails_mid_block_is_reported_by_the_next_call_and_the_ctx_tears_down():
+    r = _run("""
+        rp = ctx()
+        for _ in range(2): rp.render()
+        rp.sync()
+        try:
+            for _ in range(6): rp.render()              # frame 5 fails on the issue thread (frames 1-2 above)
+            rp.sync()
+            raise SystemExit("the failed frame was not reported")
+        except BhrayError as e:
+            assert "BHRAY_TEST_FAULT" in str(e) and "issue thread" in str(e), str(e)
+        try:
+            rp.render(); rp.sync(); raise SystemExit("a failed ctx rendered")
+        except BhrayError:
+            pass
+        t0 = time.perf_counter(); rp.close(); assert time.perf_counter() - t0 < 30.0
+        print("ok")
+    """, {"BHRAY_TEST_FAULT": "fail_render:5", "BHRAY_COMM_TIMEOUT_MS": "5000"})
+    assert "ok" in r.stdout
+
+
+def test_the_watchdog_leaves_a_healthy_ctx_alone():
+    r = _run("""
+        rp = ctx()
+        for _ in range(40): rp.render()
+        rp.sync()
+        time.sleep(0.7)                                  # idle longer than the deadline: nothing is armed between calls
+        for _ in range(40): rp.render()
+        rp.sync(); rp.read_hdr(); rp.close()
+        print("ok")
+    """, {"BHRAY_COMM_TIMEOUT_MS": "500"})
+    assert "ok" in r.stdout and "watchdog" not in r.stderr

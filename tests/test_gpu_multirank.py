@@ -45,3 +45,20 @@ def test_bench_under_torchrun_single_process_model():
            "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--process-model", "single", "--devices", "0,0"] + COMMON
     d = _line(subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT))
     assert d["n_gpus"] == 2 and d["config"]["verified_frames"] == 1
+
+
+def test_a_gather_that_fails_in_the_warm_up_falls_back_to_stripes_and_still_reports():
+    """a red collective must not cost the N > 1 run its number (nor hang it).  BENCH_TEST_GATHER_FAILS=1 makes the first block of the
+    first ctx (balanced slabs, bhray_rebalance) raise BHRAY_E_COMM; every rank learns it, the ctx is dropped, interleaved stripes take over, the
+    gathered frame is still verified and the line says where `value` comes from."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--devices", "0,0,0,0"] + COMMON
+    d = _line(subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, BENCH_TEST_GATHER_FAILS="1")))
+    assert d["config"]["verified_frames"] == 1
+    assert "stripes" in d["config"]["partition"]["mode"] and "balanced slabs" in d["config"]["partition"]["fallback_from"]
+    assert len(d["gather"]["fallbacks"]) == 1 and "BENCH_TEST_GATHER_FAILS" in d["gather"]["fallbacks"][0]
+
+
+def test_a_gather_that_keeps_failing_ends_the_run_quickly_with_a_message():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--devices", "0,0,0,0"] + COMMON
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, BENCH_TEST_GATHER_FAILS="9"))
+    assert r.returncode == 5 and "no gather configuration left" in r.stderr and r.stdout.strip() == "", (r.returncode, r.stderr[-800:])
