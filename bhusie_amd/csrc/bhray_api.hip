@@ -1215,7 +1215,10 @@ int launch_batch(bhray_dev* c) {
         // the quad march (bhray_quad.inc) for launches whose queue turns out short: how many waves per SIMD it may use (bits 2-4; 0 = off)
         // Measured (profiles/EXPERIMENTS.md R6.1): one wave per SIMD -21 % per launch (RK, a level-0-sized queue), two -10 %, three +10 %: a second wave on a
         // SIMD slows both, and from the third on a scalar wave with four times the rays is faster.  The Euler step has too little 3-vector work to gain at two.
-        const int quad_wps = c->quad_wps >= 0 ? c->quad_wps : (S.method == 0 ? 1 : 2);
+        // Only for a host that renders one frame at a time (one frame per launch, at most two frame slots): beside other frames' waves on the same SIMDs
+        // the quad march's shorter iteration is gone and its four lanes per ray cost throughput - a rank of an 8-way partition, batches of 5 frames: +3.5 %
+        // per frame in the driver's blocks against -11-14 % one frame at a time (R6.1).  BHRAY_QUAD=n forces it for every latency-build launch.
+        const int quad_wps = c->quad_wps >= 0 ? c->quad_wps : ((nb == 1 && c->slots.size() <= 2) ? (S.method == 0 ? 1 : 2) : 0);
         for (uint32_t k = 0; k < nb; k++) hl[k].probe_empty |= (quad_wps & 7) << 2;
     }
     S.launched_frames = nb;

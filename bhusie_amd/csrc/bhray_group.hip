@@ -1512,6 +1512,7 @@ int bhray_render(bhray_ctx* c) {
         c->rendered = true;
         return BHRAY_OK;
     }
+    if (c->watch_fired.load(std::memory_order_acquire)) return gfail(c, BHRAY_E_COMM, "bhray_render refused");
     if (c->threaded) {
         // record the frame and hand it to the issue threads ("Issue threads" above); nothing here touches an engine or a GPU
         if (c->async_failed.load(std::memory_order_acquire)) return drain(c);
@@ -1550,7 +1551,6 @@ int bhray_render(bhray_ctx* c) {
     }
     // staged frames of another kernel variant are launched (and gathered) first: the staging position is then final
     WatchScope watch_scope_(c, "bhray_render");
-    if (c->watch_fired.load(std::memory_order_acquire)) return gfail(c, BHRAY_E_COMM, "bhray_render refused");
     int si = -1; uint32_t sub = 0;
     for (Part& p : c->parts) {
         if (!p.dev) continue;

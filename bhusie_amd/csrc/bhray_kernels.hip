@@ -875,6 +875,9 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #ifndef BHRAY_REL_BATCH
 #define BHRAY_REL_BATCH 16       // integrator steps between refill / flat / epilogue phases
 #endif
+#ifndef BHRAY_REL_BATCH_EULER_DENSE
+#define BHRAY_REL_BATCH_EULER_DENSE BHRAY_REL_BATCH   // ... of the dense Euler kernel (its step is less than half the RK step's instructions: the phases between batches weigh more)
+#endif
 #ifndef BHRAY_FLAT_MIN_LANES
 #define BHRAY_FLAT_MIN_LANES 48    // mesh variant: run the flat/BVH phase when this many lanes wait for it ...
 #endif
@@ -904,6 +907,9 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #ifndef BHRAY_REFILL_MIN
 #define BHRAY_REFILL_MIN 16      // refill from the queue (one atomic on its head + a dependent load) only when this many lanes are empty, or nobody is
                                  // stepping: measured 1 / 8 / 16 / 24 / 32 / 48 -> 5 357 / 5 428 / 5 435 / 5 414 / 5 387 / 5 254 Mrays/s (Euler 8 009 -> 8 148 at 16)
+#endif
+#ifndef BHRAY_REFILL_MIN_EULER_DENSE
+#define BHRAY_REFILL_MIN_EULER_DENSE BHRAY_REFILL_MIN
 #endif
 #ifndef BHRAY_MESH_COLD_LDS
 #define BHRAY_MESH_COLD_LDS 0    // mesh variant: the cold per-lane state in LDS as in the dense build
@@ -961,6 +967,8 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
 #ifndef BHRAY_NO_SPAN
     if (Fb[0].span && threadIdx.x == 0) atomicMax(&Fb[0].span[0], ~(unsigned long long)wall_clock64());
 #endif
+    constexpr int REL_BATCH = (METHOD == 0 && DENSE && !MODELS) ? BHRAY_REL_BATCH_EULER_DENSE : BHRAY_REL_BATCH;
+    constexpr int REFILL_MIN = (METHOD == 0 && DENSE && !MODELS) ? BHRAY_REFILL_MIN_EULER_DENSE : BHRAY_REFILL_MIN;
     constexpr bool COLD_LDS = (DENSE && !MODELS) || (MODELS && BHRAY_MESH_COLD_LDS != 0);
     constexpr bool MESH_DENSE = MODELS && DENSE;                                              // the mesh variant's build for a saturated device
     constexpr bool MESH_PARK = MESH_DENSE && !COLD_LDS;   // its traversal in a region of its own (see the flat phase)
@@ -1087,7 +1095,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
         // ---- refill finished lanes from the queue (wave ballot + prefix popcount)
         {
             const unsigned long long need = __ballot(mode == M_EMPTY);
-            if (need != 0ull && !exhausted && (BHRAY_REFILL_MIN <= 1 || __popcll(need) >= BHRAY_REFILL_MIN || !__any(mode == M_REL))) {
+            if (need != 0ull && !exhausted && (REFILL_MIN <= 1 || __popcll(need) >= REFILL_MIN || !__any(mode == M_REL))) {
                 uint32_t n = (uint32_t)__popcll(need);
                 uint32_t base = 0;
                 if (!DENSE && thin_share != 0u) {                 // this wave's share, once (all lanes are empty: n == 64 > share)
@@ -1342,8 +1350,8 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
         }
 
         // ---- a batch of integrator steps (ray.wgsl:522-553) for lanes inside the sphere
-        if (__any(mode == M_REL)) work_steps += (unsigned)BHRAY_REL_BATCH;
-        for (int k = 0; k < BHRAY_REL_BATCH; k++) {       // (unrolled by 2 / 4 to let prev = curr become renaming: -1 % / 0 %, measured)
+        if (__any(mode == M_REL)) work_steps += (unsigned)REL_BATCH;
+        for (int k = 0; k < REL_BATCH; k++) {       // (unrolled by 2 / 4 to let prev = curr become renaming: -1 % / 0 %, measured)
             if (!__any(mode == M_REL)) break;
             if (COUNT && lane == 0) cnt[10]++;
             if (DENSE || MODELS) {                    // see bhray_step.inc
