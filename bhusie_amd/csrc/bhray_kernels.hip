@@ -911,6 +911,9 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #ifndef BHRAY_REFILL_MIN_EULER_DENSE
 #define BHRAY_REFILL_MIN_EULER_DENSE BHRAY_REFILL_MIN
 #endif
+#ifndef BHRAY_WAVE_PRIO
+#define BHRAY_WAVE_PRIO 0        // 1 (experiment R6.5): latency build - a wave raises its issue priority (s_setprio) while it holds rays predicted to be long (impact parameter near the photon sphere's)
+#endif
 #ifndef BHRAY_MESH_COLD_LDS
 #define BHRAY_MESH_COLD_LDS 0    // mesh variant: the cold per-lane state in LDS as in the dense build
 #endif
@@ -1088,6 +1091,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
 #define HIT_GET() (HIT_IN_LDS ? cold.hit() : (bool)hit)
     bool exhausted = false;
     int flat_round = 0;
+    int urg = 0;                          // BHRAY_WAVE_PRIO: this lane's ray, predicted length class 0..3
     unsigned long long cnt[13];           // [0..9] = bhray_counters' frame counters, [10] wave steps (lane 0), [11] unused (rays adopted by the drain merging of round 2), [12] longest ray
     if (COUNT) { for (int k = 0; k < 13; k++) cnt[k] = 0; }
 
@@ -1140,6 +1144,18 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
                     it = 0; HIT_SET(0);
                     mode = P.relativity0 ? M_REL : M_FLAT;
                     if (COUNT) cnt[3]++;
+                    if (BHRAY_WAVE_PRIO != 0 && !DENSE) {      // scheduling only: plain arithmetic, no pixel depends on it
+                        const F3 cb = cross(qrel, rdir);
+                        const float b2 = dot(cb, cb);          // impact parameter squared (horizon radius 1: the photon sphere's is 27/4)
+                        urg = (b2 > 4.0f && b2 < 12.0f) ? 3 : ((b2 > 2.0f && b2 < 25.0f) ? 2 : (b2 < 60.0f ? 1 : 0));
+                    }
+                }
+                if (BHRAY_WAVE_PRIO != 0 && !DENSE) {
+                    const bool live = mode != M_EMPTY;
+                    if (__any(live && urg == 3)) __builtin_amdgcn_s_setprio(3);
+                    else if (__any(live && urg == 2)) __builtin_amdgcn_s_setprio(2);
+                    else if (__any(live && urg == 1)) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
                 }
             }
             if (!__any(mode != M_EMPTY)) break;
