@@ -118,7 +118,7 @@ struct FrameLaunch {
     int radius;            // predict_kernel: dilation of the previous frame's traced set, in pixels of this level
     const uint32_t* stamp; // this level's stamp image (classify); nullptr outside temporal mode
     uint32_t stamp_value;  // stamp of the current frame
-    int probe_empty;       // trace, bit 0: this launch is expected to find its queue (nearly) used up - look before the first atomic; bit 1: thin shares are dealt strided (a whole frame, one frame per launch)
+    int probe_empty;       // trace, bit 0: this launch is expected to find its queue (nearly) used up - look before the first atomic; bit 1: thin shares are dealt strided (a whole frame, one frame per launch); bits 2-4: waves per SIMD the quad march may use (bhray_quad.inc); bit 5: waves set their issue priority by their rays' predicted length
     int blocks;            // predict (one launch, all levels): this level's own block count
     unsigned long long* span; // trace, entry 0 of a timed launch: [0] max(~first block start) [1] max(last block end), device wall clock; nullptr: untimed
     unsigned long long* work; // trace, entry 0 of a launch: work[blockIdx & (BHRAY_WORK_WORDS - 1)] += integrator steps this wave ISSUED for the frames of the batch

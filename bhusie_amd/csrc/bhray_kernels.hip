@@ -912,7 +912,20 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #define BHRAY_REFILL_MIN_EULER_DENSE BHRAY_REFILL_MIN
 #endif
 #ifndef BHRAY_WAVE_PRIO
-#define BHRAY_WAVE_PRIO 0        // 1 (experiment R6.5): latency build - a wave raises its issue priority (s_setprio) while it holds rays predicted to be long (impact parameter near the photon sphere's)
+#define BHRAY_WAVE_PRIO 1        // bit 0: the latency builds, bit 1: the dense builds - a wave raises its issue priority (s_setprio) while it holds rays predicted to be long: a launch
+                                 // lasts as long as its longest ray, and beside three other waves on its SIMD that ray steps at 1.0 us per iteration instead of 0.72.  One frame at a
+                                 // time: RK -3.3 % (S = 2) / -10 % (S = 3: 1.08 -> 0.97 ms), Euler -2 %; the dense builds at saturation LOSE 3.5 % (the arbiter serves the preferred
+                                 // wave's dependent chain where another wave had an instruction ready), so bit 1 stays off and the host enables bit 0's launches (FrameLaunch::probe_empty
+                                 // bit 5: one frame per launch, at most two frame slots).  profiles/EXPERIMENTS.md R6.5
+#endif
+// predicted length class of a ray from its impact parameter b (b^2 = |(cam - hole) x dir|^2, horizon radius 1: the photon sphere's critical value is 27/4; rays just outside it wind
+// round the hole and are the longest of a frame, rays far outside cross the sphere on a chord): class 3 for BHRAY_PRIO_3_LO < b^2 < BHRAY_PRIO_3_HI, 2 / 1 for the wider bands
+#ifndef BHRAY_PRIO_3_LO
+#define BHRAY_PRIO_3_LO 5.0f     // (bands measured: (4, 12) / (2, 25) / 60, (5, 9) / (3, 16) / 40 - shipped -, (4, 12) / (1, 30) / 100, (6, 8) / (4, 12) / 25, (0, 16) / (0, 36) / 80: within 1.5 % of each other)
+#define BHRAY_PRIO_3_HI 9.0f
+#define BHRAY_PRIO_2_LO 3.0f
+#define BHRAY_PRIO_2_HI 16.0f
+#define BHRAY_PRIO_1_HI 40.0f
 #endif
 #ifndef BHRAY_MESH_COLD_LDS
 #define BHRAY_MESH_COLD_LDS 0    // mesh variant: the cold per-lane state in LDS as in the dense build
@@ -940,6 +953,9 @@ template <> struct ColdState<false> {
     __device__ __forceinline__ void set_pend_t(float v) { pend_t_ = v; }
     __device__ __forceinline__ bool hit() const { return false; }
     __device__ __forceinline__ void set_hit(bool) {}
+    int urg_ = 0;
+    __device__ __forceinline__ int urg() const { return urg_; }
+    __device__ __forceinline__ void set_urg(int v) { urg_ = v; }
 };
 template <> struct ColdState<true> {
     float* b;                                                                     // this lane's column: plane k at b[S * k]
@@ -955,6 +971,8 @@ template <> struct ColdState<true> {
     __device__ __forceinline__ void set_pend_t(float v) { b[7 * S] = v; }
     __device__ __forceinline__ bool hit() const { return b[8 * S] != 0.0f; }                      // (BHRAY_HIT_LDS)
     __device__ __forceinline__ void set_hit(bool v) { b[8 * S] = v ? 1.0f : 0.0f; }
+    __device__ __forceinline__ int urg() const { return __float_as_int(b[(8 + BHRAY_HIT_LDS) * S]); }      // (BHRAY_WAVE_PRIO)
+    __device__ __forceinline__ void set_urg(int v) { b[(8 + BHRAY_HIT_LDS) * S] = __int_as_float(v); }
 };
 
 #include "bhray_quad.inc"
@@ -977,7 +995,8 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
     constexpr bool MESH_PARK = MESH_DENSE && !COLD_LDS;   // its traversal in a region of its own (see the flat phase)
     constexpr bool FLAT_COLD = MESH_DENSE;                // ... the flat phase marked unlikely
     constexpr bool BVH_WW = MESH_DENSE;                   // ... and the while-while traversal
-    __shared__ float cold_lds[COLD_LDS ? (8 + BHRAY_HIT_LDS) * BHRAY_TRACE_THREADS : 1];
+    constexpr bool WAVE_PRIO = ((BHRAY_WAVE_PRIO & 1) != 0 && !DENSE && !MODELS) || ((BHRAY_WAVE_PRIO & 2) != 0 && DENSE);   // (the mesh variant's lone launches wait for their traversals: nothing, measured)
+    __shared__ float cold_lds[COLD_LDS ? (8 + BHRAY_HIT_LDS + (WAVE_PRIO ? 1 : 0)) * BHRAY_TRACE_THREADS : 1];
     // Integrator steps this wave issues for the frames of the batch -> Fb[0].work at the kernel's end.  Wave-uniform: a scalar register.
     // Counted in whole batches of steps, where the step loop is entered (a batch cut short by its last ray counts in full), and for the
     // whole launch rather than per frame: the count of a batch's steps kept live across the loop cost the Euler kernel 1-2 %, a flush
@@ -1091,7 +1110,6 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
 #define HIT_GET() (HIT_IN_LDS ? cold.hit() : (bool)hit)
     bool exhausted = false;
     int flat_round = 0;
-    int urg = 0;                          // BHRAY_WAVE_PRIO: this lane's ray, predicted length class 0..3
     unsigned long long cnt[13];           // [0..9] = bhray_counters' frame counters, [10] wave steps (lane 0), [11] unused (rays adopted by the drain merging of round 2), [12] longest ray
     if (COUNT) { for (int k = 0; k < 13; k++) cnt[k] = 0; }
 
@@ -1144,17 +1162,17 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
                     it = 0; HIT_SET(0);
                     mode = P.relativity0 ? M_REL : M_FLAT;
                     if (COUNT) cnt[3]++;
-                    if (BHRAY_WAVE_PRIO != 0 && !DENSE) {      // scheduling only: plain arithmetic, no pixel depends on it
+                    if (WAVE_PRIO && (F.probe_empty & 32)) {   // scheduling only: plain arithmetic, no pixel depends on it
                         const F3 cb = cross(qrel, rdir);
-                        const float b2 = dot(cb, cb);          // impact parameter squared (horizon radius 1: the photon sphere's is 27/4)
-                        urg = (b2 > 4.0f && b2 < 12.0f) ? 3 : ((b2 > 2.0f && b2 < 25.0f) ? 2 : (b2 < 60.0f ? 1 : 0));
+                        const float b2 = dot(cb, cb);
+                        cold.set_urg((b2 > BHRAY_PRIO_3_LO && b2 < BHRAY_PRIO_3_HI) ? 3 : ((b2 > BHRAY_PRIO_2_LO && b2 < BHRAY_PRIO_2_HI) ? 2 : (b2 < BHRAY_PRIO_1_HI ? 1 : 0)));
                     }
                 }
-                if (BHRAY_WAVE_PRIO != 0 && !DENSE) {
-                    const bool live = mode != M_EMPTY;
-                    if (__any(live && urg == 3)) __builtin_amdgcn_s_setprio(3);
-                    else if (__any(live && urg == 2)) __builtin_amdgcn_s_setprio(2);
-                    else if (__any(live && urg == 1)) __builtin_amdgcn_s_setprio(1);
+                if (WAVE_PRIO && (F.probe_empty & 32)) {       // the wave's priority: its longest ray's class (until the next refill)
+                    const int u = mode != M_EMPTY ? cold.urg() : -1;
+                    if (__any(u == 3)) __builtin_amdgcn_s_setprio(3);
+                    else if (__any(u == 2)) __builtin_amdgcn_s_setprio(2);
+                    else if (__any(u == 1)) __builtin_amdgcn_s_setprio(1);
                     else __builtin_amdgcn_s_setprio(0);
                 }
             }

@@ -1,5 +1,5 @@
 """One frame at a time, library A against library B (BHRAY_LIB of two builds of the same sources), alternating, in one process each: wall time per frame
-and trace time per level for the bench scenes and ladder modes; every frame of B compared byte for byte with A's.  usage: r6_lat_ab.py libA libB [rounds]"""
+and trace time per level for the bench scenes and ladder modes; every frame of B compared byte for byte with A's.  usage: r6_lat_ab.py [--quick] libA libB ... [rounds]"""
 import os, sys, subprocess, json
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CHILD = r'''
@@ -27,7 +27,9 @@ for wl, integ, size, spec, temporal in (("disk", "rk", (1920, 1080), 2, False), 
     rp.close()
 print(json.dumps(out))
 ''' % ROOT
-libs = sys.argv[1:3]; rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+args_ = [a for a in sys.argv[1:] if not a.startswith("--")]
+libs = [a for a in args_ if a.endswith(".so")]; rounds = int(args_[-1]) if not args_[-1].endswith(".so") else 2
+if "--quick" in sys.argv: CHILD = CHILD.replace(', ("disk", "rk", (1920, 1080), 0, True), ("mesh", "rk", (1920, 1080), 2, False), ("disk", "rk", (3840, 2160), 2, False)', "")
 res = {l: [] for l in libs}
 for r in range(rounds):
     for l in libs:
