@@ -154,7 +154,7 @@ struct bhray_dev {
                                            // radius of 1-2 adds 2-4 % rays and does not shorten a moving camera's frames - the misses are scattered interpolate/trace flips)
     int bpc_override = 0;                  // BHRAY_TRACE_BLOCKS_PER_CU (tuning experiments only)
     int grid_override = 0;                 // BHRAY_TRACE_GRID: absolute number of persistent trace blocks (tuning experiments only)
-    int wave_prio = -1;                    // BHRAY_PRIO=0/1 forces wave priority off / on for every latency-build launch; -1 = one frame per launch and at most two frame slots
+    int wave_prio = -1;                    // BHRAY_PRIO=0/1 forces wave priority off / on for every latency-build launch; -1 = one frame per launch and ONE frame slot
     int quad_wps = -1;                     // BHRAY_QUAD: waves per SIMD the quad march may use for a short queue (bhray_quad.inc); 0 = the scalar thin shares only; -1 = the measured default (RK 2, Euler 1)
     int dense_override = -1;               // BHRAY_TRACE_DENSE=0/1 (tuning experiments only)
     int coarse_build = -1;                 // BHRAY_COARSE_BUILD=0/1 (experiment): the build of the trace launches below the ladder's last level (-1: the batch's build)
@@ -1220,8 +1220,9 @@ int launch_batch(bhray_dev* c) {
         // Only for a host that renders one frame at a time (one frame per launch, at most two frame slots): beside other frames' waves on the same SIMDs
         // the quad march's shorter iteration is gone and its four lanes per ray cost throughput - a rank of an 8-way partition, batches of 5 frames: +3.5 %
         // per frame in the driver's blocks against -11-14 % one frame at a time (R6.1).  BHRAY_QUAD=n forces it for every latency-build launch.
-        // ... and wave priority by predicted ray length (bit 5; BHRAY_WAVE_PRIO in bhray_kernels.hip) for the same hosts: it shortens a launch, and costs a saturated device 3.5 %
-        if (c->wave_prio >= 0 ? c->wave_prio != 0 : (nb == 1 && c->slots.size() <= 2)) for (uint32_t k = 0; k < nb; k++) hl[k].probe_empty |= 32;
+        // ... and wave priority by predicted ray length (bit 5; BHRAY_WAVE_PRIO in bhray_kernels.hip) for a host with ONE frame slot: it shortens a lone frame's launches (S = 2 1.16 -> 1.13 ms,
+        // S = 3 0.97 -> 0.95), but as soon as two frames overlap it costs - the drop-in shim with two frames in flight 0.816 -> 0.873 ms per frame, a saturated device 3.5 % (EXPERIMENTS.md R6.5)
+        if (c->wave_prio >= 0 ? c->wave_prio != 0 : (nb == 1 && c->slots.size() <= 1)) for (uint32_t k = 0; k < nb; k++) hl[k].probe_empty |= 32;
         const int quad_wps = c->quad_wps >= 0 ? c->quad_wps : ((nb == 1 && c->slots.size() <= 2) ? (S.method == 0 ? 1 : 2) : 0);
         for (uint32_t k = 0; k < nb; k++) hl[k].probe_empty |= (quad_wps & 7) << 2;
     }

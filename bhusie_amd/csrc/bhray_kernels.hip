@@ -914,9 +914,9 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #ifndef BHRAY_WAVE_PRIO
 #define BHRAY_WAVE_PRIO 1        // bit 0: the latency builds, bit 1: the dense builds - a wave raises its issue priority (s_setprio) while it holds rays predicted to be long: a launch
                                  // lasts as long as its longest ray, and beside three other waves on its SIMD that ray steps at 1.0 us per iteration instead of 0.72.  One frame at a
-                                 // time: RK -3.3 % (S = 2) / -10 % (S = 3: 1.08 -> 0.97 ms), Euler -2 %; the dense builds at saturation LOSE 3.5 % (the arbiter serves the preferred
-                                 // wave's dependent chain where another wave had an instruction ready), so bit 1 stays off and the host enables bit 0's launches (FrameLaunch::probe_empty
-                                 // bit 5: one frame per launch, at most two frame slots).  profiles/EXPERIMENTS.md R6.5
+                                 // time: RK -3 % (S = 2: 1.16 -> 1.13 ms) / -2 % (S = 3: 0.97 -> 0.95; -10 % with timing events in the stream), Euler -2 %; the dense builds at saturation LOSE 3.5 % (the arbiter serves the preferred
+                                 // wave's dependent chain where another wave had an instruction ready), and so does the drop-in shim with two frames in flight (+7 %): bit 1 stays off and the
+                                 // host enables bit 0's launches (FrameLaunch::probe_empty bit 5) for a ctx with ONE frame slot only.  profiles/EXPERIMENTS.md R6.5
 #endif
 // predicted length class of a ray from its impact parameter b (b^2 = |(cam - hole) x dir|^2, horizon radius 1: the photon sphere's critical value is 27/4; rays just outside it wind
 // round the hole and are the longest of a frame, rays far outside cross the sphere on a chord): class 3 for BHRAY_PRIO_3_LO < b^2 < BHRAY_PRIO_3_HI, 2 / 1 for the wider bands
@@ -926,6 +926,9 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #define BHRAY_PRIO_2_LO 3.0f
 #define BHRAY_PRIO_2_HI 16.0f
 #define BHRAY_PRIO_1_HI 40.0f
+#endif
+#ifndef BHRAY_FLAT_PRIO
+#define BHRAY_FLAT_PRIO 0
 #endif
 #ifndef BHRAY_MESH_COLD_LDS
 #define BHRAY_MESH_COLD_LDS 0    // mesh variant: the cold per-lane state in LDS as in the dense build
@@ -1260,6 +1263,9 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
         }
         // (FLAT_COLD: the flat phase marked unlikely, so that the register allocator weighs the step loop above the traversal's loops)
         const bool flat_now = run_flat && __any(mode == M_FLAT);
+#if BHRAY_FLAT_PRIO
+        if (MODELS && !DENSE && flat_now && (F.probe_empty & 32)) __builtin_amdgcn_s_setprio(3);      // (experiment R6.6: a wave in its traversal phase outranks the marching waves of its SIMD)
+#endif
         if (FLAT_COLD ? __builtin_expect(flat_now, 0) : flat_now) {
             if (mode == M_FLAT) {
                 if (it >= H.max_iter) {
@@ -1328,6 +1334,9 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
             }
         }
 
+#if BHRAY_FLAT_PRIO
+        if (MODELS && !DENSE && flat_now && (F.probe_empty & 32)) __builtin_amdgcn_s_setprio(0);
+#endif
         // ---- epilogue (ray.wgsl:583-595) for lanes whose loop ended
         if (__any(mode == M_FINISH)) {
             if (mode == M_FINISH) {
