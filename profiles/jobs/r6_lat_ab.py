@@ -29,6 +29,8 @@ print(json.dumps(out))
 ''' % ROOT
 args_ = [a for a in sys.argv[1:] if not a.startswith("--")]
 libs = [a for a in args_ if a.endswith(".so")]; rounds = int(args_[-1]) if not args_[-1].endswith(".so") else 2
+if "--no-timing" in sys.argv: CHILD = CHILD.replace("timing=True", "timing=False").replace("tm = rp.timing(); n = max(1, tm.frames)", "n = 1").replace("[tm.level_trace_ms[i] / n for i in range(4)]", "[0.0] * 4")
+if "--mesh" in sys.argv: CHILD = CHILD.replace('(("disk", "rk", (1920, 1080), 2, False), ("disk", "rk", (1920, 1080), 3, False), ("disk", "euler", (1920, 1080), 2, False), ("disk", "rk", (1920, 1080), 0, True), ', '(').replace(', ("disk", "rk", (3840, 2160), 2, False)', ', ("mesh", "rk", (1920, 1080), 3, False), ("mesh", "euler", (1920, 1080), 2, False)')
 if "--quick" in sys.argv: CHILD = CHILD.replace(', ("disk", "rk", (1920, 1080), 0, True), ("mesh", "rk", (1920, 1080), 2, False), ("disk", "rk", (3840, 2160), 2, False)', "")
 res = {l: [] for l in libs}
 for r in range(rounds):
