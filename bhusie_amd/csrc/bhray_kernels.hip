@@ -927,9 +927,6 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #define BHRAY_PRIO_2_HI 16.0f
 #define BHRAY_PRIO_1_HI 40.0f
 #endif
-#ifndef BHRAY_FLAT_PRIO
-#define BHRAY_FLAT_PRIO 0
-#endif
 #ifndef BHRAY_MESH_COLD_LDS
 #define BHRAY_MESH_COLD_LDS 0    // mesh variant: the cold per-lane state in LDS as in the dense build
 #endif
@@ -1263,9 +1260,6 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
         }
         // (FLAT_COLD: the flat phase marked unlikely, so that the register allocator weighs the step loop above the traversal's loops)
         const bool flat_now = run_flat && __any(mode == M_FLAT);
-#if BHRAY_FLAT_PRIO
-        if (MODELS && !DENSE && flat_now && (F.probe_empty & 32)) __builtin_amdgcn_s_setprio(3);      // (experiment R6.6: a wave in its traversal phase outranks the marching waves of its SIMD)
-#endif
         if (FLAT_COLD ? __builtin_expect(flat_now, 0) : flat_now) {
             if (mode == M_FLAT) {
                 if (it >= H.max_iter) {
@@ -1334,9 +1328,6 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
             }
         }
 
-#if BHRAY_FLAT_PRIO
-        if (MODELS && !DENSE && flat_now && (F.probe_empty & 32)) __builtin_amdgcn_s_setprio(0);
-#endif
         // ---- epilogue (ray.wgsl:583-595) for lanes whose loop ended
         if (__any(mode == M_FINISH)) {
             if (mode == M_FINISH) {
