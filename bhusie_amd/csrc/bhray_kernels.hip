@@ -300,11 +300,7 @@ __device__ __forceinline__ bool hit_triangle(F3 pos, F3 dir, float t_min, float 
                                              // the calling convention saved 360 bytes per lane around EVERY call: 43 MB of scratch writes per 1080p launch.  Inline at 6 or 8
                                              // waves the spills move into the step loop (2 819 / 1 610 Mrays/s, R3.6).  profiles/EXPERIMENTS.md R4.3
 #endif
-#ifndef BHRAY_BVH_LDS_TOP
-#define BHRAY_BVH_LDS_TOP 0        // float4 words of the TOP of the tree (breadth-first order: the root, then its children pair by pair) each wave stages in LDS once per frame: 128 = the first 5 levels
-                                   // (31 child pairs, 2 KB per wave); a visit of a node in that range reads its child pair from LDS instead of from memory.  0 = off.  profiles/EXPERIMENTS.md R6.8
-#endif
-struct BvhLds { int2* stack; const float4* top; int top_nodes; };     // stack: this lane's column (entry k at stack[k * BHRAY_TRACE_THREADS]); top: this wave's staged node tile, valid for child pairs with left index < top_nodes
+struct BvhLds { int2* stack; };     // stack: this lane's column (entry k at stack[k * BHRAY_TRACE_THREADS])
 
 // The traversal stack.  The reference stacks 19 whole nodes and has no overflow check (ray.wgsl:292,327); round 2 kept 64 two-word entries
 // per lane in scratch - 512 bytes per lane, 42 MB of scratch writes per 1080p launch.  Now: a SHORT stack of BHRAY_BVH_LDS_STACK entries
@@ -354,14 +350,8 @@ __device__ BHRAY_MODEL_INLINE void trace_ray_model(const ModelDev& M, const BvhL
     while (alive) {
         while (alive && obj_count == 0) {
             if (lev >= BHRAY_BVH_STACK) { *err = BHRAY_E_BVH_DEPTH; alive = false; break; }
-            float4 a_lo, a_hi, b_lo, b_hi;
-            if (BHRAY_BVH_LDS_TOP > 0 && contents < lds.top_nodes) {     // a child pair of the staged top of the tree
-                const float4* pair = lds.top + 2 * contents;
-                a_lo = pair[0]; a_hi = pair[1]; b_lo = pair[2]; b_hi = pair[3];
-            } else {
-                const float4* pair = M.nodes + 2 * (size_t)contents;
-                a_lo = pair[0]; a_hi = pair[1]; b_lo = pair[2]; b_hi = pair[3];
-            }
+            const float4* pair = M.nodes + 2 * (size_t)contents;
+            const float4 a_lo = pair[0], a_hi = pair[1], b_lo = pair[2], b_hi = pair[3];
             float d1 = hit_aabb(pos, inv, a_lo, a_hi, mpos);
             float d2 = hit_aabb(pos, inv, b_lo, b_hi, mpos);
             int2 n1 = make_int2(__float_as_int(a_lo.w), __float_as_int(a_hi.w));
@@ -413,14 +403,8 @@ __device__ BHRAY_MODEL_INLINE void trace_ray_model(const ModelDev& M, const BvhL
         bool pop = false;
         if (obj_count == 0) {
             if (lev >= BHRAY_BVH_STACK) { *err = BHRAY_E_BVH_DEPTH; break; }
-            float4 a_lo, a_hi, b_lo, b_hi;
-            if (BHRAY_BVH_LDS_TOP > 0 && contents < lds.top_nodes) {     // a child pair of the staged top of the tree
-                const float4* pair = lds.top + 2 * contents;
-                a_lo = pair[0]; a_hi = pair[1]; b_lo = pair[2]; b_hi = pair[3];
-            } else {
-                const float4* pair = M.nodes + 2 * (size_t)contents;
-                a_lo = pair[0]; a_hi = pair[1]; b_lo = pair[2]; b_hi = pair[3];
-            }
+            const float4* pair = M.nodes + 2 * (size_t)contents;
+            const float4 a_lo = pair[0], a_hi = pair[1], b_lo = pair[2], b_hi = pair[3];
             float d1 = hit_aabb(pos, inv, a_lo, a_hi, mpos);
             float d2 = hit_aabb(pos, inv, b_lo, b_hi, mpos);
             int2 n1 = make_int2(__float_as_int(a_lo.w), __float_as_int(a_hi.w));
@@ -1023,7 +1007,6 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
     // LDS-limited and gives up the 64-VGPR budget of 8 waves per SIMD: 142-152 VGPRs, 3 waves)
     extern __shared__ float4 bvh_dyn_lds[];
     BvhLds bvh_lds; bvh_lds.stack = reinterpret_cast<int2*>(bvh_dyn_lds) + threadIdx.x;
-    bvh_lds.top = nullptr; bvh_lds.top_nodes = 0;
     // the frames of the batch, starting with this block's own: a block whose frame has run dry helps with the others
     for (int fi = 0; fi < nb; fi++) {
     const int fb = (int)((blockIdx.x + (unsigned)fi) % (unsigned)nb);
@@ -1079,20 +1062,6 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
         if (thin_share != 0u && fi != 0) continue;
     }
     const HotParams H = load_hot<MODELS>(P);
-    if (MODELS && BHRAY_BVH_LDS_TOP > 0) {
-        // LDS-staged node tile: every wave copies the top of the model's tree into its own 2 KB behind the traversal rings (64 lanes x 16 bytes per pass: coalesced 1 KB loads), once per
-        // frame; no block barrier - a wave only ever reads what it wrote itself.  The last pair that fits: left child index 2 * contents + 3 < BHRAY_BVH_LDS_TOP.
-        float4* tile = bvh_dyn_lds + (size_t)BHRAY_BVH_LDS_STACK * BHRAY_TRACE_THREADS / 2 + (size_t)(threadIdx.x >> 6) * BHRAY_BVH_LDS_TOP;
-        int staged = 0;
-        if (P.model_count > 0) {
-            const ModelDev& Md = P.models[0];
-            staged = 2 * Md.node_count < BHRAY_BVH_LDS_TOP ? 2 * Md.node_count : BHRAY_BVH_LDS_TOP;
-#pragma unroll
-            for (int k = 0; k < BHRAY_BVH_LDS_TOP; k += 64) { const int i = k + lane; if (i < staged) tile[i] = Md.nodes[i]; }
-        }
-        bvh_lds.top = tile;
-        bvh_lds.top_nodes = (staged - 2) / 2;      // contents < top_nodes  <=>  2 * contents + 3 < staged
-    }
     // The quad march (bhray_quad.inc): a queue that fits 16 rays per wave on the waves the host allows it (bits 2-4 of probe_empty: waves per
     // SIMD; 0 = off) is marched with one ray per QUAD of lanes - x, y, z on three lanes - instead of one per lane: fewer instructions per
     // iteration of the launch's longest ray, the same operations per ray.  Dealt out once like a scalar thin share; whole rounds of one wave per SIMD.
@@ -1634,9 +1603,7 @@ static const void* trace_kernel_ptr(int method, bool models, bool count, bool de
     if (eval == 2) return trace_kernel_ptr_me<1, 2>(models, count, dense);
     return trace_kernel_ptr_me<1, 0>(models, count, dense);
 }
-static size_t trace_dyn_lds(bool models) {      // trace_ray_model's traversal rings + the waves' node tiles
-    return models ? (size_t)BHRAY_BVH_LDS_STACK * BHRAY_TRACE_THREADS * 8 + (size_t)(BHRAY_TRACE_THREADS / 64) * BHRAY_BVH_LDS_TOP * 16 : 0;
-}
+static size_t trace_dyn_lds(bool models) { return models ? (size_t)BHRAY_BVH_LDS_STACK * BHRAY_TRACE_THREADS * 8 : 0; }   // trace_ray_model's traversal ring
 
 hipError_t launch_trace(const FrameParams* Pb, const FrameLaunch* Fb, int nb, int method, bool models, bool count, bool dense, int eval, int* err_flag,
                         int grid_blocks, hipStream_t s) {
