@@ -546,6 +546,22 @@ __device__ __forceinline__ float fdistance_rn(F3 a, F3 b) { const F3 v = a - b; 
 
 __device__ __forceinline__ float pow5(float d) { return ((d * d) * (d * d)) * d; }
 
+// max_(max_(|x|, |y|), |z|) under N5 (compare-select: a < b ? b : a) in three instructions instead of five: t = the IEEE maximum of |y| and |z|
+// (v_max_f32: the operand that is not a NaN, a NaN only when both are), then |x| < t ? t : |x|.  Equal to the compare-select nest for EVERY input:
+// x NaN -> both compares of the nest are false -> |x| (here: the compare is false -> |x|); y or z NaN with x a number -> the nest skips the NaN
+// (so does the maximum); no NaN -> the maximum.  (tests/test_gpu_step_forms.py: all 5^3 combinations of {NaN, +-0, numbers} on the device.)
+__device__ __forceinline__ float max3_abs(float x, float y, float z) {
+    float t; asm("v_max_f32 %0, |%1|, |%2|" : "=v"(t) : "v"(y), "v"(z));
+    const float ax = fabsf(x);
+    return ax < t ? t : ax;
+}
+// cd < closest ? cd : closest in one instruction: v_min_f32(cd, closest) - the IEEE minimum returns the operand that is not a NaN, which is what the select
+// does when cd is a NaN; `closest` never is one (it starts at the sphere's radius and only ever takes numbers); distances carry no negative zero.
+__device__ __forceinline__ float closest_min(float cd, float closest) {
+    float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(cd), "v"(closest));
+    return r;
+}
+
 // f, ray.wgsl:401-403, under N9: f(p) = (p - bh) * s with the per-step scalar s = (-1.5*h2) * (1/dist^5); positions are kept
 // relative to the hole (q = p - bh), so a stage is fma(sum, h, q0) * s.
 // Cash–Karp tableau, ray.wgsl:133-165: untyped consts are evaluated in binary64 and rounded once.
@@ -566,8 +582,9 @@ __device__ constexpr float DB1 = KF(37.0 / 378.0 - 2825.0 / 27648.0),
 // `dist` = flength(pos - bpos), carried from the previous step's exit test (same operands, same value).
 // (A form with the (x, y) components of every 3-vector operation in one packed instruction was built and measured: faster in isolation,
 // slower in this kernel - a packed instruction takes no literal, and the kernel has no SGPRs left for the 25 coefficients: EXPERIMENTS.md R3.13.)
-__device__ __forceinline__ void next_ray_rk(F3 q0, F3& pos, F3& dir, float& h_io, float dist) {
-    const F3 p0 = pos, d0 = dir;           // q0 = p0 - bpos (N9), carried by the caller together with dist = flength(q0)
+// (`_to`: the new position goes to a register set of its own - the unified march of bhray_step_u.inc alternates two, so that "previous = current" is renaming)
+__device__ __forceinline__ void next_ray_rk_to(const F3 q0, const F3 p0, F3& pos, F3& dir, float& h_io, float dist) {
+    const F3 d0 = dir;                     // q0 = p0 - bpos (N9), carried by the caller together with dist = flength(q0)
     const F3 cr = fcross(p0, d0);
     const float h2 = fdot(cr, cr);                   // N3: pow(length(v), 2.0) = dot(v, v)
     const float s = (-1.5f * h2) * rcp_rn(pow5(dist));   // N9
@@ -581,7 +598,7 @@ __device__ __forceinline__ void next_ray_rk(F3 q0, F3& pos, F3& dir, float& h_io
     const F3 K5 = fmadd3(K4, A54, fmadd3(K3, A53, fmadd3(K2, A52, fmadd3(K1, A51, q0)))) * sh;
     const F3 K6 = fmadd3(K5, A65, fmadd3(K4, A64, fmadd3(K3, A63, fmadd3(K2, A62, fmadd3(K1, A61, q0))))) * sh;
     const F3 e = fmadd3(K6, DB6, fmadd3(K5, DB5, fmadd3(K4, DB4, fmadd3(K3, DB3, K1 * DB1))));
-    const float e_max = max_(max_(fabsf(e.x), fabsf(e.y)), fabsf(e.z));
+    const float e_max = max3_abs(e.x, e.y, e.z);
     // the small terms are summed first and added to the unit-length direction once (one rounding at magnitude 1)
     const F3 ds = fmadd3(K6, BA6, fmadd3(K5, BA5, fmadd3(K4, BA4, fmadd3(K3, BA3, K1 * BA1))));
     dir = fnormalize_rn(d0 + ds);
@@ -589,14 +606,22 @@ __device__ __forceinline__ void next_ray_rk(F3 q0, F3& pos, F3& dir, float& h_io
     if (e_max > 0.00002f) h_io = h * (0.9f * pow_m001_step(e_max));
     else h_io = h * 1.0001f;
 }
+__device__ __forceinline__ void next_ray_rk(F3 q0, F3& pos, F3& dir, float& h_io, float dist) {
+    const F3 p0 = pos;
+    next_ray_rk_to(q0, p0, pos, dir, h_io, dist);
+}
 
 // next_ray_euler, ray.wgsl:467-480 (N7, N9).
-__device__ __forceinline__ void next_ray_euler(F3 q0, F3& pos, F3& dir, float step, float dist) {
-    const F3 cr = fcross(pos, dir);
+__device__ __forceinline__ void next_ray_euler_to(const F3 q0, const F3 p0, F3& pos, F3& dir, float step, float dist) {
+    const F3 cr = fcross(p0, dir);
     const float h2 = fdot(cr, cr);                   // N3: pow(length(v), 2.0) = dot(v, v)
     const float s = (-1.5f * h2) * rcp_rn(pow5(dist));
     dir = fnormalize_rn(fmadd3(q0, s * step, dir));   // N9, N10
-    pos = fmadd3(dir, step, pos);
+    pos = fmadd3(dir, step, p0);
+}
+__device__ __forceinline__ void next_ray_euler(F3 q0, F3& pos, F3& dir, float step, float dist) {
+    const F3 p0 = pos;
+    next_ray_euler_to(q0, p0, pos, dir, step, dist);
 }
 
 // The LITERAL reading of the integrator (BHRAY_F_LITERAL, EVAL == 1): ray.wgsl:401-480 operator by operator under N0-N2 — one
@@ -904,6 +929,9 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #ifndef BHRAY_TRACE_WAVES_DENSE
 #define BHRAY_TRACE_WAVES_DENSE 6
 #endif
+#ifndef BHRAY_UNIFIED
+#define BHRAY_UNIFIED 1         // the no-mesh contract kernels march in pairs of steps over two position register sets (bhray_step_u.inc): 16 -> 3 register moves per step
+#endif
 #ifndef BHRAY_REFILL_MIN
 #define BHRAY_REFILL_MIN 16      // refill from the queue (one atomic on its head + a dependent load) only when this many lanes are empty, or nobody is
                                  // stepping: measured 1 / 8 / 16 / 24 / 32 / 48 -> 5 357 / 5 428 / 5 435 / 5 414 / 5 387 / 5 254 Mrays/s (Euler 8 009 -> 8 148 at 16)
@@ -990,6 +1018,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
 #endif
     constexpr int REL_BATCH = (METHOD == 0 && DENSE && !MODELS) ? BHRAY_REL_BATCH_EULER_DENSE : BHRAY_REL_BATCH;
     constexpr int REFILL_MIN = (METHOD == 0 && DENSE && !MODELS) ? BHRAY_REFILL_MIN_EULER_DENSE : BHRAY_REFILL_MIN;
+    constexpr bool UNIFIED = BHRAY_UNIFIED != 0 && EVAL == 0 && !MODELS && !COUNT;           // the unified march (bhray_step_u.inc) in the contract kernels without a mesh
     constexpr bool COLD_LDS = (DENSE && !MODELS) || (MODELS && BHRAY_MESH_COLD_LDS != 0);
     constexpr bool MESH_DENSE = MODELS && DENSE;                                              // the mesh variant's build for a saturated device
     constexpr bool MESH_PARK = MESH_DENSE && !COLD_LDS;   // its traversal in a region of its own (see the flat phase)
@@ -1385,6 +1414,39 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
 
         // ---- a batch of integrator steps (ray.wgsl:522-553) for lanes inside the sphere
         if (__any(mode == M_REL)) work_steps += (unsigned)REL_BATCH;
+        if constexpr (UNIFIED) {
+            // The unified march (bhray_step_u.inc): pairs of steps over two position register sets, the state that only the rare paths and the other
+            // phases read (cpos / cdir / ppos / pdir apart from the integrator's own) written when a lane LEAVES the march, not on every step.
+            // RK: the integrator runs on rkpos / rkdir and the hit test's segment starts at cpos, which differs from rkpos for one step after a
+            // disk hit or a sphere entry moved it (ray.wgsl keeps two rays) - a wave that holds such a lane takes one step of the general form first.
+            if (METHOD == 1) {
+                const bool odd = (mode == M_REL) & ((cpos.x != rkpos.x) | (cpos.y != rkpos.y) | (cpos.z != rkpos.z) | (cpos_dist != dist_c));
+                if (__any(odd)) {
+                    work_steps += 1u;
+                    {                                        // (the lean text in both builds: the dense text leaves a step with `continue`)
+#define BHRAY_STEP_LEAN 1
+#include "bhray_step.inc"
+#undef BHRAY_STEP_LEAN
+                    }
+                }
+            }
+            F3& upos = METHOD == 0 ? cpos : rkpos;      // the integrator's position and direction
+            F3& udir = METHOD == 0 ? cdir : rkdir;
+            for (int k = 0; k < REL_BATCH; k += 2) {
+                if (!__any(mode == M_REL)) break;
+#define BHRAY_U_FIRST 1
+#include "bhray_step_u.inc"
+#undef BHRAY_U_FIRST
+#define BHRAY_U_FIRST 0
+#include "bhray_step_u.inc"
+#undef BHRAY_U_FIRST
+            }
+            if (mode == M_REL) {                         // between batches every lane's state is exactly the general step's (after the second step of a pair ppos
+                if (METHOD == 1) { cpos = rkpos; cdir = rkdir; }   // is the previous position already): a general step, the iteration limit inside it, the other phases read it
+                pdir = udir;
+                cpos_dist = dist_c;
+            }
+        } else {
         for (int k = 0; k < REL_BATCH; k++) {       // (unrolled by 2 / 4 to let prev = curr become renaming: -1 % / 0 %, measured)
             if (!__any(mode == M_REL)) break;
             if (COUNT && lane == 0) cnt[10]++;
@@ -1397,6 +1459,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
 #include "bhray_step.inc"
 #undef BHRAY_STEP_LEAN
             }
+        }
         }
     }
 
