@@ -217,6 +217,20 @@ __device__ __forceinline__ void black_hole_culls(const HotParams& H, F3 pos, flo
         near_disk = (pos_dist <= H.outer + reach) & (fabsf(numer) <= (1.01f * t_max) * H.bn_len + 1e-4f * H.bn_len);     // & : no branch
     }
 }
+// The same predicates with the plane distance handed in (the unified march has the hole-relative position of the segment's start already: n.(pos - b) is the
+// negative of n.(b - pos) bit for bit - a - b = -(b - a) and fdot's products and sums change sign with their operands - and only its magnitude is used).
+template <bool FOLDED>
+__device__ __forceinline__ void black_hole_culls_rel(const HotParams& H, float numer, float pos_dist, float t_max, bool& near_horizon, bool& near_disk) {
+    if (FOLDED) {
+        const float e = __builtin_fmaf(t_max, -1.05f, pos_dist);
+        near_horizon = e <= 1.05f;
+        near_disk = (e <= H.outer_pad) & (fabsf(numer) <= __builtin_fmaf(t_max, H.plane_c1, H.plane_c2));
+    } else {
+        const float reach = 1.05f * t_max + 0.05f;
+        near_horizon = pos_dist <= 1.0f + reach;
+        near_disk = (pos_dist <= H.outer + reach) & (fabsf(numer) <= (1.01f * t_max) * H.bn_len + 1e-4f * H.bn_len);
+    }
+}
 __device__ __forceinline__ bool hit_black_hole_geom(const HotParams& H, F3 pos, F3 dir, bool near_horizon, bool near_disk, float t_min, float t_max, Hit& rs, float& td_out) {
     const F3 bpos = H.bh;
     float ts = t_max, td = t_max;
@@ -1005,6 +1019,20 @@ template <> struct ColdState<true> {
 
 #include "bhray_quad.inc"
 
+#ifdef BHRAY_WAVE_LOG      // a measurement build (profiles/jobs/r6_wave_log.py): every trace wave leaves a record of when and where it was resident
+__device__ unsigned long long* g_wave_log = nullptr;
+__device__ unsigned g_wave_log_n = 0, g_wave_log_cap = 0;
+}  // namespace bhray
+extern "C" __attribute__((visibility("default"))) int bhray_debug_wave_log(unsigned long long* buf, unsigned cap, unsigned* n_out) {
+    if (n_out) { if (hipMemcpyFromSymbol(n_out, HIP_SYMBOL(bhray::g_wave_log_n), sizeof(unsigned)) != hipSuccess) return -1; }
+    const unsigned zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(bhray::g_wave_log), &buf, sizeof(buf)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(bhray::g_wave_log_cap), &cap, sizeof(cap)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(bhray::g_wave_log_n), &zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
+namespace bhray {
+#endif
 template <int METHOD, bool MODELS, bool COUNT, bool DENSE, int EVAL = 0>
 __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_WAVES_MESH_DENSE : BHRAY_TRACE_WAVES_MESH) : (DENSE ? BHRAY_TRACE_WAVES_DENSE : BHRAY_TRACE_WAVES)) void trace_kernel(const FrameParams* __restrict__ Pb, const FrameLaunch* __restrict__ Fb, const int nb, int* __restrict__ err_flag) {
     const int lane = threadIdx.x & 63;
@@ -1015,6 +1043,9 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
     // span[0] = max(~start) (zero-initialised), span[1] = max(end).
 #ifndef BHRAY_NO_SPAN
     if (Fb[0].span && threadIdx.x == 0) atomicMax(&Fb[0].span[0], ~(unsigned long long)wall_clock64());
+#endif
+#ifdef BHRAY_WAVE_LOG
+    const unsigned long long wl_t0 = wall_clock64();
 #endif
     constexpr int REL_BATCH = (METHOD == 0 && DENSE && !MODELS) ? BHRAY_REL_BATCH_EULER_DENSE : BHRAY_REL_BATCH;
     constexpr int REFILL_MIN = (METHOD == 0 && DENSE && !MODELS) ? BHRAY_REFILL_MIN_EULER_DENSE : BHRAY_REFILL_MIN;
@@ -1430,6 +1461,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
                     }
                 }
             }
+            if (mode == M_REL && it >= H.max_iter) mode = M_FINISH;      // the iteration limit (ray.wgsl:522) in front of the pairs; inside them it is tested where `it` changes
             F3& upos = METHOD == 0 ? cpos : rkpos;      // the integrator's position and direction
             F3& udir = METHOD == 0 ? cdir : rkdir;
             for (int k = 0; k < REL_BATCH; k += 2) {
@@ -1481,6 +1513,18 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
     if (Fb[0].span && threadIdx.x == 0) atomicMax(&Fb[0].span[1], (unsigned long long)wall_clock64());
 #endif
     if (err) *err_flag = err;
+#ifdef BHRAY_WAVE_LOG
+    if (g_wave_log && lanes_below(~0ull) == 0u) {      // one record per wave: start, end (100 MHz), where it ran, how many integrator steps it issued
+        const unsigned i = atomicAdd(&g_wave_log_n, 1u);
+        if (i < g_wave_log_cap) {
+            unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_wave_log[4 * i] = wl_t0; g_wave_log[4 * i + 1] = wall_clock64();
+            g_wave_log[4 * i + 2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+            g_wave_log[4 * i + 3] = (unsigned long long)work_steps | ((unsigned long long)(DENSE ? 1 : 0) << 24) | ((((unsigned long long)(size_t)Fb[0].queue) >> 8) << 32);   // the queue's address: which launch
+        }
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
