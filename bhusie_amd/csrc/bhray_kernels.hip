@@ -563,7 +563,7 @@ __device__ __forceinline__ float pow5(float d) { return ((d * d) * (d * d)) * d;
 // max_(max_(|x|, |y|), |z|) under N5 (compare-select: a < b ? b : a) in three instructions instead of five: t = the IEEE maximum of |y| and |z|
 // (v_max_f32: the operand that is not a NaN, a NaN only when both are), then |x| < t ? t : |x|.  Equal to the compare-select nest for EVERY input:
 // x NaN -> both compares of the nest are false -> |x| (here: the compare is false -> |x|); y or z NaN with x a number -> the nest skips the NaN
-// (so does the maximum); no NaN -> the maximum.  (tests/test_gpu_step_forms.py: all 5^3 combinations of {NaN, +-0, numbers} on the device.)
+// (so does the maximum); no NaN -> the maximum.  (bhray_selftest: 16^3 triples of special values and 2^20 random bit patterns, bit for bit, on the device.)
 __device__ __forceinline__ float max3_abs(float x, float y, float z) {
     float t; asm("v_max_f32 %0, |%1|, |%2|" : "=v"(t) : "v"(y), "v"(z));
     const float ax = fabsf(x);
@@ -1573,6 +1573,28 @@ __global__ __launch_bounds__(256) void selftest_kernel(unsigned long long* __res
         const float c = sqrt_rn(x), d = sqrtf(x);
         if (f2u(c) != f2u(d) && !(c != c && d != d)) ns++;
         if (x > 0.00002f && f2u(pow_m001_step(x)) != f2u(bh_pow_m001(x))) nr++;      // the step-size power on its whole domain
+    }
+    // max3_abs / closest_min against the compare-select forms they replace (N5), bit for bit: every triple / pair of 16 special values (quiet NaNs of
+    // both signs with payloads, infinities, zeros, denormals, numbers) and 2^20 pseudo-random bit patterns
+    {
+        const uint32_t sp[16] = {0x7fc00000u, 0xffc00001u, 0x7fe12345u, 0x7f800000u, 0xff800000u, 0x00000000u, 0x80000000u, 0x00000001u,
+                                 0x807fffffu, 0x00800000u, 0x3f800000u, 0xbf800000u, 0x37a7c5acu, 0x7f7fffffu, 0xff7fffffu, 0x3727c5acu};
+        const unsigned long long gid = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+        if (gid < (1ull << 20)) {
+            uint32_t a, b, c;
+            if (gid < 4096) { a = sp[gid & 15]; b = sp[(gid >> 4) & 15]; c = sp[(gid >> 8) & 15]; }
+            else { a = (uint32_t)gid * 2654435761u; b = a * 2246822519u + 374761393u; c = b * 3266489917u + 668265263u; }
+            // (no SIGNALLING NaNs: arithmetic never produces one, and the operands here are results of arithmetic - e of fused multiply-adds, cd of a square root;
+            // the hardware maximum / minimum would quiet and return one where the compare-select skips it)
+            if ((a & 0x7fc00000u) == 0x7f800000u && (a & 0x003fffffu)) a |= 0x00400000u;
+            if ((b & 0x7fc00000u) == 0x7f800000u && (b & 0x003fffffu)) b |= 0x00400000u;
+            if ((c & 0x7fc00000u) == 0x7f800000u && (c & 0x003fffffu)) c |= 0x00400000u;
+            const float x = u2f(a), y = u2f(b), z = u2f(c);
+            const float want = max_(max_(fabsf(x), fabsf(y)), fabsf(z)), got = max3_abs(x, y, z);
+            if (f2u(want) != f2u(got)) nr++;
+            const float cd = fabsf(x), cl = fabsf(y);                          // distances: no sign; `closest` is never a NaN
+            if (!(cl != cl)) { const float w2 = cd < cl ? cd : cl, g2 = closest_min(cd, cl); if (f2u(w2) != f2u(g2)) nr++; }
+        }
     }
     if (nr) atomicAdd(&bad[0], nr);
     if (ns) atomicAdd(&bad[1], ns);
