@@ -946,6 +946,9 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #ifndef BHRAY_UNIFIED
 #define BHRAY_UNIFIED 1         // the no-mesh contract kernels march in pairs of steps over two position register sets (bhray_step_u.inc): 16 -> 3 register moves per step
 #endif
+#ifndef BHRAY_UNIFIED_MESH
+#define BHRAY_UNIFIED_MESH 1    // ... and the mesh variant's kernels too (RK +1.5-2.2 %, Euler +3.5 % on configs[2]; profiles/EXPERIMENTS.md R6.10)
+#endif
 #ifndef BHRAY_REFILL_MIN
 #define BHRAY_REFILL_MIN 16      // refill from the queue (one atomic on its head + a dependent load) only when this many lanes are empty, or nobody is
                                  // stepping: measured 1 / 8 / 16 / 24 / 32 / 48 -> 5 357 / 5 428 / 5 435 / 5 414 / 5 387 / 5 254 Mrays/s (Euler 8 009 -> 8 148 at 16)
@@ -1049,7 +1052,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
 #endif
     constexpr int REL_BATCH = (METHOD == 0 && DENSE && !MODELS) ? BHRAY_REL_BATCH_EULER_DENSE : BHRAY_REL_BATCH;
     constexpr int REFILL_MIN = (METHOD == 0 && DENSE && !MODELS) ? BHRAY_REFILL_MIN_EULER_DENSE : BHRAY_REFILL_MIN;
-    constexpr bool UNIFIED = BHRAY_UNIFIED != 0 && EVAL == 0 && !MODELS && !COUNT;           // the unified march (bhray_step_u.inc) in the contract kernels without a mesh
+    constexpr bool UNIFIED = BHRAY_UNIFIED != 0 && EVAL == 0 && (!MODELS || BHRAY_UNIFIED_MESH != 0) && !COUNT;           // the unified march (bhray_step_u.inc) in the contract kernels that do not count
     constexpr bool COLD_LDS = (DENSE && !MODELS) || (MODELS && BHRAY_MESH_COLD_LDS != 0);
     constexpr bool MESH_DENSE = MODELS && DENSE;                                              // the mesh variant's build for a saturated device
     constexpr bool MESH_PARK = MESH_DENSE && !COLD_LDS;   // its traversal in a region of its own (see the flat phase)

@@ -5,10 +5,10 @@ fewer in the step's tail made the kernel 1 % slower: profiles/EXPERIMENTS.md R5.
 or an innocent edit losing 10 %.  The bounds are 10 % over the medians of round 5's boxes (BENCH_r05, profiles/r05_bench_*.json) and of
 this round's first runs (gpurun_out/r6_base):
 
-    1920x1080 adaptive RK,  the driver's block (--steps 20 --warmup 5, 22 frames in flight)   <= 0.45 ms per frame   (0.412-0.416 measured)
-    ... one frame at a time (bhray_render + bhray_sync, two speculative levels)              <= 1.30 ms             (1.19-1.21)
-    1920x1080 Euler, the driver's block                                                       <= 0.27 ms             (0.245-0.257)
-    1920x1080 adaptive RK + the 327 680-triangle mesh (configs[2]), the driver's block        <= 0.56 ms             (0.51-0.52)
+    1920x1080 adaptive RK,  the driver's block (--steps 20 --warmup 5, 22 frames in flight)   <= 0.445 ms per frame  (0.401-0.406 since the unified march; 0.412-0.416 before)
+    ... one frame at a time (bhray_render + bhray_sync, two speculative levels)              <= 1.19 ms             (1.06-1.08; 1.19-1.21 in round 5)
+    1920x1080 Euler, the driver's block                                                       <= 0.27 ms             (0.244-0.248)
+    1920x1080 adaptive RK + the 327 680-triangle mesh (configs[2]), the driver's block        <= 0.56 ms             (0.508-0.516)
 
 Measured by `bench.py` itself in a process of its own, and FIRST of the -m gpu files (hence the file's name): a second process that holds
 hardware queues on the device - this pytest process once any other GPU test has run: 24 queues - makes the driver time-slice the two
@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NOMINAL_SELFTEST_MS = 8.1      # bhray_selftest on this round's boxes: 8.03-8.11 ms (gpurun_out/r6_p/selftest_ms.txt)
 SLOW_BOX = 1.08
 
-BOUNDS_MS = {"rk_block": 0.45, "rk_one_frame": 1.30, "euler_block": 0.27, "mesh_block": 0.56}
+BOUNDS_MS = {"rk_block": 0.445, "rk_one_frame": 1.19, "euler_block": 0.27, "mesh_block": 0.56}
 
 
 _SELFTEST = """

@@ -106,3 +106,34 @@ def test_unified_march_equals_the_general_step_dense_builds(general_library, met
     general_library(True); b = frames_of(scenes, tex, frames_in_flight=22, speculative_levels=2)
     general_library(False)
     same_bytes(a, b, f"dense builds, method {method}")
+
+
+@pytest.mark.parametrize("method", [0, 1])
+def test_unified_march_equals_the_general_step_mesh_variant(general_library, tmp_path, method):
+    """The mesh variant's kernels march unified too (the flat phase's BVH traversal between batches finds the general step's state): latency build (one frame)
+    and the dense build with its parked traversal (a full set of slots), a mesh in front of and beside the hole."""
+    from bhusie_amd import assets
+    tex = T.textures()
+    p = tmp_path / "mesh.obj"
+    p.write_text(assets.icosphere_mesh_obj(3, radius=6.0, bump=0.2, seed=11))
+    model = B.load_model(str(p))
+    model.set_transform((-7.0, 1.0, 24.0), 1)
+
+    def frames(cfg, u, n, **kw):
+        rp = B.RayPass(cfg, device=0, **kw)
+        rp.set_textures(*tex); rp.upload_model(model); rp.set_uniforms(*u)
+        for _ in range(n):
+            rp.render()
+        rp.sync()
+        f = rp.read_hdr().copy()
+        rp.close()
+        return f
+    small = B.ladder_from_base((24, 14), 3, 2)
+    big = B.ladder_for_frame((1920, 1080), 3, 4)
+    cases = [(small, T.uniforms(integration_method=method, model_count=1), 1, dict(speculative_levels=0)),
+             (small, T.uniforms(integration_method=method, model_count=1, camera=B.Camera(position=(0.0, 3.0, -45.0), forward=(0.0, -3.0 / 45.1, 45.0 / 45.1), fov=1.0)), 1, dict(speculative_levels=0)),
+             (big, T.uniforms(integration_method=method, model_count=1), 24, dict(frames_in_flight=22, speculative_levels=2))]
+    general_library(False); a = [frames(c, u, n, **kw) for c, u, n, kw in cases]
+    general_library(True); b = [frames(c, u, n, **kw) for c, u, n, kw in cases]
+    general_library(False)
+    same_bytes(a, b, f"mesh variant, method {method}")
