@@ -597,11 +597,16 @@ __device__ constexpr float DB1 = KF(37.0 / 378.0 - 2825.0 / 27648.0),
 // (A form with the (x, y) components of every 3-vector operation in one packed instruction was built and measured: faster in isolation,
 // slower in this kernel - a packed instruction takes no literal, and the kernel has no SGPRs left for the 25 coefficients: EXPERIMENTS.md R3.13.)
 // (`_to`: the new position goes to a register set of its own - the unified march of bhray_step_u.inc alternates two, so that "previous = current" is renaming)
-__device__ __forceinline__ void next_ray_rk_to(const F3 q0, const F3 p0, F3& pos, F3& dir, float& h_io, float dist) {
+// (FAST: the short 1/x and sqrt sequences WITHOUT their range tests and the step size's common arm only; the return value says for which lanes that is
+// not the exact step - an operand outside a sequence's range, or an error estimate above the threshold: the one-test step of bhray_step_u.inc runs the exact
+// form again for those, behind the test every step has anyway.  A wave that runs alone pays ~35 cycles for every test of its own - profiles/EXPERIMENTS.md R6.12.)
+template <bool FAST>
+__device__ __forceinline__ bool next_ray_rk_t(const F3 q0, const F3 p0, F3& pos, F3& dir, float& h_io, float dist) {
     const F3 d0 = dir;                     // q0 = p0 - bpos (N9), carried by the caller together with dist = flength(q0)
     const F3 cr = fcross(p0, d0);
     const float h2 = fdot(cr, cr);                   // N3: pow(length(v), 2.0) = dot(v, v)
-    const float s = (-1.5f * h2) * rcp_rn(pow5(dist));   // N9
+    const float d5 = pow5(dist);
+    const float s = (-1.5f * h2) * (FAST ? rcp_newton(d5) : rcp_rn(d5));   // N9
     const float h = h_io;
     // N10: K_i = h*k_i = (q0 + sum a_ij K_j) * (s*h); zero-coefficient terms (b_2, b*_2) dropped
     const float sh = s * h;
@@ -615,24 +620,47 @@ __device__ __forceinline__ void next_ray_rk_to(const F3 q0, const F3 p0, F3& pos
     const float e_max = max3_abs(e.x, e.y, e.z);
     // the small terms are summed first and added to the unit-length direction once (one rounding at magnitude 1)
     const F3 ds = fmadd3(K6, BA6, fmadd3(K5, BA5, fmadd3(K4, BA4, fmadd3(K3, BA3, K1 * BA1))));
-    dir = fnormalize_rn(d0 + ds);
-    pos = fmadd3(d0, h, p0);
-    if (e_max > 0.00002f) h_io = h * (0.9f * pow_m001_step(e_max));
-    else h_io = h * 1.0001f;
+    if constexpr (FAST) {
+        const F3 v = d0 + ds;
+        const float nn = fdot(v, v);
+        dir = v * rcp_newton(sqrt_corrected(nn));
+        pos = fmadd3(d0, h, p0);
+        h_io = h * 1.0001f;
+        return !rcp_in_range(d5) | !sqrt_in_range(nn) | (e_max > 0.00002f);
+    } else {
+        dir = fnormalize_rn(d0 + ds);
+        pos = fmadd3(d0, h, p0);
+        if (e_max > 0.00002f) h_io = h * (0.9f * pow_m001_step(e_max));
+        else h_io = h * 1.0001f;
+        return false;
+    }
 }
+__device__ __forceinline__ void next_ray_rk_to(const F3 q0, const F3 p0, F3& pos, F3& dir, float& h_io, float dist) { (void)next_ray_rk_t<false>(q0, p0, pos, dir, h_io, dist); }
 __device__ __forceinline__ void next_ray_rk(F3 q0, F3& pos, F3& dir, float& h_io, float dist) {
     const F3 p0 = pos;
     next_ray_rk_to(q0, p0, pos, dir, h_io, dist);
 }
 
 // next_ray_euler, ray.wgsl:467-480 (N7, N9).
-__device__ __forceinline__ void next_ray_euler_to(const F3 q0, const F3 p0, F3& pos, F3& dir, float step, float dist) {
+template <bool FAST>
+__device__ __forceinline__ bool next_ray_euler_t(const F3 q0, const F3 p0, F3& pos, F3& dir, float step, float dist) {
     const F3 cr = fcross(p0, dir);
     const float h2 = fdot(cr, cr);                   // N3: pow(length(v), 2.0) = dot(v, v)
-    const float s = (-1.5f * h2) * rcp_rn(pow5(dist));
-    dir = fnormalize_rn(fmadd3(q0, s * step, dir));   // N9, N10
+    const float d5 = pow5(dist);
+    const float s = (-1.5f * h2) * (FAST ? rcp_newton(d5) : rcp_rn(d5));
+    bool bad = false;
+    if constexpr (FAST) {
+        const F3 v = fmadd3(q0, s * step, dir);
+        const float nn = fdot(v, v);
+        dir = v * rcp_newton(sqrt_corrected(nn));
+        bad = !rcp_in_range(d5) | !sqrt_in_range(nn);
+    } else {
+        dir = fnormalize_rn(fmadd3(q0, s * step, dir));   // N9, N10
+    }
     pos = fmadd3(dir, step, p0);
+    return bad;
 }
+__device__ __forceinline__ void next_ray_euler_to(const F3 q0, const F3 p0, F3& pos, F3& dir, float step, float dist) { (void)next_ray_euler_t<false>(q0, p0, pos, dir, step, dist); }
 __device__ __forceinline__ void next_ray_euler(F3 q0, F3& pos, F3& dir, float step, float dist) {
     const F3 p0 = pos;
     next_ray_euler_to(q0, p0, pos, dir, step, dist);
@@ -946,6 +974,9 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #ifndef BHRAY_UNIFIED
 #define BHRAY_UNIFIED 1         // the no-mesh contract kernels march in pairs of steps over two position register sets (bhray_step_u.inc): 16 -> 3 register moves per step
 #endif
+#ifndef BHRAY_ONE_TEST
+#define BHRAY_ONE_TEST 1        // bit 0: the latency builds, bit 1: the dense builds - the unified march's step with ONE test: the range tests of its short 1/x and sqrt sequences and the
+#endif                          // step-size power's arm folded into the rare-path test every step has (a lane for which they matter runs the exact step again behind it); bit 2 (tests): lanes flagged at random
 #ifndef BHRAY_UNIFIED_MESH
 #define BHRAY_UNIFIED_MESH 1    // ... and the mesh variant's kernels too (RK +1.5-2.2 %, Euler +3.5 % on configs[2]; profiles/EXPERIMENTS.md R6.10)
 #endif
@@ -1053,6 +1084,7 @@ __global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_
     constexpr int REL_BATCH = (METHOD == 0 && DENSE && !MODELS) ? BHRAY_REL_BATCH_EULER_DENSE : BHRAY_REL_BATCH;
     constexpr int REFILL_MIN = (METHOD == 0 && DENSE && !MODELS) ? BHRAY_REFILL_MIN_EULER_DENSE : BHRAY_REFILL_MIN;
     constexpr bool UNIFIED = BHRAY_UNIFIED != 0 && EVAL == 0 && (!MODELS || BHRAY_UNIFIED_MESH != 0) && !COUNT;           // the unified march (bhray_step_u.inc) in the contract kernels that do not count
+    constexpr bool ONE_TEST = UNIFIED && !MODELS && (((BHRAY_ONE_TEST & 1) != 0 && !DENSE) || ((BHRAY_ONE_TEST & 2) != 0 && DENSE));
     constexpr bool COLD_LDS = (DENSE && !MODELS) || (MODELS && BHRAY_MESH_COLD_LDS != 0);
     constexpr bool MESH_DENSE = MODELS && DENSE;                                              // the mesh variant's build for a saturated device
     constexpr bool MESH_PARK = MESH_DENSE && !COLD_LDS;   // its traversal in a region of its own (see the flat phase)

@@ -30,10 +30,12 @@ def frames_of(scenes, tex, **kw):
     return out
 
 
-@pytest.fixture()
-def general_library():
+@pytest.fixture(params=["general", "redo"])
+def general_library(request):
+    """`general`: the general step everywhere (-DBHRAY_UNIFIED=0).  `redo`: the shipped sources with the one-test step's exact second pass forced on an eighth of the
+    steps (-DBHRAY_ONE_TEST=5; the latency builds): the frames must still be the product's, byte for byte - the path real scenes almost never take."""
     from bhusie_amd import _lib, layouts
-    path = T.variant_library("general")
+    path = T.variant_library(request.param)
     saved = _lib.lib()
     L = C.CDLL(path)
     layouts.declare(L)
