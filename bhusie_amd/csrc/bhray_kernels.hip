@@ -58,6 +58,31 @@ __device__ __forceinline__ float4 sample_bilinear(const TexDev& t, float u, floa
     return r;
 }
 
+// The same sample in two halves - the four texel loads issued, then (later) converted and blended - so that a caller with two independent samples has both
+// in flight at once (disk shading; a wave that runs alone waits a memory round trip for each: one frame at a time -0.5 to -1 %, profiles/EXPERIMENTS.md R6.13).
+struct BilinearTaps { uchar4 a, b, c, d; float fx, fy; };
+__device__ __forceinline__ BilinearTaps fetch_bilinear(const TexDev& t, float u, float v) {
+    int x0, x1, y0, y1;
+    BilinearTaps r;
+    r.fx = unit_coord(u, t.w, x0, x1);
+    r.fy = unit_coord(v, t.h, y0, y1);
+    r.a = *reinterpret_cast<const uchar4*>(t.rgba + 4 * ((size_t)y0 * (size_t)t.w + (size_t)x0));
+    r.b = *reinterpret_cast<const uchar4*>(t.rgba + 4 * ((size_t)y0 * (size_t)t.w + (size_t)x1));
+    r.c = *reinterpret_cast<const uchar4*>(t.rgba + 4 * ((size_t)y1 * (size_t)t.w + (size_t)x0));
+    r.d = *reinterpret_cast<const uchar4*>(t.rgba + 4 * ((size_t)y1 * (size_t)t.w + (size_t)x1));
+    return r;
+}
+__device__ __forceinline__ float4 unorm4(uchar4 p) { return make_float4((float)p.x / 255.0f, (float)p.y / 255.0f, (float)p.z / 255.0f, (float)p.w / 255.0f); }
+__device__ __forceinline__ float4 blend_bilinear(const BilinearTaps& t) {
+    const float4 a = unorm4(t.a), b = unorm4(t.b), c = unorm4(t.c), d = unorm4(t.d);
+    float4 r;
+    r.x = mix_(mix_(a.x, b.x, t.fx), mix_(c.x, d.x, t.fx), t.fy);
+    r.y = mix_(mix_(a.y, b.y, t.fx), mix_(c.y, d.y, t.fx), t.fy);
+    r.z = mix_(mix_(a.z, b.z, t.fx), mix_(c.z, d.z, t.fx), t.fy);
+    r.w = mix_(mix_(a.w, b.w, t.fx), mix_(c.w, d.w, t.fx), t.fy);
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------
 // intersections
 // ------------------------------------------------------------------------------------------
@@ -153,6 +178,8 @@ __device__ __forceinline__ void shade_disk(const HotParams& P, F3 pos, F3 dir, f
     rs.opacity = clamp_(od * 0.2f, 0.0f, 1.0f);
     rs.color = f3(od, od, od);
     if (COUNT) cnt[8]++;
+    // The two texture samples do not depend on each other: both sets of texel loads are issued before either is used (the arithmetic and its order are the shader's).
+    BilinearTaps tap_disk, tap_temp;
     if (P.show_tex != 0) {
         float r = (dist - P.inner) / (P.outer - P.inner);
         F3 rel = div_s(ip - bpos, P.outer);
@@ -162,9 +189,7 @@ __device__ __forceinline__ void shade_disk(const HotParams& P, F3 pos, F3 dir, f
         float ph = angle + P.time_rot;        // time * rotation_speed (ray.wgsl:633), one binary32 product, formed on the host
         float u = bh_sincos<0>(ph) * r, v = bh_sincos<1>(ph) * r;
         u = (u + 1.0f) * 0.5f; v = (v + 1.0f) * 0.5f;
-        float4 dc = sample_bilinear(P.disk, u, v);
-        rs.opacity *= clamp_(0.7f + dc.w * 0.5f, 0.0f, 1.0f);
-        rs.color = rs.color * (f3(dc.x, dc.y, dc.z) * dc.w);
+        tap_disk = fetch_bilinear(P.disk, u, v);
     }
     if (P.show_shift != 0) {
         float temp_max = 100000.0f, temp_min = 10000.0f, temp = 15000.0f;
@@ -174,7 +199,15 @@ __device__ __forceinline__ void shade_disk(const HotParams& P, F3 pos, F3 dir, f
         float doppler = sqrtf((1.0f - velocity) / (1.0f + velocity));
         float grav = sqrtf((1.0f - 2.0f / dist) / (1.0f - 2.0f / total_distance));
         float sh = clamp_(grav * doppler, 0.0f, 1.0f);
-        float4 sc = sample_bilinear(P.temp, sh * sh, y);
+        tap_temp = fetch_bilinear(P.temp, sh * sh, y);
+    }
+    if (P.show_tex != 0) {
+        const float4 dc = blend_bilinear(tap_disk);
+        rs.opacity *= clamp_(0.7f + dc.w * 0.5f, 0.0f, 1.0f);
+        rs.color = rs.color * (f3(dc.x, dc.y, dc.z) * dc.w);
+    }
+    if (P.show_shift != 0) {
+        const float4 sc = blend_bilinear(tap_temp);
         rs.color = rs.color * f3(sc.x, sc.y, sc.z);
     }
 }
