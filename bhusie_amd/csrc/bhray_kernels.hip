@@ -535,8 +535,19 @@ __device__ __forceinline__ float sqrt_corrected(float x) {
     const float res = __builtin_fmaf(-s0, s0, x);
     return __builtin_fmaf(res, 0.5f * y, s0);
 }
+#ifndef BHRAY_INT_GUARDS
+#define BHRAY_INT_GUARDS 1     // (A/B against the two-compare form, profiles/r06_ab_int_guards.txt: Euler +1.1 %, RK -0.2 %, one frame at a time 0 to -2 %)
+#endif
+#if BHRAY_INT_GUARDS
+// The same ranges as ONE unsigned compare of the bit pattern (a subtraction and a compare instead of two compares and a scalar OR; no scalar operands): a negative
+// operand or a NaN lands above the range and takes the IEEE lowering, which is exact for every input - the short sequences' results never are used outside
+// [2^-125, 2^126) / [2^-95, 2^95] (bhray_selftest runs rcp_rn / sqrt_rn through these tests over all 2^32 patterns).
+__device__ __forceinline__ bool rcp_in_range(float x) { return (__float_as_uint(x) - 0x01000000u) < 0x7d800000u; }      // 2^-125 <= x < 2^126 (positive x)
+__device__ __forceinline__ bool sqrt_in_range(float x) { return (__float_as_uint(x) - 0x10000000u) <= 0x5f000000u; }    // 2^-95 <= x <= 2^95
+#else
 __device__ __forceinline__ bool rcp_in_range(float x) { return fabsf(x) >= 0x1p-125f && fabsf(x) < 0x1p126f; }
 __device__ __forceinline__ bool sqrt_in_range(float x) { return x >= 0x1p-95f && x <= 0x1p95f; }
+#endif
 // The short sequence is computed unconditionally and REPLACED behind a wave-uniform, never-taken-in-practice branch: the result does
 // not wait for the range test and the step has one not-taken branch per use instead of a diamond (two) - a wave that runs
 // alone on its SIMD pays for every branch (profiles/ubench/lone_wave.hip).
