@@ -1111,8 +1111,11 @@ extern "C" __attribute__((visibility("default"))) int bhray_debug_wave_log(unsig
 }
 namespace bhray {
 #endif
+#ifndef BHRAY_TRACE_KERNEL_ATTR
+#define BHRAY_TRACE_KERNEL_ATTR      // (experiments: e.g. __attribute__((amdgpu_num_sgpr(88))))
+#endif
 template <int METHOD, bool MODELS, bool COUNT, bool DENSE, int EVAL = 0>
-__global__ __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_WAVES_MESH_DENSE : BHRAY_TRACE_WAVES_MESH) : (DENSE ? BHRAY_TRACE_WAVES_DENSE : BHRAY_TRACE_WAVES)) void trace_kernel(const FrameParams* __restrict__ Pb, const FrameLaunch* __restrict__ Fb, const int nb, int* __restrict__ err_flag) {
+__global__ BHRAY_TRACE_KERNEL_ATTR __launch_bounds__(BHRAY_TRACE_THREADS, MODELS ? (DENSE ? BHRAY_TRACE_WAVES_MESH_DENSE : BHRAY_TRACE_WAVES_MESH) : (DENSE ? BHRAY_TRACE_WAVES_DENSE : BHRAY_TRACE_WAVES)) void trace_kernel(const FrameParams* __restrict__ Pb, const FrameLaunch* __restrict__ Fb, const int nb, int* __restrict__ err_flag) {
     const int lane = threadIdx.x & 63;
     int err = 0;
     // Execution span of this launch (timed batches only: Fb[0].span != nullptr): first block's start and last block's end on the
