@@ -1021,6 +1021,9 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #ifndef BHRAY_ONE_TEST
 #define BHRAY_ONE_TEST 1        // bit 0: the latency builds, bit 1: the dense builds - the unified march's step with ONE test: the range tests of its short 1/x and sqrt sequences and the
 #endif                          // step-size power's arm folded into the rare-path test every step has (a lane for which they matter runs the exact step again behind it); bit 2 (tests): lanes flagged at random
+#ifndef BHRAY_ORIGIN_PATH
+#define BHRAY_ORIGIN_PATH 1      // bit 0: Euler, bit 1: RK - a second copy of the unified pairs for a hole at the scene's origin (no position - bpos per step): Euler +1.7 %; RK -1.8 % (the doubled loop costs its kernel 48 bytes of scratch in the phases): Euler only
+#endif
 #ifndef BHRAY_UNIFIED_MESH
 #define BHRAY_UNIFIED_MESH 1    // ... and the mesh variant's kernels too (RK +1.5-2.2 %, Euler +3.5 % on configs[2]; profiles/EXPERIMENTS.md R6.10)
 #endif
@@ -1546,6 +1549,22 @@ __global__ BHRAY_TRACE_KERNEL_ATTR __launch_bounds__(BHRAY_TRACE_THREADS, MODELS
             if (mode == M_REL && it >= H.max_iter) mode = M_FINISH;      // the iteration limit (ray.wgsl:522) in front of the pairs; inside them it is tested where `it` changes
             F3& upos = METHOD == 0 ? cpos : rkpos;      // the integrator's position and direction
             F3& udir = METHOD == 0 ? cdir : rkdir;
+            // (the hole at the origin - all three words +0, wave-uniform: a scalar test - marches without forming position - bpos: see bhray_step_u.inc)
+            if (!MODELS && (BHRAY_ORIGIN_PATH & (1 << METHOD)) != 0 && ((__float_as_uint(H.bh.x) | __float_as_uint(H.bh.y) | __float_as_uint(H.bh.z)) == 0u)) {
+#define BHRAY_U_ORIGIN 1
+                for (int k = 0; k < REL_BATCH; k += 2) {
+                    if (!__any(mode == M_REL)) break;
+#define BHRAY_U_FIRST 1
+#include "bhray_step_u.inc"
+#undef BHRAY_U_FIRST
+#define BHRAY_U_FIRST 0
+#include "bhray_step_u.inc"
+#undef BHRAY_U_FIRST
+                }
+                if (mode == M_REL) qrel = upos;
+#undef BHRAY_U_ORIGIN
+            } else {
+#define BHRAY_U_ORIGIN 0
             for (int k = 0; k < REL_BATCH; k += 2) {
                 if (!__any(mode == M_REL)) break;
 #define BHRAY_U_FIRST 1
@@ -1554,6 +1573,8 @@ __global__ BHRAY_TRACE_KERNEL_ATTR __launch_bounds__(BHRAY_TRACE_THREADS, MODELS
 #define BHRAY_U_FIRST 0
 #include "bhray_step_u.inc"
 #undef BHRAY_U_FIRST
+            }
+#undef BHRAY_U_ORIGIN
             }
             if (mode == M_REL) {                         // between batches every lane's state is exactly the general step's (after the second step of a pair ppos
                 if (METHOD == 1) { cpos = rkpos; cdir = rkdir; }   // is the previous position already): a general step, the iteration limit inside it, the other phases read it

@@ -34,9 +34,15 @@ def ctx(**kw):
 """ % ROOT
 
 
-def _run(body, env, timeout=180):
+def _run(body, env, timeout=240):
     e = dict(os.environ); e.update(env)
-    r = subprocess.run([sys.executable, "-c", PRELUDE + textwrap.dedent(body)], capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=e)
+    cmd = [sys.executable, "-c", PRELUDE + textwrap.dedent(body)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=e)
+    except subprocess.TimeoutExpired:
+        # Seen once in eight runs of the suite (round 6, on a box on which every test took three times as long): the child - eight partitions of ONE device,
+        # an aborted communicator, then a second ctx in the same process - did not finish in 180 s.  One more try in a fresh process; a second timeout fails.
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=2 * timeout, cwd=ROOT, env=e)
     assert r.returncode == 0, "stdout:\n" + r.stdout[-3000:] + "\nstderr:\n" + r.stderr[-3000:]
     return r
 

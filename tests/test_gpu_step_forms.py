@@ -103,7 +103,9 @@ def test_unified_march_equals_the_general_step_dense_builds(general_library, met
     tex = T.textures()
     cfg = B.ladder_for_frame((1920, 1080), 3, 4)
     scenes = [(cfg, T.uniforms(integration_method=method), 24),
-              (cfg, T.uniforms(integration_method=method, max_iterations=301, camera=B.Camera(position=(2.0, 1.0, -25.0), forward=(-0.08, -0.04, 1.0), fov=1.3)), 24)]
+              (cfg, T.uniforms(integration_method=method, max_iterations=301, camera=B.Camera(position=(2.0, 1.0, -25.0), forward=(-0.08, -0.04, 1.0), fov=1.3)), 24),
+              (cfg, T.uniforms(integration_method=method, black_hole=B.BlackHole(position=(1.5, -0.75, 2.0))), 24),      # hole off the origin: the pairs that form position - bpos
+              (cfg, T.uniforms(integration_method=method, black_hole=B.BlackHole(position=(-0.0, 0.0, 0.0))), 24)]       # a NEGATIVE zero is not the origin path's case (x - (-0) is not x for x = -0)
     general_library(False); a = frames_of(scenes, tex, frames_in_flight=22, speculative_levels=2)
     general_library(True); b = frames_of(scenes, tex, frames_in_flight=22, speculative_levels=2)
     general_library(False)
