@@ -1021,6 +1021,9 @@ enum : int { M_EMPTY = 0, M_REL = 1, M_FLAT = 2, M_FINISH = 3, M_SHADE_REL = 4, 
 #ifndef BHRAY_ONE_TEST
 #define BHRAY_ONE_TEST 1        // bit 0: the latency builds, bit 1: the dense builds - the unified march's step with ONE test: the range tests of its short 1/x and sqrt sequences and the
 #endif                          // step-size power's arm folded into the rare-path test every step has (a lane for which they matter runs the exact step again behind it); bit 2 (tests): lanes flagged at random
+#ifndef BHRAY_PNUMER_EARLY
+#define BHRAY_PNUMER_EARLY 1
+#endif
 #ifndef BHRAY_ORIGIN_PATH
 #define BHRAY_ORIGIN_PATH 1      // bit 0: Euler, bit 1: RK - a second copy of the unified pairs for a hole at the scene's origin (no position - bpos per step): Euler +1.7 %; RK -1.8 % (the doubled loop costs its kernel 48 bytes of scratch in the phases): Euler only
 #endif
